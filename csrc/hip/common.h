@@ -1,0 +1,77 @@
+// Shared device helpers for the gfx950 (MI355X / CDNA4) kernels.  Wave = 64 lanes everywhere.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef uint16_t bf16_t;   // raw bfloat16 bits; activations/weights are bf16, accumulation fp32
+
+typedef __attribute__((ext_vector_type(8))) short s16x8;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+#define DDL_API extern "C" __attribute__((visibility("default")))
+
+enum Act { ACT_LINEAR = 0, ACT_RELU = 1, ACT_SIGMOID = 2, ACT_SOFTPLUS = 3, ACT_TANH = 4,
+           ACT_SOFTSIGN = 5, ACT_LEAKY = 6, ACT_TANH01 = 7 };
+
+__device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
+
+// Plain cast: hipcc emits v_cvt_pk_bf16_f32 (RNE, NaN stays NaN).
+__device__ __forceinline__ bf16_t f2bf(float f) {
+    __bf16 b = (__bf16)f;
+    return __builtin_bit_cast(bf16_t, b);
+}
+
+__device__ __forceinline__ uint32_t pack2bf(float lo, float hi) {
+    return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
+}
+
+__device__ __forceinline__ void unpack8(const uint4& v, float* f) {
+    f[0] = __uint_as_float(v.x << 16); f[1] = __uint_as_float(v.x & 0xffff0000u);
+    f[2] = __uint_as_float(v.y << 16); f[3] = __uint_as_float(v.y & 0xffff0000u);
+    f[4] = __uint_as_float(v.z << 16); f[5] = __uint_as_float(v.z & 0xffff0000u);
+    f[6] = __uint_as_float(v.w << 16); f[7] = __uint_as_float(v.w & 0xffff0000u);
+}
+
+__device__ __forceinline__ uint4 pack8(const float* f) {
+    uint4 v;
+    v.x = pack2bf(f[0], f[1]); v.y = pack2bf(f[2], f[3]);
+    v.z = pack2bf(f[4], f[5]); v.w = pack2bf(f[6], f[7]);
+    return v;
+}
+
+__device__ __forceinline__ float act_apply(float x, int kind, float alpha) {
+    switch (kind) {
+        case ACT_RELU: return fmaxf(x, 0.f);
+        case ACT_SIGMOID: return 1.f / (1.f + __expf(-x));
+        case ACT_SOFTPLUS: return x > 20.f ? x : log1pf(__expf(x));
+        case ACT_TANH: return tanhf(x);
+        case ACT_SOFTSIGN: return x / (1.f + fabsf(x));
+        case ACT_LEAKY: return x > 0.f ? x : alpha * x;
+        case ACT_TANH01: return 0.5f * (tanhf(x) + 1.f);
+        default: return x;
+    }
+}
+
+// d act(x)/dx written through the OUTPUT y = act(x) (no pre-activation is ever stored).
+__device__ __forceinline__ float act_grad_y(float y, int kind, float alpha) {
+    switch (kind) {
+        case ACT_RELU: return y > 0.f ? 1.f : 0.f;
+        case ACT_SIGMOID: return y * (1.f - y);
+        case ACT_SOFTPLUS: return 1.f - __expf(-y);
+        case ACT_TANH: return 1.f - y * y;
+        case ACT_SOFTSIGN: { float t = 1.f - fabsf(y); return t * t; }
+        case ACT_LEAKY: return y > 0.f ? 1.f : alpha;
+        case ACT_TANH01: { float t = 2.f * y - 1.f; return 0.5f * (1.f - t * t); }
+        default: return 1.f;
+    }
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+static inline int ceil_div(long a, long b) { return (int)((a + b - 1) / b); }

@@ -1,0 +1,433 @@
+// Memory-bound kernels: activations, BatchNorm (stats / apply / backward), bias gradient, casts,
+// weight relayout, channel padding, dataset gather.  All tensors are [rows][C] with C a
+// multiple of 8 so every access is a 16-byte vector (8 x bf16) per lane.
+#include "common.h"
+
+#define EW_BLOCK 256
+#define EW_MAX_GRID 2048
+
+static inline int ew_grid(long n_groups) {
+    long g = (n_groups + EW_BLOCK - 1) / EW_BLOCK;
+    return (int)(g < 1 ? 1 : (g > EW_MAX_GRID ? EW_MAX_GRID : g));
+}
+
+// ------------------------------------------------------------------------------ activations
+__global__ void act_fwd_kernel(const uint4* __restrict__ x, uint4* __restrict__ y, long n8, int cg,
+                               int c_true, int kind, float alpha) {
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n8; i += (long)gridDim.x * blockDim.x) {
+        float f[8];
+        unpack8(x[i], f);
+        int c0 = (int)(i % cg) * 8;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) f[j] = (c0 + j < c_true) ? act_apply(f[j], kind, alpha) : 0.f;
+        y[i] = pack8(f);
+    }
+}
+
+__global__ void act_bwd_kernel(const uint4* __restrict__ dy, const uint4* __restrict__ y,
+                               uint4* __restrict__ dx, long n8, int kind, float alpha) {
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n8; i += (long)gridDim.x * blockDim.x) {
+        float g[8], v[8];
+        unpack8(dy[i], g);
+        unpack8(y[i], v);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) g[j] *= act_grad_y(v[j], kind, alpha);
+        dx[i] = pack8(g);
+    }
+}
+
+DDL_API void ddl_act_fwd(const void* x, void* y, long rows, int C, int c_true, int kind, float alpha,
+                         hipStream_t s) {
+    long n8 = rows * (C / 8);
+    act_fwd_kernel<<<ew_grid(n8), EW_BLOCK, 0, s>>>((const uint4*)x, (uint4*)y, n8, C / 8, c_true, kind, alpha);
+}
+
+DDL_API void ddl_act_bwd(const void* dy, const void* y, void* dx, long n, int kind, float alpha,
+                         hipStream_t s) {
+    long n8 = n / 8;
+    act_bwd_kernel<<<ew_grid(n8), EW_BLOCK, 0, s>>>((const uint4*)dy, (const uint4*)y, (uint4*)dx, n8, kind, alpha);
+}
+
+// ------------------------------------------------------------------------------ column reductions
+// One kernel shape for the three per-channel reductions over rows:
+//   MODE 0 (stats):   s0 = sum x          s1 = sum x^2
+//   MODE 1 (bn bwd):  s0 = sum g          s1 = sum g * xhat      g = dy * act'(y)
+//   MODE 2 (colsum):  s0 = sum dy
+// Block partials go to part[block][2][C]; a finalize kernel combines them in fp64 (deterministic).
+template <int MODE>
+__global__ __launch_bounds__(EW_BLOCK) void colreduce_kernel(
+    const uint4* __restrict__ a, const uint4* __restrict__ b, const uint4* __restrict__ yv,
+    const float* __restrict__ mean, const float* __restrict__ invstd, float* __restrict__ part,
+    long rows, int C, int act, float alpha) {
+    __shared__ float red[EW_BLOCK][17];
+    const int cg = C / 8;
+    const int cgl = cg < EW_BLOCK ? cg : EW_BLOCK;           // channel groups handled by this block column
+    const int rpi = EW_BLOCK / cgl;                            // rows per block iteration
+    const int g = blockIdx.y * EW_BLOCK + (threadIdx.x % cgl);
+    const int rl = threadIdx.x / cgl;
+    float s0[8], s1[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s0[j] = s1[j] = 0.f;
+    const bool active = rl < rpi && g < cg;
+    if (active) {
+        float mu[8], is[8];
+        if (MODE == 1) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { mu[j] = mean[g * 8 + j]; is[j] = invstd[g * 8 + j]; }
+        }
+        for (long r = blockIdx.x * (long)rpi + rl; r < rows; r += (long)gridDim.x * rpi) {
+            float v[8];
+            unpack8(a[r * cg + g], v);
+            if (MODE == 0) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { s0[j] += v[j]; s1[j] += v[j] * v[j]; }
+            } else if (MODE == 1) {
+                float x[8], yy[8];
+                unpack8(b[r * cg + g], x);
+                if (act != ACT_LINEAR) {
+                    unpack8(yv[r * cg + g], yy);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) v[j] *= act_grad_y(yy[j], act, alpha);
+                }
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { s0[j] += v[j]; s1[j] += v[j] * (x[j] - mu[j]) * is[j]; }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) s0[j] += v[j];
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { red[threadIdx.x][j] = s0[j]; red[threadIdx.x][8 + j] = s1[j]; }
+    __syncthreads();
+    if (rl == 0 && g < cg) {
+        for (int q = 1; q < rpi; ++q) {
+#pragma unroll
+            for (int j = 0; j < 16; ++j) red[threadIdx.x][j] += red[threadIdx.x + q * cgl][j];
+        }
+        float* p = part + (size_t)blockIdx.x * 2 * C;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { p[g * 8 + j] = red[threadIdx.x][j]; p[C + g * 8 + j] = red[threadIdx.x][8 + j]; }
+    }
+}
+
+static inline void colreduce_grid(long rows, int C, dim3* grid) {
+    int cg = C / 8;
+    int cgl = cg < EW_BLOCK ? cg : EW_BLOCK;
+    int rpi = EW_BLOCK / cgl;
+    long nb = (rows + (long)rpi * 8 - 1) / ((long)rpi * 8);      // >= 8 rows per thread
+    if (nb < 1) nb = 1;
+    if (nb > 1024) nb = 1024;
+    *grid = dim3((unsigned)nb, (unsigned)((cg + EW_BLOCK - 1) / EW_BLOCK), 1);
+}
+
+DDL_API int ddl_colreduce_blocks(long rows, int C) {
+    dim3 g;
+    colreduce_grid(rows, C, &g);
+    return (int)g.x;
+}
+
+// BN forward statistics -> per-channel affine (scale, shift), saved (mean, invstd), moving update.
+__global__ void bn_stats_finalize_kernel(const float* __restrict__ part, int nblocks, int C, long rows,
+                                         const float* __restrict__ gamma, const float* __restrict__ beta,
+                                         float* __restrict__ mm, float* __restrict__ mv, float momentum,
+                                         float eps, int bessel, int update_moving, float* __restrict__ scale,
+                                         float* __restrict__ shift, float* __restrict__ mean_out,
+                                         float* __restrict__ invstd_out) {
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double s0 = 0, s1 = 0;
+    for (int b = 0; b < nblocks; ++b) { s0 += part[(size_t)b * 2 * C + c]; s1 += part[(size_t)b * 2 * C + C + c]; }
+    double mean = s0 / (double)rows;
+    double var = s1 / (double)rows - mean * mean;
+    if (var < 0) var = 0;
+    float is = rsqrtf((float)var + eps);
+    float sc = gamma[c] * is;
+    scale[c] = sc;
+    shift[c] = beta[c] - (float)mean * sc;
+    mean_out[c] = (float)mean;
+    invstd_out[c] = is;
+    if (update_moving) {
+        double v = bessel && rows > 1 ? var * ((double)rows / (double)(rows - 1)) : var;
+        mm[c] = mm[c] * momentum + (float)mean * (1.f - momentum);
+        mv[c] = mv[c] * momentum + (float)v * (1.f - momentum);
+    }
+}
+
+DDL_API void ddl_bn_batch_stats(const void* x, long rows, int C, float* part, const float* gamma,
+                                const float* beta, float* mm, float* mv, float momentum, float eps, int bessel,
+                                int update_moving, float* scale, float* shift, float* mean, float* invstd,
+                                hipStream_t s) {
+    dim3 grid;
+    colreduce_grid(rows, C, &grid);
+    colreduce_kernel<0><<<grid, EW_BLOCK, 0, s>>>((const uint4*)x, nullptr, nullptr, nullptr, nullptr, part,
+                                                  rows, C, 0, 0.f);
+    bn_stats_finalize_kernel<<<(C + 127) / 128, 128, 0, s>>>(part, grid.x, C, rows, gamma, beta, mm, mv,
+                                                             momentum, eps, bessel, update_moving, scale,
+                                                             shift, mean, invstd);
+}
+
+// Inference-phase BN: scale/shift from the moving statistics (tiny, one launch).
+__global__ void bn_infer_affine_kernel(const float* gamma, const float* beta, const float* mm, const float* mv,
+                                       float eps, int C, float* scale, float* shift, float* invstd) {
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    float is = rsqrtf(mv[c] + eps);
+    float sc = gamma[c] * is;
+    scale[c] = sc;
+    shift[c] = beta[c] - mm[c] * sc;
+    invstd[c] = is;
+}
+
+DDL_API void ddl_bn_infer_affine(const float* gamma, const float* beta, const float* mm, const float* mv,
+                                 float eps, int C, float* scale, float* shift, float* invstd, hipStream_t s) {
+    bn_infer_affine_kernel<<<(C + 127) / 128, 128, 0, s>>>(gamma, beta, mm, mv, eps, C, scale, shift, invstd);
+}
+
+__global__ void bn_apply_kernel(const uint4* __restrict__ x, uint4* __restrict__ y,
+                                const float* __restrict__ scale, const float* __restrict__ shift, long n8,
+                                int cg, int c_true, int act, float alpha) {
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n8; i += (long)gridDim.x * blockDim.x) {
+        int c0 = (int)(i % cg) * 8;
+        float f[8];
+        unpack8(x[i], f);
+        const float4 sa = *(const float4*)(scale + c0), sb = *(const float4*)(scale + c0 + 4);
+        const float4 ha = *(const float4*)(shift + c0), hb = *(const float4*)(shift + c0 + 4);
+        const float sc[8] = {sa.x, sa.y, sa.z, sa.w, sb.x, sb.y, sb.z, sb.w};
+        const float sh[8] = {ha.x, ha.y, ha.z, ha.w, hb.x, hb.y, hb.z, hb.w};
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            f[j] = (c0 + j < c_true) ? act_apply(fmaf(f[j], sc[j], sh[j]), act, alpha) : 0.f;
+        y[i] = pack8(f);
+    }
+}
+
+DDL_API void ddl_bn_apply(const void* x, void* y, const float* scale, const float* shift, long rows, int C,
+                          int c_true, int act, float alpha, hipStream_t s) {
+    long n8 = rows * (C / 8);
+    bn_apply_kernel<<<ew_grid(n8), EW_BLOCK, 0, s>>>((const uint4*)x, (uint4*)y, scale, shift, n8, C / 8,
+                                                     c_true, act, alpha);
+}
+
+// BN backward: reduce -> finalize (dgamma, dbeta, c1 = dbeta/M, c2 = dgamma/M) -> apply.
+__global__ void bn_bwd_finalize_kernel(const float* __restrict__ part, int nblocks, int C, long rows,
+                                       int train_stats, float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                       float* __restrict__ c1, float* __restrict__ c2) {
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double s0 = 0, s1 = 0;
+    for (int b = 0; b < nblocks; ++b) { s0 += part[(size_t)b * 2 * C + c]; s1 += part[(size_t)b * 2 * C + C + c]; }
+    if (dbeta) dbeta[c] = (float)s0;
+    if (dgamma) dgamma[c] = (float)s1;
+    c1[c] = train_stats ? (float)(s0 / (double)rows) : 0.f;
+    c2[c] = train_stats ? (float)(s1 / (double)rows) : 0.f;
+}
+
+__global__ void bn_bwd_apply_kernel(const uint4* __restrict__ dy, const uint4* __restrict__ x,
+                                    const uint4* __restrict__ yv, uint4* __restrict__ dx,
+                                    const float* __restrict__ mean, const float* __restrict__ invstd,
+                                    const float* __restrict__ gamma, const float* __restrict__ c1,
+                                    const float* __restrict__ c2, long n8, int cg, int act, float alpha,
+                                    int prev_act, float prev_alpha) {
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n8; i += (long)gridDim.x * blockDim.x) {
+        int c0 = (int)(i % cg) * 8;
+        float g[8], xv[8], yy[8];
+        unpack8(dy[i], g);
+        unpack8(x[i], xv);
+        if (act != ACT_LINEAR) {
+            unpack8(yv[i], yy);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) g[j] *= act_grad_y(yy[j], act, alpha);
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            int c = c0 + j;
+            float is = invstd[c];
+            float xhat = (xv[j] - mean[c]) * is;
+            float d = gamma[c] * is * (g[j] - c1[c] - xhat * c2[c]);
+            if (prev_act != ACT_LINEAR) d *= act_grad_y(xv[j], prev_act, prev_alpha);
+            g[j] = d;
+        }
+        dx[i] = pack8(g);
+    }
+}
+
+DDL_API void ddl_bn_bwd(const void* dy, const void* x, const void* y, void* dx, long rows, int C,
+                        const float* mean, const float* invstd, const float* gamma, int act, float alpha,
+                        int train_stats, int prev_act, float prev_alpha, float* part, float* dgamma,
+                        float* dbeta, float* c1, float* c2, hipStream_t s) {
+    dim3 grid;
+    colreduce_grid(rows, C, &grid);
+    colreduce_kernel<1><<<grid, EW_BLOCK, 0, s>>>((const uint4*)dy, (const uint4*)x, (const uint4*)y, mean,
+                                                  invstd, part, rows, C, act, alpha);
+    bn_bwd_finalize_kernel<<<(C + 127) / 128, 128, 0, s>>>(part, grid.x, C, rows, train_stats, dgamma, dbeta,
+                                                           c1, c2);
+    long n8 = rows * (C / 8);
+    bn_bwd_apply_kernel<<<ew_grid(n8), EW_BLOCK, 0, s>>>((const uint4*)dy, (const uint4*)x, (const uint4*)y,
+                                                         (uint4*)dx, mean, invstd, gamma, c1, c2, n8, C / 8,
+                                                         act, alpha, prev_act, prev_alpha);
+}
+
+// bias gradient = per-channel column sum of dY
+__global__ void colsum_finalize_kernel(const float* __restrict__ part, int nblocks, int C, int c_out,
+                                       float* __restrict__ out) {
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= c_out) return;
+    double s0 = 0;
+    for (int b = 0; b < nblocks; ++b) s0 += part[(size_t)b * 2 * C + c];
+    out[c] = (float)s0;
+}
+
+DDL_API void ddl_bias_grad(const void* dy, long rows, int C, int c_out, float* part, float* out,
+                           hipStream_t s) {
+    dim3 grid;
+    colreduce_grid(rows, C, &grid);
+    colreduce_kernel<2><<<grid, EW_BLOCK, 0, s>>>((const uint4*)dy, nullptr, nullptr, nullptr, nullptr, part,
+                                                  rows, C, 0, 0.f);
+    colsum_finalize_kernel<<<(c_out + 127) / 128, 128, 0, s>>>(part, grid.x, C, c_out, out);
+}
+
+// ------------------------------------------------------------------------------ casts / layout
+__global__ void cast_f32_bf16_kernel(const float4* __restrict__ src, uint2* __restrict__ dst, long n4) {
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+        float4 v = src[i];
+        dst[i] = make_uint2(pack2bf(v.x, v.y), pack2bf(v.z, v.w));
+    }
+}
+
+DDL_API void ddl_cast_f32_bf16(const float* src, void* dst, long n, hipStream_t s) {
+    long n4 = n / 4;     // flat buffers are padded to multiples of 8 elements
+    cast_f32_bf16_kernel<<<ew_grid(n4), EW_BLOCK, 0, s>>>((const float4*)src, (uint2*)dst, n4);
+}
+
+// Alternate-layout weights for the adjoint direction: canonical [R][T][C] (fp32 master) ->
+// [Cp][T][Rp] (bf16), zero-filled where r >= R.  One launch handles every layer of a network
+// through a descriptor table (blockIdx.y = layer).
+struct RelayoutDesc { long src_off; long dst_off; int R, T, C, Rp; };
+
+__global__ void relayout_alt_kernel(const float* __restrict__ P, bf16_t* __restrict__ alt,
+                                    const RelayoutDesc* __restrict__ descs) {
+    const RelayoutDesc d = descs[blockIdx.y];
+    const long total = (long)d.C * d.T * d.Rp;
+    const float* src = P + d.src_off;
+    bf16_t* dst = alt + d.dst_off;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        int r = (int)(i % d.Rp);
+        long q = i / d.Rp;
+        int t = (int)(q % d.T);
+        int c = (int)(q / d.T);
+        float v = r < d.R ? src[((long)r * d.T + t) * d.C + c] : 0.f;
+        dst[i] = f2bf(v);
+    }
+}
+
+DDL_API void ddl_relayout_alt(const float* P, void* alt, const void* descs, int n_layers, long max_elems,
+                              hipStream_t s) {
+    if (n_layers <= 0) return;
+    int gx = ew_grid(max_elems);
+    if (gx > 256) gx = 256;
+    relayout_alt_kernel<<<dim3(gx, n_layers), EW_BLOCK, 0, s>>>(P, (bf16_t*)alt, (const RelayoutDesc*)descs);
+}
+
+// [rows][c_in] (bf16 or fp32 or u8) -> [rows][Cp] bf16, channel c copied (or replicated when
+// c_in == 1 and c_true > 1: the reference stacks MNIST to 3 channels, DDL.py:119), pad = 0.
+template <typename T>
+__device__ __forceinline__ float load_as_float(const T* p, long i);
+template <> __device__ __forceinline__ float load_as_float<float>(const float* p, long i) { return p[i]; }
+template <> __device__ __forceinline__ float load_as_float<uint8_t>(const uint8_t* p, long i) { return (float)p[i]; }
+template <> __device__ __forceinline__ float load_as_float<bf16_t>(const bf16_t* p, long i) { return bf2f(p[i]); }
+
+template <typename T>
+__global__ void pad_channels_kernel(const T* __restrict__ src, const long* __restrict__ index,
+                                    bf16_t* __restrict__ dst, long rows, int pix_per_sample, int c_in,
+                                    int c_true, int Cp, float scale) {
+    const long total = rows * Cp;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        int c = (int)(i % Cp);
+        long r = i / Cp;
+        float v = 0.f;
+        if (c < c_true) {
+            long sr = r;
+            if (index) { long smp = r / pix_per_sample; sr = index[smp] * pix_per_sample + (r - smp * pix_per_sample); }
+            v = load_as_float<T>(src, sr * c_in + (c_in == 1 ? 0 : c)) * scale;
+        }
+        dst[i] = f2bf(v);
+    }
+}
+
+// dtype: 0 = fp32, 1 = u8, 2 = bf16.  `index` (optional, int64 per sample) gathers samples.
+DDL_API void ddl_pad_channels(const void* src, int dtype, const long* index, void* dst, long rows,
+                              int pix_per_sample, int c_in, int c_true, int Cp, float scale, hipStream_t s) {
+    long total = rows * Cp;
+    int grid = ew_grid(total);
+    if (dtype == 0)
+        pad_channels_kernel<float><<<grid, EW_BLOCK, 0, s>>>((const float*)src, index, (bf16_t*)dst, rows,
+                                                             pix_per_sample, c_in, c_true, Cp, scale);
+    else if (dtype == 1)
+        pad_channels_kernel<uint8_t><<<grid, EW_BLOCK, 0, s>>>((const uint8_t*)src, index, (bf16_t*)dst, rows,
+                                                               pix_per_sample, c_in, c_true, Cp, scale);
+    else
+        pad_channels_kernel<bf16_t><<<grid, EW_BLOCK, 0, s>>>((const bf16_t*)src, index, (bf16_t*)dst, rows,
+                                                              pix_per_sample, c_in, c_true, Cp, scale);
+}
+
+// [rows][Cp] bf16 -> [rows][c_true] fp32 (strip padding; used for predictions / export of activations)
+__global__ void strip_channels_kernel(const bf16_t* __restrict__ src, float* __restrict__ dst, long rows,
+                                      int Cp, int c_true) {
+    const long total = rows * c_true;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        int c = (int)(i % c_true);
+        long r = i / c_true;
+        dst[i] = bf2f(src[r * Cp + c]);
+    }
+}
+
+DDL_API void ddl_strip_channels(const void* src, float* dst, long rows, int Cp, int c_true, hipStream_t s) {
+    strip_channels_kernel<<<ew_grid(rows * c_true), EW_BLOCK, 0, s>>>((const bf16_t*)src, dst, rows, Cp, c_true);
+}
+
+// Spatial zero padding / cropping of an NHWC tensor (ZeroPadding2D and its backward).
+__global__ void spatial_pad_kernel(const uint4* __restrict__ src, uint4* __restrict__ dst, int B, int Hs, int Ws,
+                                   int Hd, int Wd, int cg, int off_h, int off_w) {
+    const long total = (long)B * Hd * Wd * cg;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        int g = (int)(i % cg);
+        long p = i / cg;
+        int w = (int)(p % Wd);
+        long q = p / Wd;
+        int h = (int)(q % Hd);
+        int b = (int)(q / Hd);
+        int hs = h - off_h, ws = w - off_w;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if ((unsigned)hs < (unsigned)Hs && (unsigned)ws < (unsigned)Ws)
+            v = src[(((long)b * Hs + hs) * Ws + ws) * cg + g];
+        dst[i] = v;
+    }
+}
+
+// dst[b][h][w] = src[b][h - off_h][w - off_w] (zero outside); negative offsets crop.
+DDL_API void ddl_spatial_pad(const void* src, void* dst, int B, int Hs, int Ws, int Hd, int Wd, int C,
+                             int off_h, int off_w, hipStream_t s) {
+    long total = (long)B * Hd * Wd * (C / 8);
+    spatial_pad_kernel<<<ew_grid(total), EW_BLOCK, 0, s>>>((const uint4*)src, (uint4*)dst, B, Hs, Ws, Hd, Wd,
+                                                           C / 8, off_h, off_w);
+}
+
+// y = x * scale + shift on a bf16 tensor (generic Lambda-affine), padding channels kept zero.
+__global__ void affine_kernel(const uint4* __restrict__ x, uint4* __restrict__ y, long n8, int cg, int c_true,
+                              float scale, float shift) {
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n8; i += (long)gridDim.x * blockDim.x) {
+        float f[8];
+        unpack8(x[i], f);
+        int c0 = (int)(i % cg) * 8;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) f[j] = (c0 + j < c_true) ? fmaf(f[j], scale, shift) : 0.f;
+        y[i] = pack8(f);
+    }
+}
+
+DDL_API void ddl_affine(const void* x, void* y, long rows, int C, int c_true, float scale, float shift,
+                        hipStream_t s) {
+    long n8 = rows * (C / 8);
+    affine_kernel<<<ew_grid(n8), EW_BLOCK, 0, s>>>((const uint4*)x, (uint4*)y, n8, C / 8, c_true, scale, shift);
+}

@@ -1,0 +1,238 @@
+// Implicit-GEMM convolution on the gfx950 matrix cores (v_mfma_f32_16x16x32_bf16).
+//
+// One kernel serves Conv2D forward (fprop), Conv2DTranspose forward / Conv2D backward-data
+// (dgrad) and Dense: everything is phrased as a *class grid* problem
+//
+//   dst[b, ph + sdh*i, pw + sdw*j, n] = act( bias[n] +
+//        sum_{t < ntaps} sum_{c < Cs} src[b, i*ssh + offh[t], j*ssw + offw[t], c] * wgt[n][wtap[t]][c] )
+//
+// fprop : one class, (ssh,ssw) = conv stride, offsets kh*dh - pt.
+// dgrad : one class per output parity (ph,pw) in [0,sh)x[0,sw); only taps with
+//         (ph + pt - kh*dh) % sh == 0 contribute, with offset (ph + pt - kh*dh)/sh  (sub-pixel
+//         decomposition: no zero-insertion, no wasted MACs).
+// Out-of-range source pixels read as zero, so TF's asymmetric `same` padding, `valid` transpose
+// output padding and kernels larger than the image need no special cases.
+//
+// Tiling (wave64, 256 threads = 4 waves): block tile BM pixels x BN channels, K step 32.
+// MFMA operands are swapped -- weights are the A operand (rows = channel n), pixels the B operand
+// (cols) -- so a lane's 4 accumulator registers are 4 consecutive channels of one pixel and the
+// epilogue stores 8-byte bf16x4 vectors.  LDS rows are 64 B of data on a 96 B pitch: with that
+// pitch the four 16-lane groups of a ds_read_b128 fragment read hit 16 distinct 16-B slots
+// (conflict-free; a 64/80 B pitch is 2-4 way).  Global->LDS staging is register-staged and
+// software-pipelined one K step ahead (one barrier per step).
+#include "common.h"
+
+struct ClassDesc { int ph, pw, Hc, Wc, ntaps, tap_off, M, pad; };
+
+struct ConvArgs {
+    const bf16_t* src; const bf16_t* wgt; const float* bias; bf16_t* dst;
+    const ClassDesc* classes; const int4* taps;     // tap = {offh, offw, wtap, 0}
+    int B, Hs, Ws, Cs;        // source tensor [B][Hs][Ws][Cs]
+    int Hd, Wd, Nd;           // destination tensor [B][Hd][Wd][Nd] (Nd = physical channels)
+    int Nw;                   // weight rows (true output channels) ; n >= Nw produces 0
+    int ssh, ssw, sdh, sdw;
+    int Ttot;                 // taps per weight row
+    int act; float alpha;
+    int max_taps;
+};
+
+#define PITCH 96              // bytes per LDS row (64 B of bf16 K-data + 32 B pad)
+
+template <int BM, int BN>
+__global__ __launch_bounds__(256) void igemm_conv_kernel(const ConvArgs a) {
+    constexpr int WAVES_M = BM / 64;
+    constexpr int WAVES_N = 4 / WAVES_M;
+    constexpr int WN = BN / WAVES_N;          // channels per wave
+    constexpr int NT = WN / 16;               // 16-channel MFMA tiles per wave
+    constexpr int RA = BM / 64;               // pixel rows staged per thread
+    constexpr int RW = (BN + 63) / 64;        // weight rows staged per thread
+    static_assert(WN >= 16 && WN % 16 == 0, "bad tile");
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* sA = smem;                                  // [2][BM][PITCH]
+    char* sW = smem + 2 * BM * PITCH;                 // [2][BN][PITCH]
+    int4* sT = (int4*)(smem + 2 * (BM + BN) * PITCH); // [max_taps]
+
+    const ClassDesc cd = a.classes[blockIdx.y];
+    const int m0 = blockIdx.x * BM;
+    if (m0 >= cd.M) return;
+    const int n0 = blockIdx.z * BN;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave % WAVES_M, wn = wave / WAVES_M;
+
+    for (int i = tid; i < cd.ntaps; i += 256) sT[i] = a.taps[cd.tap_off + i];
+
+    // ---- per-thread staging assignment: kgroup q (8 k-elements), rows r0 + 64*r
+    const int q = tid & 3, r0 = tid >> 2;
+    const int HW = cd.Hc * cd.Wc;
+    long abase[RA];
+    int aih[RA], aiw[RA];
+    bool aval[RA];
+#pragma unroll
+    for (int r = 0; r < RA; ++r) {
+        int m = m0 + r0 + 64 * r;
+        aval[r] = m < cd.M;
+        int mm = aval[r] ? m : 0;
+        int b = mm / HW, rem = mm - b * HW;
+        int i = rem / cd.Wc, j = rem - i * cd.Wc;
+        abase[r] = (long)b * a.Hs * a.Ws * a.Cs;
+        aih[r] = i * a.ssh;
+        aiw[r] = j * a.ssw;
+    }
+    const int Cs = a.Cs;
+    int tap = (q * 8) / Cs, c = (q * 8) - tap * Cs;
+    const int nsteps = (cd.ntaps * Cs + 31) / 32;
+
+    uint4 regA[RA], regW[RW];
+    auto gload = [&]() {
+        const bool tv = tap < cd.ntaps;
+        int4 te = tv ? sT[tap] : make_int4(0, 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < RA; ++r) {
+            int ih = aih[r] + te.x, iw = aiw[r] + te.y;
+            bool ok = tv && aval[r] && (unsigned)ih < (unsigned)a.Hs && (unsigned)iw < (unsigned)a.Ws;
+            regA[r] = ok ? *(const uint4*)(a.src + abase[r] + ((long)ih * a.Ws + iw) * Cs + c)
+                         : make_uint4(0, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < RW; ++r) {
+            int nl = r0 + 64 * r, n = n0 + nl;
+            bool ok = tv && nl < BN && n < a.Nw;
+            regW[r] = ok ? *(const uint4*)(a.wgt + ((long)n * a.Ttot + te.z) * Cs + c) : make_uint4(0, 0, 0, 0);
+        }
+    };
+    auto lstore = [&](int buf) {
+#pragma unroll
+        for (int r = 0; r < RA; ++r)
+            *(uint4*)(sA + (buf * BM + r0 + 64 * r) * PITCH + q * 16) = regA[r];
+#pragma unroll
+        for (int r = 0; r < RW; ++r)
+            if (r0 + 64 * r < BN) *(uint4*)(sW + (buf * BN + r0 + 64 * r) * PITCH + q * 16) = regW[r];
+    };
+    auto advance = [&]() {
+        c += 32;
+        while (c >= Cs) { c -= Cs; ++tap; }
+    };
+
+    f32x4 acc[NT][4];
+#pragma unroll
+    for (int i = 0; i < NT; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    __syncthreads();                 // tap table visible
+    if (nsteps > 0) {
+        gload();
+        lstore(0);
+    }
+    __syncthreads();
+
+    const int fr = lane & 15, fq = lane >> 4;
+    for (int s = 0; s < nsteps; ++s) {
+        const int cur = s & 1;
+        const bool more = s + 1 < nsteps;
+        if (more) { advance(); gload(); }
+        bf16x8_t wf[NT], xf[4];
+#pragma unroll
+        for (int i = 0; i < NT; ++i)
+            wf[i] = *(const bf16x8_t*)(sW + (cur * BN + wn * WN + 16 * i + fr) * PITCH + fq * 16);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            xf[j] = *(const bf16x8_t*)(sA + (cur * BM + wm * 64 + 16 * j + fr) * PITCH + fq * 16);
+#pragma unroll
+        for (int i = 0; i < NT; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], xf[j], acc[i][j], 0, 0, 0);
+        if (more) lstore(cur ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue: lane holds channels nb..nb+3 (nb = 4*fq) of pixel fr in each 16x16 tile
+    const bool vec_ok = (a.Nd & 3) == 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        int m = m0 + wm * 64 + 16 * j + fr;
+        if (m >= cd.M) continue;
+        int b = m / HW, rem = m - b * HW;
+        int i = rem / cd.Wc, jj = rem - i * cd.Wc;
+        long pix = ((long)b * a.Hd + cd.ph + (long)a.sdh * i) * a.Wd + cd.pw + (long)a.sdw * jj;
+        bf16_t* drow = a.dst + pix * a.Nd;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            int nb = n0 + wn * WN + 16 * t + 4 * fq;
+            if (nb >= a.Nd) continue;
+            float v[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                int n = nb + e;
+                float x = acc[t][j][e];
+                if (n < a.Nw) {
+                    if (a.bias) x += a.bias[n];
+                    v[e] = act_apply(x, a.act, a.alpha);
+                } else {
+                    v[e] = 0.f;
+                }
+            }
+            if (vec_ok) {
+                *(uint2*)(drow + nb) = make_uint2(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]));
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (nb + e < a.Nd) drow[nb + e] = f2bf(v[e]);
+            }
+        }
+    }
+}
+
+template <int BM, int BN>
+static int launch_igemm(const ConvArgs& a, int n_classes, int max_M, hipStream_t s) {
+    size_t smem = 2 * (BM + BN) * PITCH + (size_t)a.max_taps * sizeof(int4);
+    if (smem > 160 * 1024) return -2;
+    if (smem > 64 * 1024) {
+        static bool done = false;   // per-instantiation opt-in for > 64 KiB dynamic LDS
+        if (!done) {
+            hipFuncSetAttribute((const void*)igemm_conv_kernel<BM, BN>,
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            done = true;
+        }
+    }
+    dim3 grid((max_M + BM - 1) / BM, n_classes, (a.Nd + BN - 1) / BN);
+    igemm_conv_kernel<BM, BN><<<grid, 256, smem, s>>>(a);
+    return 0;
+}
+
+// tile: 0 = auto.  Returns 0 on success, negative on a host-side shape/argument error (nothing
+// is launched in that case).
+DDL_API int ddl_igemm_conv(const void* src, const void* wgt, const float* bias, void* dst, const void* classes,
+                           const void* taps, int n_classes, int max_M, int max_taps, int B, int Hs, int Ws,
+                           int Cs, int Hd, int Wd, int Nd, int Nw, int ssh, int ssw, int sdh, int sdw, int Ttot,
+                           int act, float alpha, int tile, hipStream_t s) {
+    if (Cs % 8 != 0 || Cs <= 0 || Nd <= 0 || n_classes <= 0 || max_M <= 0) return -1;
+    if ((long)B * Hs * Ws * Cs >= (1L << 31) || (long)B * Hd * Wd * Nd >= (1L << 31)) return -3;
+    ConvArgs a;
+    a.src = (const bf16_t*)src; a.wgt = (const bf16_t*)wgt; a.bias = bias; a.dst = (bf16_t*)dst;
+    a.classes = (const ClassDesc*)classes; a.taps = (const int4*)taps;
+    a.B = B; a.Hs = Hs; a.Ws = Ws; a.Cs = Cs; a.Hd = Hd; a.Wd = Wd; a.Nd = Nd; a.Nw = Nw;
+    a.ssh = ssh; a.ssw = ssw; a.sdh = sdh; a.sdw = sdw; a.Ttot = Ttot; a.act = act; a.alpha = alpha;
+    a.max_taps = max_taps;
+    if (tile == 0) {
+        // widest channel tile that is not mostly padding; shrink the pixel tile when the grid
+        // would otherwise leave CUs idle (256 CUs, want >= ~2 blocks each)
+        long blocks256 = (long)((max_M + 255) / 256) * n_classes;
+        if (Nd <= 16) tile = 1;
+        else if (Nd <= 32) tile = 3;
+        else if (Nd <= 64) tile = blocks256 >= 512 ? 5 : 4;
+        else tile = ((long)((max_M + 127) / 128) * n_classes * ((Nd + 127) / 128) >= 512) ? 6 : 8;
+    }
+    switch (tile) {
+        case 1: return launch_igemm<256, 16>(a, n_classes, max_M, s);
+        case 2: return launch_igemm<64, 64>(a, n_classes, max_M, s);     // WN = 16
+        case 3: return launch_igemm<256, 32>(a, n_classes, max_M, s);
+        case 4: return launch_igemm<128, 64>(a, n_classes, max_M, s);    // WN = 32
+        case 5: return launch_igemm<256, 64>(a, n_classes, max_M, s);
+        case 6: return launch_igemm<128, 128>(a, n_classes, max_M, s);   // WN = 64
+        case 8: return launch_igemm<64, 128>(a, n_classes, max_M, s);    // WN = 32
+        default: return -4;
+    }
+}

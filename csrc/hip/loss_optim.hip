@@ -1,0 +1,378 @@
+// Fused loss kernels (softmax-CE / softmax-MSE / sigmoid-BCE / Dense(K->1)+BCE forward+backward),
+// metrics, the flat multi-tensor optimizers and the Philox noise generator.
+#include "common.h"
+
+#define LB 256
+
+// ------------------------------------------------------------------------------ softmax family
+// logits: [B][Cs] bf16 (Cs = padded stride), N true classes (N <= 64).  One row per lane.
+// mode 0: probabilities only; mode 1: categorical cross-entropy; mode 2: mean squared error.
+// Row losses go to rowloss[B]; dlogits (bf16, [B][Cs], pad = 0) already carry the 1/B mean factor.
+__global__ void softmax_loss_kernel(const bf16_t* __restrict__ logits, const float* __restrict__ target,
+                                    float* __restrict__ probs, bf16_t* __restrict__ dlogits,
+                                    float* __restrict__ rowloss, int B, int Cs, int N, int mode, int want_grad) {
+    int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= B) return;
+    const bf16_t* l = logits + (size_t)r * Cs;
+    float v[64];
+    float mx = -3.0e38f;
+    for (int j = 0; j < N; ++j) { v[j] = bf2f(l[j]); mx = fmaxf(mx, v[j]); }
+    float sum = 0.f;
+    for (int j = 0; j < N; ++j) { v[j] = __expf(v[j] - mx); sum += v[j]; }
+    float inv = 1.f / sum;
+    for (int j = 0; j < N; ++j) v[j] *= inv;
+    if (probs) for (int j = 0; j < N; ++j) probs[(size_t)r * N + j] = v[j];
+    if (mode == 0) return;
+    const float* t = target + (size_t)r * N;
+    float loss = 0.f;
+    if (mode == 1) {
+        float tsum = 0.f;
+        for (int j = 0; j < N; ++j) {
+            float pc = fminf(fmaxf(v[j], 1e-7f), 1.f - 1e-7f);
+            loss -= t[j] * __logf(pc);
+            tsum += t[j];
+        }
+        if (want_grad) {
+            bf16_t* d = dlogits + (size_t)r * Cs;
+            float ib = 1.f / (float)B;
+            for (int j = 0; j < N; ++j) d[j] = f2bf((v[j] * tsum - t[j]) * ib);
+            for (int j = N; j < Cs; ++j) d[j] = 0;
+        }
+    } else {
+        float dot = 0.f;
+        float k = 2.f / ((float)B * (float)N);
+        for (int j = 0; j < N; ++j) {
+            float df = v[j] - t[j];
+            loss += df * df;
+            dot += k * df * v[j];
+        }
+        loss /= (float)N;
+        if (want_grad) {
+            bf16_t* d = dlogits + (size_t)r * Cs;
+            for (int j = 0; j < N; ++j) d[j] = f2bf(v[j] * (k * (v[j] - t[j]) - dot));
+            for (int j = N; j < Cs; ++j) d[j] = 0;
+        }
+    }
+    rowloss[r] = loss;
+}
+
+// mean of n floats -> out[0] (single block, deterministic order)
+__global__ void mean_kernel(const float* __restrict__ v, long n, float scale, float* __restrict__ out) {
+    __shared__ double red[LB];
+    double s = 0;
+    for (long i = threadIdx.x; i < n; i += LB) s += v[i];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = LB / 2; o > 0; o >>= 1) {
+        if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[0] = (float)(red[0] * scale);
+}
+
+DDL_API void ddl_softmax_loss(const void* logits, const float* target, float* probs, void* dlogits,
+                              float* rowloss, float* loss_out, int B, int Cs, int N, int mode, int want_grad,
+                              hipStream_t s) {
+    softmax_loss_kernel<<<(B + 127) / 128, 128, 0, s>>>((const bf16_t*)logits, target, probs, (bf16_t*)dlogits,
+                                                        rowloss, B, Cs, N, mode, want_grad);
+    if (mode != 0) mean_kernel<<<1, LB, 0, s>>>(rowloss, B, 1.0 / (double)B, loss_out);
+}
+
+// ------------------------------------------------------------------------------ sigmoid BCE
+__device__ __forceinline__ float bce_logits(float x, float z) {
+    return fmaxf(x, 0.f) - x * z + log1pf(__expf(-fabsf(x)));
+}
+
+__global__ void sigmoid_bce_kernel(const float* __restrict__ logits, const float* __restrict__ labels,
+                                   float* __restrict__ rowloss, float* __restrict__ dl, int n) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float x = logits[i], z = labels[i];
+    rowloss[i] = bce_logits(x, z);
+    if (dl) dl[i] = (1.f / (1.f + __expf(-x)) - z) / (float)n;
+}
+
+DDL_API void ddl_sigmoid_bce(const float* logits, const float* labels, float* rowloss, float* dl,
+                             float* loss_out, int n, hipStream_t s) {
+    sigmoid_bce_kernel<<<(n + 255) / 256, 256, 0, s>>>(logits, labels, rowloss, dl, n);
+    mean_kernel<<<1, LB, 0, s>>>(rowloss, n, 1.0 / (double)n, loss_out);
+}
+
+// ------------------------------------------------------------------------------ Dense(K->1)+BCE
+// The DCGAN discriminator head in one pass: one wave per sample row computes the logit (dot of
+// the bf16 feature row with the weight vector), the BCE term and d logit, then immediately
+// writes dX[row] = dlogit * w (outer product) while the row is still in registers; per-block
+// partial dW goes to a slab reduced by a second tiny kernel.  K multiple of 8, K <= 64*8*KMAXV.
+#define HEAD_ROWS 4      // waves (= rows in flight) per block
+#define HEAD_VMAX 8      // uint4 vectors per lane  -> K <= 4096
+
+__global__ __launch_bounds__(HEAD_ROWS * 64) void dense1_bce_kernel(
+    const uint4* __restrict__ x, const bf16_t* __restrict__ w, const float* __restrict__ bias,
+    float label_first, float label_second, int n_first, int M, int K, uint4* __restrict__ dx,
+    float* __restrict__ dw_part, float* __restrict__ logits, float* __restrict__ rowloss,
+    float* __restrict__ dlogit_out, int want_dx, int want_dw) {
+    __shared__ float sw[HEAD_VMAX * 64 * 8];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int kv = K / 8;                       // vectors per row
+    for (int i = threadIdx.x; i < K; i += blockDim.x) sw[i] = bf2f(w[i]);
+    __syncthreads();
+    float acc_dw[HEAD_VMAX][8];
+#pragma unroll
+    for (int v = 0; v < HEAD_VMAX; ++v)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc_dw[v][j] = 0.f;
+    const float b = bias[0];
+    const float invM = 1.f / (float)M;
+    for (int r = blockIdx.x * HEAD_ROWS + wv; r < M; r += gridDim.x * HEAD_ROWS) {
+        float f[HEAD_VMAX][8];
+        float dot = 0.f;
+#pragma unroll
+        for (int v = 0; v < HEAD_VMAX; ++v) {
+            int idx = v * 64 + lane;
+            if (idx < kv) {
+                unpack8(x[(size_t)r * kv + idx], f[v]);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) dot += f[v][j] * sw[idx * 8 + j];
+            }
+        }
+        dot = wave_sum(dot) + b;
+        float z = r < n_first ? label_first : label_second;
+        float dl = (1.f / (1.f + __expf(-dot)) - z) * invM;
+        if (lane == 0) { logits[r] = dot; rowloss[r] = bce_logits(dot, z); dlogit_out[r] = dl; }
+#pragma unroll
+        for (int v = 0; v < HEAD_VMAX; ++v) {
+            int idx = v * 64 + lane;
+            if (idx < kv) {
+                if (want_dw) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) acc_dw[v][j] += dl * f[v][j];
+                }
+                if (want_dx) {
+                    float o[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) o[j] = dl * sw[idx * 8 + j];
+                    dx[(size_t)r * kv + idx] = pack8(o);
+                }
+            }
+        }
+    }
+    if (!want_dw) return;
+    // reduce the HEAD_ROWS waves' partial dW through LDS (reuse sw after a barrier)
+    __syncthreads();
+    float* red = sw;    // K floats
+    for (int q = 0; q < HEAD_ROWS; ++q) {
+        if (wv == q) {
+#pragma unroll
+            for (int v = 0; v < HEAD_VMAX; ++v) {
+                int idx = v * 64 + lane;
+                if (idx < kv) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        if (q == 0) red[idx * 8 + j] = acc_dw[v][j];
+                        else red[idx * 8 + j] += acc_dw[v][j];
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+    for (int i = threadIdx.x; i < K; i += blockDim.x) dw_part[(size_t)blockIdx.x * K + i] = red[i];
+}
+
+__global__ void head_finalize_kernel(const float* __restrict__ dw_part, int nblocks, int K,
+                                     const float* __restrict__ dlogit, int M, float* __restrict__ dw,
+                                     float* __restrict__ db) {
+    int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < K) {
+        double s = 0;
+        for (int b = 0; b < nblocks; ++b) s += dw_part[(size_t)b * K + k];
+        dw[k] = (float)s;
+    }
+    if (blockIdx.x == 0 && threadIdx.x < 64) {
+        double s = 0;
+        for (int i = threadIdx.x; i < M; i += 64) s += dlogit[i];
+        float t = wave_sum((float)s);
+        if (threadIdx.x == 0) db[0] = t;
+    }
+}
+
+DDL_API int ddl_dense1_bce_blocks(int M) {
+    int nb = (M + HEAD_ROWS - 1) / HEAD_ROWS;
+    return nb > 512 ? 512 : (nb < 1 ? 1 : nb);
+}
+
+DDL_API int ddl_dense1_bce(const void* x, const void* w, const float* bias, float label_first,
+                           float label_second, int n_first, int M, int K, void* dx, float* dw_part,
+                           float* logits, float* rowloss, float* dlogit, float* loss_out, float* dw, float* db,
+                           int want_dx, int want_dw, hipStream_t s) {
+    if (K % 8 != 0 || K > HEAD_VMAX * 64 * 8) return -1;
+    int nb = ddl_dense1_bce_blocks(M);
+    dense1_bce_kernel<<<nb, HEAD_ROWS * 64, 0, s>>>((const uint4*)x, (const bf16_t*)w, bias, label_first,
+                                                    label_second, n_first, M, K, (uint4*)dx, dw_part, logits,
+                                                    rowloss, dlogit, want_dx, want_dw);
+    mean_kernel<<<1, LB, 0, s>>>(rowloss, M, 1.0 / (double)M, loss_out);
+    if (want_dw) head_finalize_kernel<<<(K + 255) / 256, 256, 0, s>>>(dw_part, nb, K, dlogit, M, dw, db);
+    return 0;
+}
+
+// ------------------------------------------------------------------------------ metrics
+// count rows where argmax(pred[r][:N]) == argmax(onehot[r][:N]); pred fp32 [B][N]
+__global__ void argmax_match_kernel(const float* __restrict__ pred, const float* __restrict__ onehot, int B,
+                                    int N, int* __restrict__ count) {
+    int r = blockIdx.x * blockDim.x + threadIdx.x;
+    int hit = 0;
+    if (r < B) {
+        int ap = 0, at = 0;
+        float bp = pred[(size_t)r * N], bt = onehot[(size_t)r * N];
+        for (int j = 1; j < N; ++j) {
+            float p = pred[(size_t)r * N + j], t = onehot[(size_t)r * N + j];
+            if (p > bp) { bp = p; ap = j; }
+            if (t > bt) { bt = t; at = j; }
+        }
+        hit = ap == at;
+    }
+    unsigned long long m = __ballot(hit);
+    if ((threadIdx.x & 63) == 0 && m) atomicAdd(count, __popcll(m));
+}
+
+DDL_API void ddl_argmax_match(const float* pred, const float* onehot, int B, int N, int* count, hipStream_t s) {
+    hipMemsetAsync(count, 0, sizeof(int), s);
+    argmax_match_kernel<<<(B + 255) / 256, 256, 0, s>>>(pred, onehot, B, N, count);
+}
+
+// ------------------------------------------------------------------------------ optimizers
+// One launch updates every parameter of a network (flat fp32 master P, grads G, moments) and
+// emits the bf16 working copy.  `step` lives in device memory and is incremented by the kernel
+// launch wrapper's tiny pre-kernel so hipGraph replays keep advancing the bias correction.
+// kind: 0 adam, 1 sgd, 2 rmsprop, 3 adam_fresh_double.
+// If `avg` != nullptr the result is blended in place: p = (1-avg_w)*p_new + avg_w*avg[i]
+// (periodic weight averaging folded into the update, [R-ns]).
+__global__ void step_inc_kernel(int* step) { step[0] += 1; }
+
+__global__ void optim_kernel(float4* __restrict__ P, const float4* __restrict__ G, float4* __restrict__ Mo,
+                             float4* __restrict__ Vo, uint2* __restrict__ Pc, const int* __restrict__ step,
+                             long n4, int kind, float lr, float b1, float b2, float eps, float rho,
+                             float gscale, const float4* __restrict__ avg, float avg_w) {
+    float lr_t = lr, lr_2 = lr;
+    if (kind == 0) {
+        float t = (float)step[0];
+        lr_t = lr * sqrtf(1.f - powf(b2, t)) / (1.f - powf(b1, t));
+    } else if (kind == 3) {
+        lr_t = lr * sqrtf(1.f - b2) / (1.f - b1);
+        lr_2 = lr * sqrtf(1.f - b2 * b2) / (1.f - b1 * b1);
+    }
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+        float4 p4 = P[i], g4 = G[i];
+        float p[4] = {p4.x, p4.y, p4.z, p4.w};
+        float g[4] = {g4.x * gscale, g4.y * gscale, g4.z * gscale, g4.w * gscale};
+        if (kind == 0) {
+            float4 m4 = Mo[i], v4 = Vo[i];
+            float m[4] = {m4.x, m4.y, m4.z, m4.w}, v[4] = {v4.x, v4.y, v4.z, v4.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                m[j] = b1 * m[j] + (1.f - b1) * g[j];
+                v[j] = b2 * v[j] + (1.f - b2) * g[j] * g[j];
+                p[j] -= lr_t * m[j] / (sqrtf(v[j]) + eps);
+            }
+            Mo[i] = make_float4(m[0], m[1], m[2], m[3]);
+            Vo[i] = make_float4(v[0], v[1], v[2], v[3]);
+        } else if (kind == 1) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) p[j] -= lr * g[j];
+        } else if (kind == 2) {
+            float4 v4 = Vo[i];
+            float v[4] = {v4.x, v4.y, v4.z, v4.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                v[j] = rho * v[j] + (1.f - rho) * g[j] * g[j];
+                p[j] -= lr * g[j] / (sqrtf(v[j]) + eps);
+            }
+            Vo[i] = make_float4(v[0], v[1], v[2], v[3]);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float m1 = (1.f - b1) * g[j], v1 = (1.f - b2) * g[j] * g[j];
+                p[j] -= lr_t * m1 / (sqrtf(v1) + eps);
+                float m2 = b1 * m1 + (1.f - b1) * g[j], v2 = b2 * v1 + (1.f - b2) * g[j] * g[j];
+                p[j] -= lr_2 * m2 / (sqrtf(v2) + eps);
+            }
+        }
+        if (avg) {
+            float4 a = avg[i];
+            p[0] = (1.f - avg_w) * p[0] + avg_w * a.x; p[1] = (1.f - avg_w) * p[1] + avg_w * a.y;
+            p[2] = (1.f - avg_w) * p[2] + avg_w * a.z; p[3] = (1.f - avg_w) * p[3] + avg_w * a.w;
+        }
+        P[i] = make_float4(p[0], p[1], p[2], p[3]);
+        if (Pc) Pc[i] = make_uint2(pack2bf(p[0], p[1]), pack2bf(p[2], p[3]));
+    }
+}
+
+DDL_API void ddl_optim_step(float* P, const float* G, float* M, float* V, void* Pc, int* step, long n, int kind,
+                            float lr, float b1, float b2, float eps, float rho, float gscale, const float* avg,
+                            float avg_w, hipStream_t s) {
+    long n4 = n / 4;
+    step_inc_kernel<<<1, 1, 0, s>>>(step);
+    long g = (n4 + 255) / 256;
+    int grid = (int)(g > 2048 ? 2048 : (g < 1 ? 1 : g));
+    optim_kernel<<<grid, 256, 0, s>>>((float4*)P, (const float4*)G, (float4*)M, (float4*)V, (uint2*)Pc, step, n4,
+                                      kind, lr, b1, b2, eps, rho, gscale, (const float4*)avg, avg_w);
+}
+
+// In-place weight average after an all-reduce(sum): P = sum / world, plus bf16 emit.
+__global__ void scale_emit_kernel(float4* __restrict__ P, uint2* __restrict__ Pc, long n4, float scale) {
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+        float4 p = P[i];
+        p.x *= scale; p.y *= scale; p.z *= scale; p.w *= scale;
+        P[i] = p;
+        if (Pc) Pc[i] = make_uint2(pack2bf(p.x, p.y), pack2bf(p.z, p.w));
+    }
+}
+
+DDL_API void ddl_scale_emit(float* P, void* Pc, long n, float scale, hipStream_t s) {
+    long n4 = n / 4;
+    long g = (n4 + 255) / 256;
+    int grid = (int)(g > 2048 ? 2048 : (g < 1 ? 1 : g));
+    scale_emit_kernel<<<grid, 256, 0, s>>>((float4*)P, (uint2*)Pc, n4, scale);
+}
+
+// ------------------------------------------------------------------------------ Philox noise
+// Philox4x32-10, counter = (element group index, stream offset), key = seed.  The 64-bit offset
+// lives in device memory (state[1]) and is advanced by a 1-thread kernel after each draw, so a
+// captured graph produces fresh noise on every replay.
+__device__ __forceinline__ void philox_round(uint32_t* c, uint32_t k0, uint32_t k1) {
+    const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u;
+    uint32_t hi0 = __umulhi(M0, c[0]), lo0 = M0 * c[0];
+    uint32_t hi1 = __umulhi(M1, c[2]), lo1 = M1 * c[2];
+    uint32_t n0 = hi1 ^ c[1] ^ k0, n1 = lo1, n2 = hi0 ^ c[3] ^ k1, n3 = lo0;
+    c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+}
+
+__global__ void philox_uniform_kernel(bf16_t* __restrict__ out, long n, const long* __restrict__ state,
+                                      float lo, float hi) {
+    const uint64_t seed = (uint64_t)state[0], off = (uint64_t)state[1];
+    const long n4 = (n + 3) / 4;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+        uint32_t c[4] = {(uint32_t)i, (uint32_t)((uint64_t)i >> 32), (uint32_t)off, (uint32_t)(off >> 32)};
+        uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+#pragma unroll
+        for (int r = 0; r < 10; ++r) { philox_round(c, k0, k1); k0 += 0x9E3779B9u; k1 += 0xBB67AE85u; }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            long e = i * 4 + j;
+            if (e < n) {
+                float u = (float)(c[j] >> 8) * (1.0f / 16777216.0f);
+                out[e] = f2bf(lo + (hi - lo) * u);
+            }
+        }
+    }
+}
+
+__global__ void philox_advance_kernel(long* state) { state[1] += 1; }
+
+DDL_API void ddl_philox_uniform(void* out, long n, long* state, float lo, float hi, hipStream_t s) {
+    long n4 = (n + 3) / 4;
+    long g = (n4 + 255) / 256;
+    int grid = (int)(g > 2048 ? 2048 : (g < 1 ? 1 : g));
+    philox_uniform_kernel<<<grid, 256, 0, s>>>((bf16_t*)out, n, state, lo, hi);
+    philox_advance_kernel<<<1, 1, 0, s>>>(state);
+}

@@ -1,0 +1,367 @@
+// Weight gradient of the core correlation on the matrix cores:
+//
+//   dW[n][t][c] = sum_{m=(b,oh,ow)} dY[m][n] * X[b, oh*sh + kh*dh - pt, ow*sw + kw*dw - pl, c]
+//
+// The reduction index is the PIXEL, but both operands are stored pixel-major / channel-minor
+// (NHWC), i.e. k-strided for an MFMA fragment.  gfx950's ds_read_b64_tr_b16 does the transpose
+// on the LDS read: tiles are staged exactly as they sit in memory ([pixel][16 channels] sub-tiles
+// with a 32-byte row pitch, so the 8 rows a half-wave reads are one contiguous 256-B bank row ->
+// conflict-free) and read back column-major.  The MFMA k index of lane group g, element j is
+// pixel 4g+j (j<4) / 16+4g+(j-4) (j>=4) for BOTH operands, which is all a dot product needs.
+//
+// v0 decomposition: block = (k-split, tap, [TN x TC] output tile); the block's 4 waves each own a
+// private 32-pixel slice per iteration (no block barrier in the main loop), partial tiles are
+// reduced across waves through LDS and written to a per-split slab; a second kernel sums the
+// slabs in a fixed order (deterministic, no float atomics).
+#include "common.h"
+
+struct WgradArgs {
+    const bf16_t* dy; const bf16_t* x; float* slab;
+    int B, OH, OW, Ny;        // dY [B][OH][OW][Ny]
+    int H, W, Cx;             // X  [B][H][W][Cx]
+    int KH, KW, sh, sw, dh, dw, pt, pl;
+    int n_lim, c_lim;         // valid output rows / cols
+    long sn, st, sc;          // output strides (elements): index = n*sn + t*st + c*sc
+    long slab_stride;         // elements per k-split slab
+    int M, chunk;             // total pixels, pixels per k-split (multiple of 128)
+    int tiles_c;              // number of c tiles (blockIdx.z = nt * tiles_c + ct)
+};
+
+__device__ __forceinline__ s16x4 tr_read(const char* p) {
+    return __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(p));
+}
+
+template <int TN, int TC>
+__global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a) {
+    constexpr int SN = TN / 16, SC = TC / 16;           // 16-channel sub-tiles
+    constexpr int STAGE = (SN + SC) * 1024;             // bytes per wave: [sub][32 px][16 ch] bf16
+    constexpr int RED = TN * TC * 4;                    // bytes per wave partial tile
+    constexpr int PER_WAVE = STAGE > RED ? STAGE : RED;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    char* sY = smem + wave * PER_WAVE;
+    char* sX = sY + SN * 1024;
+
+    const int ks = blockIdx.x, tap = blockIdx.y;
+    const int nt = blockIdx.z / a.tiles_c, ct = blockIdx.z - nt * a.tiles_c;
+    const int n0 = nt * TN, c0 = ct * TC;
+    const int kh = tap / a.KW, kw = tap - kh * a.KW;
+    const int offh = kh * a.dh - a.pt, offw = kw * a.dw - a.pl;
+    const int m_begin = ks * a.chunk;
+    const int m_end = min(a.M, m_begin + a.chunk);
+    const int OHW = a.OH * a.OW;
+
+    f32x4 acc[SN][SC];
+#pragma unroll
+    for (int i = 0; i < SN; ++i)
+#pragma unroll
+        for (int j = 0; j < SC; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    // staging assignment: 16-B units (8 channels of one pixel)
+    constexpr int UY = TN / 8, UX = TC / 8;              // units per pixel row
+    constexpr int RPY = 64 / UY, RPX = 64 / UX;          // rows per pass
+    constexpr int PY = 32 / RPY, PX = 32 / RPX;          // passes
+    const int yrow = lane / UY, ycol = lane % UY;
+    const int xrow = lane / UX, xcol = lane % UX;
+    const bool ycol_ok = n0 + ycol * 8 < a.Ny;
+    const bool xcol_ok = c0 + xcol * 8 < a.Cx;
+
+    // transposed-read addressing
+    const int g = lane >> 4, li = lane & 15, tq = li >> 2, tp = li & 3;
+    const int tr_off = (4 * g + tq) * 32 + tp * 8;
+
+    for (int mb = m_begin + wave * 32; mb < m_end; mb += 128) {
+        uint4 ry[PY], rx[PX];
+#pragma unroll
+        for (int p = 0; p < PY; ++p) {
+            int m = mb + yrow + p * RPY;
+            bool ok = ycol_ok && m < m_end;
+            ry[p] = ok ? *(const uint4*)(a.dy + (long)m * a.Ny + n0 + ycol * 8) : make_uint4(0, 0, 0, 0);
+        }
+#pragma unroll
+        for (int p = 0; p < PX; ++p) {
+            int m = mb + xrow + p * RPX;
+            bool ok = xcol_ok && m < m_end;
+            int mm = ok ? m : 0;
+            int b = mm / OHW, rem = mm - b * OHW;
+            int oh = rem / a.OW, ow = rem - oh * a.OW;
+            int ih = oh * a.sh + offh, iw = ow * a.sw + offw;
+            ok = ok && (unsigned)ih < (unsigned)a.H && (unsigned)iw < (unsigned)a.W;
+            rx[p] = ok ? *(const uint4*)(a.x + (((long)b * a.H + ih) * a.W + iw) * a.Cx + c0 + xcol * 8)
+                       : make_uint4(0, 0, 0, 0);
+        }
+#pragma unroll
+        for (int p = 0; p < PY; ++p) {
+            int row = yrow + p * RPY;
+            *(uint4*)(sY + (ycol >> 1) * 1024 + row * 32 + (ycol & 1) * 16) = ry[p];
+        }
+#pragma unroll
+        for (int p = 0; p < PX; ++p) {
+            int row = xrow + p * RPX;
+            *(uint4*)(sX + (xcol >> 1) * 1024 + row * 32 + (xcol & 1) * 16) = rx[p];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        bf16x8_t fy[SN], fx[SC];
+#pragma unroll
+        for (int i = 0; i < SN; ++i) {
+            s16x4 lo = tr_read(sY + i * 1024 + tr_off), hi = tr_read(sY + i * 1024 + tr_off + 512);
+            s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            fy[i] = __builtin_bit_cast(bf16x8_t, v);
+        }
+#pragma unroll
+        for (int j = 0; j < SC; ++j) {
+            s16x4 lo = tr_read(sX + j * 1024 + tr_off), hi = tr_read(sX + j * 1024 + tr_off + 512);
+            s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            fx[j] = __builtin_bit_cast(bf16x8_t, v);
+        }
+#pragma unroll
+        for (int i = 0; i < SN; ++i)
+#pragma unroll
+            for (int j = 0; j < SC; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fy[i], fx[j], acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+    }
+
+    // ---- cross-wave reduction through LDS, then one slab write per block
+    __syncthreads();
+    float* red = (float*)(smem + wave * PER_WAVE);       // [TN][TC] row-major per wave
+#pragma unroll
+    for (int i = 0; i < SN; ++i)
+#pragma unroll
+        for (int j = 0; j < SC; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                red[(16 * i + 4 * g + e) * TC + 16 * j + li] = acc[i][j][e];
+    __syncthreads();
+    float* out = a.slab + (long)ks * a.slab_stride;
+    for (int idx = tid; idx < TN * TC; idx += 256) {
+        float s = 0.f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) s += ((const float*)(smem + w * PER_WAVE))[idx];
+        int n = n0 + idx / TC, c = c0 + idx % TC;
+        if (n < a.n_lim && c < a.c_lim) out[n * a.sn + tap * a.st + c * a.sc] = s;
+    }
+}
+
+__global__ void slab_reduce_kernel(const float* __restrict__ slab, float* __restrict__ out, long n,
+                                   long slab_stride, int ksplit) {
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        float s = 0.f;
+        for (int k = 0; k < ksplit; ++k) s += slab[k * slab_stride + i];
+        out[i] = s;
+    }
+}
+
+template <int TN, int TC>
+static void launch_wgrad(const WgradArgs& a, int ksplit, int taps, int tiles, hipStream_t s) {
+    constexpr int STAGE = (TN / 16 + TC / 16) * 1024, RED = TN * TC * 4;
+    constexpr int PER_WAVE = STAGE > RED ? STAGE : RED;
+    wgrad_kernel<TN, TC><<<dim3(ksplit, taps, tiles), 256, 4 * PER_WAVE, s>>>(a);
+}
+
+DDL_API int ddl_wgrad_ksplit(int M, int taps, int n_lim, int c_lim) {
+    int tn = n_lim > 32 ? 64 : (n_lim > 16 ? 32 : 16);
+    int tc = c_lim > 32 ? 64 : (c_lim > 16 ? 32 : 16);
+    long tiles = (long)((n_lim + tn - 1) / tn) * ((c_lim + tc - 1) / tc) * taps;
+    long want = (1024 + tiles - 1) / tiles;
+    long maxk = (M + 127) / 128;
+    long k = want < 1 ? 1 : want;
+    if (k > maxk) k = maxk;
+    if (k > 256) k = 256;
+    return (int)k;
+}
+
+// out: fp32 [numel] gradient view (contiguous); slab: fp32 scratch of ksplit*numel floats (unused
+// when ksplit == 1).  Every element of `out` inside the (n_lim, T, c_lim) box is overwritten;
+// the caller zero-fills `out` beforehand if the box does not cover it.
+DDL_API int ddl_conv_wgrad(const void* dy, const void* x, float* out, float* slab, long numel, int ksplit, int B,
+                           int OH, int OW, int Ny, int H, int W, int Cx, int KH, int KW, int sh, int sw, int dh,
+                           int dw, int pt, int pl, int n_lim, int c_lim, long sn, long st, long sc,
+                           hipStream_t s) {
+    if (Ny % 8 || Cx % 8 || ksplit < 1) return -1;
+    long M = (long)B * OH * OW;
+    if (M >= (1L << 31) || (long)B * H * W * Cx >= (1L << 31)) return -3;
+    WgradArgs a;
+    a.dy = (const bf16_t*)dy; a.x = (const bf16_t*)x;
+    a.slab = ksplit == 1 ? out : slab;
+    a.B = B; a.OH = OH; a.OW = OW; a.Ny = Ny; a.H = H; a.W = W; a.Cx = Cx;
+    a.KH = KH; a.KW = KW; a.sh = sh; a.sw = sw; a.dh = dh; a.dw = dw; a.pt = pt; a.pl = pl;
+    a.n_lim = n_lim; a.c_lim = c_lim; a.sn = sn; a.st = st; a.sc = sc;
+    a.slab_stride = numel; a.M = (int)M;
+    long chunk = (M + ksplit - 1) / ksplit;
+    a.chunk = (int)((chunk + 127) / 128 * 128);
+    int tn = n_lim > 32 ? 64 : (n_lim > 16 ? 32 : 16);
+    int tc = c_lim > 32 ? 64 : (c_lim > 16 ? 32 : 16);
+    int tiles_n = (n_lim + tn - 1) / tn;
+    a.tiles_c = (c_lim + tc - 1) / tc;
+    long tiles = (long)tiles_n * a.tiles_c;
+    if (tiles > 65535 || KH * KW > 65535) return -2;
+    int taps = KH * KW;
+#define WG_CASE(TN_, TC_) if (tn == TN_ && tc == TC_) launch_wgrad<TN_, TC_>(a, ksplit, taps, (int)tiles, s);
+    WG_CASE(64, 64) WG_CASE(64, 32) WG_CASE(64, 16) WG_CASE(32, 64) WG_CASE(32, 32) WG_CASE(32, 16)
+    WG_CASE(16, 64) WG_CASE(16, 32) WG_CASE(16, 16)
+#undef WG_CASE
+    if (ksplit > 1) {
+        long g = (numel + 255) / 256;
+        slab_reduce_kernel<<<(int)(g > 2048 ? 2048 : g), 256, 0, s>>>(slab, out, numel, numel, ksplit);
+    }
+    return 0;
+}
+
+// ------------------------------------------------------------------------------ depthwise (direct)
+// Depthwise correlation has no channel reduction, so it is a bandwidth-bound stencil: one lane
+// handles 8 channels (16 B) of one output pixel.  Weights are [KH][KW][C] fp32-from-bf16.
+__global__ void dw_fprop_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ w,
+                                const float* __restrict__ bias, bf16_t* __restrict__ y, int B, int H, int W,
+                                int C, int OH, int OW, int KH, int KW, int sh, int sw, int dh, int dw, int pt,
+                                int pl, int c_true, int act, float alpha) {
+    const int cg = C / 8;
+    const long total = (long)B * OH * OW * cg;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        int gch = (int)(i % cg);
+        long p = i / cg;
+        int ow = (int)(p % OW);
+        long q = p / OW;
+        int oh = (int)(q % OH);
+        int b = (int)(q / OH);
+        float acc[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+        for (int kh = 0; kh < KH; ++kh) {
+            int ih = oh * sh + kh * dh - pt;
+            if ((unsigned)ih >= (unsigned)H) continue;
+            for (int kw = 0; kw < KW; ++kw) {
+                int iw = ow * sw + kw * dw - pl;
+                if ((unsigned)iw >= (unsigned)W) continue;
+                float xv[8], wv[8];
+                unpack8(*(const uint4*)(x + (((long)b * H + ih) * W + iw) * C + gch * 8), xv);
+                unpack8(*(const uint4*)(w + ((long)kh * KW + kw) * C + gch * 8), wv);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc[j] = fmaf(xv[j], wv[j], acc[j]);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            int c = gch * 8 + j;
+            acc[j] = c < c_true ? act_apply(acc[j] + (bias ? bias[c] : 0.f), act, alpha) : 0.f;
+        }
+        *(uint4*)(y + i * 8) = pack8(acc);
+    }
+}
+
+__global__ void dw_dgrad_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ w,
+                                bf16_t* __restrict__ dx, int B, int H, int W, int C, int OH, int OW, int KH,
+                                int KW, int sh, int sw, int dh, int dw, int pt, int pl) {
+    const int cg = C / 8;
+    const long total = (long)B * H * W * cg;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        int gch = (int)(i % cg);
+        long p = i / cg;
+        int iw = (int)(p % W);
+        long q = p / W;
+        int ih = (int)(q % H);
+        int b = (int)(q / H);
+        float acc[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+        for (int kh = 0; kh < KH; ++kh) {
+            int th = ih + pt - kh * dh;
+            if (th < 0 || th % sh) continue;
+            int oh = th / sh;
+            if (oh >= OH) continue;
+            for (int kw = 0; kw < KW; ++kw) {
+                int tw = iw + pl - kw * dw;
+                if (tw < 0 || tw % sw) continue;
+                int ow = tw / sw;
+                if (ow >= OW) continue;
+                float gv[8], wv[8];
+                unpack8(*(const uint4*)(dy + (((long)b * OH + oh) * OW + ow) * C + gch * 8), gv);
+                unpack8(*(const uint4*)(w + ((long)kh * KW + kw) * C + gch * 8), wv);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc[j] = fmaf(gv[j], wv[j], acc[j]);
+            }
+        }
+        *(uint4*)(dx + i * 8) = pack8(acc);
+    }
+}
+
+// dW[kh][kw][c]: block = (pixel chunk, tap); lanes sweep pixels x channel groups, reduce in LDS.
+__global__ __launch_bounds__(256) void dw_wgrad_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x,
+                                                       float* __restrict__ part, int B, int H, int W, int C, int OH,
+                                                       int OW, int KH, int KW, int sh, int sw, int dh, int dw,
+                                                       int pt, int pl) {
+    __shared__ float red[256][9];
+    const int cg = C / 8;
+    const int cgl = cg < 256 ? cg : 256;
+    const int rpi = 256 / cgl;
+    const int gch = blockIdx.z * 256 + threadIdx.x % cgl, rl = threadIdx.x / cgl;
+    const int tap = blockIdx.y, kh = tap / KW, kw = tap - kh * KW;
+    const long M = (long)B * OH * OW;
+    float acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+    if (rl < rpi && gch < cg) {
+        for (long m = blockIdx.x * (long)rpi + rl; m < M; m += (long)gridDim.x * rpi) {
+            int ow = (int)(m % OW);
+            long q = m / OW;
+            int oh = (int)(q % OH);
+            int b = (int)(q / OH);
+            int ih = oh * sh + kh * dh - pt, iw = ow * sw + kw * dw - pl;
+            if ((unsigned)ih >= (unsigned)H || (unsigned)iw >= (unsigned)W) continue;
+            float gv[8], xv[8];
+            unpack8(*(const uint4*)(dy + m * C + gch * 8), gv);
+            unpack8(*(const uint4*)(x + (((long)b * H + ih) * W + iw) * C + gch * 8), xv);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[j] = fmaf(gv[j], xv[j], acc[j]);
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) red[threadIdx.x][j] = acc[j];
+    __syncthreads();
+    if (rl == 0 && gch < cg) {
+        for (int r = 1; r < rpi; ++r)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) red[threadIdx.x][j] += red[threadIdx.x + r * cgl][j];
+        float* o = part + ((long)blockIdx.x * KH * KW + tap) * C + gch * 8;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = red[threadIdx.x][j];
+    }
+}
+
+DDL_API int ddl_dw_wgrad_blocks(long M, int C) {
+    int cg = C / 8, cgl = cg < 256 ? cg : 256, rpi = 256 / cgl;
+    long nb = (M + (long)rpi * 16 - 1) / ((long)rpi * 16);
+    return (int)(nb < 1 ? 1 : (nb > 256 ? 256 : nb));
+}
+
+DDL_API int ddl_depthwise(int mode, const void* a, const void* w, const float* bias, void* out, float* part,
+                          int B, int H, int W, int C, int OH, int OW, int KH, int KW, int sh, int sw, int dh,
+                          int dw, int pt, int pl, int c_true, int act, float alpha, hipStream_t s) {
+    if (C % 8) return -1;
+    const int cg = C / 8;
+    if (mode == 0) {          // fprop: a = x, out = y
+        long total = (long)B * OH * OW * cg;
+        long g = (total + 255) / 256;
+        dw_fprop_kernel<<<(int)(g > 4096 ? 4096 : g), 256, 0, s>>>((const bf16_t*)a, (const bf16_t*)w, bias,
+                                                                    (bf16_t*)out, B, H, W, C, OH, OW, KH, KW, sh,
+                                                                    sw, dh, dw, pt, pl, c_true, act, alpha);
+    } else if (mode == 1) {   // dgrad: a = dy, out = dx
+        long total = (long)B * H * W * cg;
+        long g = (total + 255) / 256;
+        dw_dgrad_kernel<<<(int)(g > 4096 ? 4096 : g), 256, 0, s>>>((const bf16_t*)a, (const bf16_t*)w,
+                                                                    (bf16_t*)out, B, H, W, C, OH, OW, KH, KW, sh,
+                                                                    sw, dh, dw, pt, pl);
+    } else {                  // wgrad: a = dy, w = x, out = dW fp32 [KH][KW][C], part = scratch
+        int nb = ddl_dw_wgrad_blocks((long)B * OH * OW, C);
+        dw_wgrad_kernel<<<dim3(nb, KH * KW, (cg + 255) / 256), 256, 0, s>>>((const bf16_t*)a, (const bf16_t*)w,
+                                                                             part, B, H, W, C, OH, OW, KH, KW,
+                                                                             sh, sw, dh, dw, pt, pl);
+        long n = (long)KH * KW * C;
+        long g = (n + 255) / 256;
+        slab_reduce_kernel<<<(int)(g > 2048 ? 2048 : g), 256, 0, s>>>(part, (float*)out, n, n, nb);
+    }
+    return 0;
+}

@@ -1,0 +1,169 @@
+"""DCGAN on 28x28 (reference-exact graphs) and 64x64 [R-ns], with a data-parallel trainer.
+
+Graphs: /root/reference/GAN_distributed.py:15-72 (shapes in SURVEY 2.6.1).  Step semantics:
+/root/reference/GAN_distributed.py:86-117 -- per iteration a D-step on [real ; G(noise)] with
+labels [1 ; 0] in ONE pass, then a G-step through the frozen D with labels 1; sigmoid-BCE on
+logits; Adam(2e-4).
+
+Two modes, selectable per trainer:
+  * `reference_exact=True`  : fresh TF-Adam applied twice per phase (== 2*lr*sign(g)), BN in
+    inference phase (moving stats, never updated) -- what the reference script really computes;
+  * `reference_exact=False` : persistent Adam, training-mode BN with batch statistics -- the sane
+    default used for data-parallel benchmarking.
+
+No host round trips inside a step: noise comes from a device RNG, the generated batch is written
+next to the real batch on device, the loss stays on device until someone asks for it.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Optional
+
+import torch
+
+from ..ops import functional as F
+from . import ir
+from .network import ConvOp, Network
+from .optim import FlatOptimizer, OptimConfig
+
+NOISE_DIM = 128
+
+
+def discriminator_spec(size: int = 28, base: int = 32) -> ir.ModelSpec:
+    """28: Conv 5x5 s2 1->32, LeakyReLU, Conv 32->64, BN, LeakyReLU, Conv 64->128, BN, LeakyReLU,
+    Flatten, Dense 1 (GAN_distributed.py:16-43).  64: one more stride-2 stage [R-ns]."""
+    n = ir.NameScope()
+    m = ir.ModelSpec("discriminator", [ir.Input(n("input"), (size, size, 1))])
+    stages = 3 if size == 28 else 4
+    for s in range(stages):
+        m.append(ir.Conv2D(n("conv2d"), base << s, 5, 2, 1, "same"))
+        if s > 0:
+            m.append(ir.BatchNorm(n("batch_norm")))
+        m.append(ir.LeakyReLU(n("leaky_relu"), 0.3))
+    m.append(ir.Flatten(n("flatten")))
+    m.append(ir.Dense(n("dense"), 1))
+    return m
+
+
+def generator_spec(size: int = 28, base: int = 32, noise_dim: int = NOISE_DIM) -> ir.ModelSpec:
+    """28: Dense 128->7*7*128, Reshape, ConvT 5x5 s2 ->64 relu, BN, ConvT s2 ->32 relu, BN,
+    ConvT s1 ->1 tanh, Lambda (x+1)/2 (GAN_distributed.py:46-72).  64: 8x8x256 seed and three
+    stride-2 stages [R-ns]."""
+    n = ir.NameScope()
+    m = ir.ModelSpec("generator", [ir.Input(n("input"), (noise_dim,))])
+    if size == 28:
+        seed_hw, chans = 7, [base * 4, base * 2, base]
+    elif size == 64:
+        seed_hw, chans = 8, [base * 8, base * 4, base * 2, base]
+    else:
+        raise ValueError("size must be 28 or 64")
+    m.append(ir.Dense(n("dense"), seed_hw * seed_hw * chans[0]))
+    m.append(ir.Reshape(n("reshape"), (seed_hw, seed_hw, chans[0])))
+    for c in chans[1:]:
+        m.append(ir.Conv2DTranspose(n("conv2d_transpose"), c, 5, 2, 1, "same", "relu"))
+        m.append(ir.BatchNorm(n("batch_norm")))
+    m.append(ir.Conv2DTranspose(n("conv2d_transpose"), 1, 5, 1, 1, "same", "tanh"))
+    m.append(ir.LambdaAffine(n("lambda_affine"), 0.5, 0.5))
+    return m
+
+
+@dataclass
+class GANConfig:
+    size: int = 28
+    batch: int = 1000               # real images per step per rank (reference: 1000, full batch)
+    noise_dim: int = NOISE_DIM
+    lr: float = 2e-4
+    reference_exact: bool = False
+    seed: int = 0
+    base: int = 32
+
+
+class DeviceRNG:
+    """Uniform(-1,1) noise.  Device: counter-based Philox kernel whose offset lives in device
+    memory (replay-safe under hipGraph capture).  CPU: torch.Generator."""
+
+    def __init__(self, device, seed: int):
+        self.device = torch.device(device)
+        self.seed = int(seed)
+        if self.device.type == "cuda":
+            self.state = torch.zeros(2, dtype=torch.int64, device=self.device)
+            self.state[0] = self.seed
+        else:
+            self.gen = torch.Generator().manual_seed(self.seed)
+
+    def uniform(self, shape, dtype, lo=-1.0, hi=1.0):
+        if self.device.type == "cuda":
+            return F.hip_backend().philox_uniform(shape, dtype, self.state, lo, hi)
+        return (torch.rand(shape, generator=self.gen) * (hi - lo) + lo).to(dtype)
+
+
+class GANTrainer:
+    """One rank's DCGAN trainer.  `dp` (parallel.ddp.FlatDataParallel or None) averages the flat
+    gradient buffer of the network being updated across ranks -- one collective per phase."""
+
+    def __init__(self, cfg: GANConfig, device="cpu", dp=None, rank: int = 0):
+        self.cfg, self.device, self.dp = cfg, torch.device(device), dp
+        bn_mode = "inference" if cfg.reference_exact else "batch"
+        # same seed on every rank -> identical initial replicas (dp.broadcast makes it certain)
+        self.G = Network(generator_spec(cfg.size, cfg.base, cfg.noise_dim), device, cfg.seed + 1, bn_mode)
+        self.D = Network(discriminator_spec(cfg.size, cfg.base), device, cfg.seed + 2, bn_mode)
+        ocfg = OptimConfig.tf_adam(cfg.lr, fresh_double=cfg.reference_exact)
+        self.optG, self.optD = FlatOptimizer(self.G, ocfg), FlatOptimizer(self.D, ocfg)
+        self.rng = DeviceRNG(device, cfg.seed * 7919 + 17 + rank)
+        self.head: ConvOp = self.D.ops[-1]
+        assert self.head.kind == "dense" and self.head.g.O == 1
+        self.d_loss = self.g_loss = None
+        if dp is not None:
+            dp.broadcast_(self.G.P, self.G.S, self.D.P, self.D.S)
+            self.G.refresh_working_copies()
+            self.D.refresh_working_copies()
+
+    # ---- the two phases -------------------------------------------------------------------
+    def _d_head(self, feat, n_first, label_first, label_second, want_dx, want_dw):
+        h = self.head
+        loss, dfeat, _, _, _ = F.dense1_bce_fwd_bwd(feat, h.w_main, h.bias, label_first, label_second,
+                                                    n_first, want_dx, want_dw,
+                                                    h.gkernel if want_dw else None,
+                                                    h.gbias if want_dw else None)
+        return loss, dfeat
+
+    def d_backward(self, real):
+        """Forward/backward of the discriminator phase; leaves averaged grads in D.G."""
+        B = real.shape[0]
+        z = self.rng.uniform((B, self.cfg.noise_dim), self.G.cdtype)
+        fake = self.G.forward(z, training=False)               # generator.predict(noise)
+        xs = torch.cat([real, fake], 0)
+        feat = self.D.forward(xs, training=True, stop=-1)
+        loss, dfeat = self._d_head(feat, B, 1.0, 0.0, True, True)
+        self.D.backward(dfeat, need_input_grad=False, start=-1)
+        self.d_loss = loss
+        return loss
+
+    def g_backward(self, B):
+        z = self.rng.uniform((B, self.cfg.noise_dim), self.G.cdtype)
+        fake = self.G.forward(z, training=True)
+        feat = self.D.forward(fake, training=True, stop=-1)
+        loss, dfeat = self._d_head(feat, B, 1.0, 1.0, True, False)
+        dfake = self.D.backward(dfeat, need_input_grad=True, need_dw=False, start=-1)
+        self.G.backward(dfake, need_input_grad=False)
+        self.g_loss = loss
+        return loss
+
+    def train_step(self, real):
+        """One reference iteration: train_discriminator() then train_generator()."""
+        real = self.D.prepare_input(real)
+        self.d_backward(real)
+        if self.dp is not None:
+            self.dp.all_reduce_mean_(self.D.G)
+        self.optD.step()
+        self.g_backward(real.shape[0])
+        if self.dp is not None:
+            self.dp.all_reduce_mean_(self.G.G)
+        self.optG.step()
+        self.D.release()
+        self.G.release()
+        return self.d_loss, self.g_loss
+
+    def generate(self, n: int):
+        z = self.rng.uniform((n, self.cfg.noise_dim), self.G.cdtype)
+        return self.G.to_logical(self.G.forward(z, training=False))

@@ -1,0 +1,631 @@
+"""Static-graph executor: explicit forward/backward over a `ModelSpec` chain.
+
+Design (MI355X-first, not a Keras clone):
+  * one flat fp32 master buffer per network for all trainable parameters, one flat gradient
+    buffer of the same layout, one flat buffer for BN moving statistics -> a single RCCL
+    collective per network and a single fused multi-tensor optimizer launch;
+  * on device, a flat bf16 working copy (`Pc`, same offsets) plus an alternate-layout copy
+    (`Palt`) for the transposed operand the dgrad kernels want; both are refreshed by the fused
+    optimizer / relayout kernels, never by host code;
+  * activations NHWC, bf16 on device / fp32 on CPU; on device every channel dimension is
+    physically padded to a multiple of 8 with zero lanes (16-byte vector access everywhere, MFMA
+    friendly reduction dims, odd channel counts of the random search space need no slow path);
+    parameters are stored padded the same way and stripped on export;
+  * shapes are static so a whole training step can be captured in a hipGraph;
+  * no autograd: every op has a hand-written backward that calls the HIP kernels.
+
+Replaces what Keras' `Model`/`fit` machinery did for the reference (/root/reference/DDL.py:58-96,
+/root/reference/GAN_distributed.py:15-117).
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, List, Optional, Tuple
+
+import numpy as np
+import torch
+
+from ..ops import functional as F
+from ..ops.geometry import ConvGeom, dense_geom
+from .ir import LayerSpec, ModelSpec
+
+ALIGN = 8      # every tensor starts at a multiple of 8 elements (16 B in bf16, 32 B in fp32)
+
+
+def _round_up(n, a):
+    return (n + a - 1) // a * a
+
+
+class _Param:
+    """One tensor inside a flat buffer.  `shape` is the physical (padded) shape, `lshape` the
+    logical one (same rank): logical data lives in the leading corner, the rest is zero."""
+    __slots__ = ("layer", "wname", "shape", "lshape", "numel", "offset", "trainable", "keras_shape")
+
+    def __init__(self, layer, wname, shape, lshape, trainable, keras_shape):
+        self.layer, self.wname, self.trainable = layer, wname, trainable
+        self.shape, self.lshape, self.keras_shape = tuple(shape), tuple(lshape), tuple(keras_shape)
+        self.numel = int(np.prod(shape))
+        self.offset = -1
+
+    def corner(self):
+        return tuple(slice(0, n) for n in self.lshape)
+
+
+# =============================================================================== exec ops
+class Op:
+    name = "op"
+    has_params = False
+
+    def fwd(self, x, training):
+        raise NotImplementedError
+
+    def bwd(self, dy, need_dx=True, need_dw=True):
+        raise NotImplementedError
+
+    def release(self):
+        pass
+
+
+class ConvOp(Op):
+    """Conv2D / Conv2DTranspose / DepthwiseConv2D / Dense with fused bias + activation."""
+    has_params = True
+
+    def __init__(self, spec: LayerSpec, kind: str, g: ConvGeom, act: str, alpha: float, cpad: int,
+                 kstruct: Optional[Tuple[int, int, int]] = None):
+        self.spec, self.kind, self.g, self.act, self.alpha = spec, kind, g, act, alpha
+        self.name = spec.name
+        self.cpad = cpad
+        self.kstruct = kstruct          # Dense fed by Flatten of (H, W, C): K is structured
+        self.act_bwd_fused = False      # a following BN op applies act'(y) for us
+        self.kernel = self.bias = None            # fp32 master views
+        self.gkernel = self.gbias = None          # fp32 gradient views
+        self.w_main = self.w_alt = None           # compute-dtype views
+        self.x = self.y = None
+
+    def _p(self, c):
+        return _round_up(c, self.cpad)
+
+    def in_channels(self):       # logical, layer view
+        return self.g.O if self.kind == "conv2d_transpose" else self.g.I
+
+    def out_channels(self):
+        return self.g.I if self.kind == "conv2d_transpose" else self.g.O
+
+    def shapes(self):
+        """(physical, logical) canonical kernel shapes:
+        [layer_out][KH][KW][layer_in] ; Dense [N][K] (or [N][H][W][C]) ; depthwise [KH][KW][C]."""
+        g, p = self.g, self._p
+        cin, cout = self.in_channels(), self.out_channels()
+        if self.kind == "dense":
+            if self.kstruct is not None:
+                H, W, Cc = self.kstruct
+                return (cout, H, W, p(Cc)), (cout, H, W, Cc)
+            return (cout, p(cin)), (cout, cin)
+        if self.kind == "depthwise_conv2d":
+            return (g.KH, g.KW, p(cin)), (g.KH, g.KW, cin)
+        return (cout, g.KH, g.KW, p(cin)), (cout, g.KH, g.KW, cin)
+
+    def relayout_dims(self):
+        """(R, T, C, Rp) for canonical [R][T][C] -> alternate [C][T][Rp]."""
+        phys, _ = self.shapes()
+        R = phys[0]
+        Cc = phys[-1] if self.kstruct is None else int(np.prod(phys[1:]))
+        T = 1 if self.kind == "dense" else self.g.KH * self.g.KW
+        return R, T, Cc, self._p(R)
+
+    def alt_shape(self):
+        R, T, Cc, Rp = self.relayout_dims()
+        if self.kind == "dense":
+            return (Cc, Rp)
+        return (Cc, self.g.KH, self.g.KW, Rp)
+
+    def _w4(self, w, rows_first=True):
+        """Dense weights as a 1x1 conv kernel."""
+        return w.reshape(w.shape[0], 1, 1, -1)
+
+    def fwd(self, x, training):
+        g = self.g
+        if self.kind == "dense":
+            B = x.shape[0]
+            x4 = x.reshape(B, 1, 1, -1)
+            y = F.conv_fprop(x4, self._w4(self.w_main), self.bias, g, self.act, self.alpha).reshape(B, -1)
+        elif self.kind == "conv2d_transpose":
+            y = F.conv_dgrad(x, self.w_main, g, self.bias, self.act, self.alpha)
+        else:
+            y = F.conv_fprop(x, self.w_main, self.bias, g, self.act, self.alpha)
+        if training:
+            self.x, self.y = x, y
+        return y
+
+    def bwd(self, dy, need_dx=True, need_dw=True):
+        g = self.g
+        if self.act not in (None, "linear") and not self.act_bwd_fused:
+            dy = F.act_bwd(dy, self.y, self.act, self.alpha)
+        x = self.x
+        dx = None
+        if self.kind == "dense":
+            B = x.shape[0]
+            dy4, x4 = dy.reshape(B, 1, 1, -1), x.reshape(B, 1, 1, -1)
+            if need_dw:
+                F.conv_wgrad(x4, dy4, g, "A", out=self._w4(self.gkernel))
+                F.bias_grad(dy, out=self.gbias)
+            if need_dx:
+                dx = F.conv_dgrad(dy4, self._w4(self.w_alt), g).reshape(x.shape)
+        elif self.kind == "conv2d_transpose":
+            # core X = our output (dy), core Y = our input (x)
+            if need_dw:
+                F.conv_wgrad(dy, x, g, "B", out=self.gkernel)
+                F.bias_grad(dy, out=self.gbias)
+            if need_dx:
+                dx = F.conv_fprop(dy, self.w_alt, None, g)
+        else:
+            if need_dw:
+                F.conv_wgrad(x, dy, g, "A", out=self.gkernel)
+                F.bias_grad(dy, out=self.gbias)
+            if need_dx:
+                dx = F.conv_dgrad(dy, self.w_main if g.depthwise else self.w_alt, g)
+        return dx
+
+    def release(self):
+        self.x = self.y = None
+
+
+class BNOp(Op):
+    """BatchNormalization (+ fused following activation; + fused act' of the preceding layer)."""
+    has_params = True
+
+    def __init__(self, spec: LayerSpec, channels: int, cphys: int, rank4: bool):
+        self.spec, self.name, self.C, self.Cp, self.rank4 = spec, spec.name, channels, cphys, rank4
+        self.momentum, self.eps = spec.cfg["momentum"], spec.cfg["epsilon"]
+        self.post_act, self.post_alpha = None, 0.3
+        self.prev_act, self.prev_alpha = None, 0.3
+        self.mode = "batch"        # "batch" | "inference" 
+        self.gamma = self.beta = self.ggamma = self.gbeta = None
+        self.moving_mean = self.moving_var = None
+        self.x = self.y = self.mean = self.invstd = None
+        self.used_batch_stats = False
+
+    def fwd(self, x, training):
+        use_batch = training and self.mode == "batch"
+        if use_batch:
+            scale, shift, mean, invstd = F.bn_train_affine(x, self.gamma, self.beta, self.moving_mean,
+                                                           self.moving_var, self.momentum, self.eps,
+                                                           self.rank4, True)
+        else:
+            mean = self.moving_mean
+            scale, shift, invstd = F.bn_infer_affine(self.gamma, self.beta, self.moving_mean, self.moving_var,
+                                                     self.eps)
+        y = F.bn_apply(x, scale, shift, self.post_act, self.post_alpha, self.C)
+        if training:
+            self.x, self.y, self.mean, self.invstd = x, y, mean, invstd
+            self.used_batch_stats = use_batch
+        return y
+
+    def bwd(self, dy, need_dx=True, need_dw=True):
+        dx, _, _ = F.bn_bwd(dy, self.x, self.y, self.mean, self.invstd, self.gamma, self.post_act,
+                            self.post_alpha, self.used_batch_stats, self.prev_act, self.prev_alpha,
+                            self.ggamma if need_dw else None, self.gbeta if need_dw else None)
+        return dx
+
+    def release(self):
+        self.x = self.y = self.mean = self.invstd = None
+
+
+class ViewOp(Op):
+    def __init__(self, spec, out_phys):
+        self.spec, self.name, self.out_phys = spec, spec.name, tuple(out_phys)
+        self.in_shape = None
+
+    def fwd(self, x, training):
+        self.in_shape = x.shape
+        return x.reshape(x.shape[0], *self.out_phys)
+
+    def bwd(self, dy, need_dx=True, need_dw=True):
+        return dy.reshape(self.in_shape)
+
+
+class PadOp(Op):
+    def __init__(self, spec):
+        self.spec, self.name = spec, spec.name
+        (self.pt, self.pb), (self.pl, self.pr) = spec.cfg["padding"]
+
+    def fwd(self, x, training):
+        return F.spatial_pad(x, self.pt, self.pb, self.pl, self.pr)
+
+    def bwd(self, dy, need_dx=True, need_dw=True):
+        return F.spatial_pad(dy, -self.pt, -self.pb, -self.pl, -self.pr)
+
+
+class ActOp(Op):
+    def __init__(self, spec, act, alpha, c_true):
+        self.spec, self.name, self.act, self.alpha, self.c_true = spec, spec.name, act, alpha, c_true
+        self.y = None
+
+    def fwd(self, x, training):
+        y = F.act_fwd(x, self.act, self.alpha, self.c_true)
+        if training:
+            self.y = y
+        return y
+
+    def bwd(self, dy, need_dx=True, need_dw=True):
+        return F.act_bwd(dy, self.y, self.act, self.alpha)
+
+    def release(self):
+        self.y = None
+
+
+class AffineOp(Op):
+    def __init__(self, spec, c_true):
+        self.spec, self.name, self.c_true = spec, spec.name, c_true
+        self.scale, self.shift = spec.cfg["scale"], spec.cfg["shift"]
+
+    def fwd(self, x, training):
+        return F.affine(x, self.scale, self.shift, self.c_true)
+
+    def bwd(self, dy, need_dx=True, need_dw=True):
+        return F.affine(dy, self.scale, 0.0, self.c_true)
+
+
+# =============================================================================== network
+class Network:
+    def __init__(self, spec: ModelSpec, device="cpu", seed: int = 0, bn_mode: str = "batch"):
+        self.spec = spec
+        self.device = torch.device(device)
+        self.on_gpu = self.device.type == "cuda"
+        self.cdtype = torch.bfloat16 if self.on_gpu else torch.float32
+        self.cpad = 8 if self.on_gpu else 1
+        self.bn_mode = bn_mode
+        self.softmax_head = False
+        self.ops: List[Op] = []
+        self._params: List[_Param] = []
+        self._build_ops()
+        self._allocate()
+        self.init_weights(seed)
+
+    def _phys(self, shape):
+        return tuple(shape[:-1]) + (_round_up(shape[-1], self.cpad),)
+
+    # ------------------------------------------------------------------ graph -> exec ops
+    def _build_ops(self):
+        spec = self.spec
+        chain = spec.chain()
+        shapes = spec.infer_shapes()
+        i = 1
+        cur = shapes[chain[0].name]          # logical shape (no batch dim)
+        self.in_shape = cur
+        flat_from = None                     # (H, W, C) if `cur` is a Flatten of a rank-3 tensor
+        while i < len(chain):
+            l = chain[i]
+            nxt = chain[i + 1] if i + 1 < len(chain) else None
+            k = l.kind
+            consumed = 1
+            new_flat_from = None
+            if k in ("conv2d", "conv2d_transpose", "depthwise_conv2d", "dense"):
+                kstruct = flat_from if (k == "dense" and flat_from is not None and self.cpad > 1) else None
+                if k == "dense":
+                    kin = cur[0] if kstruct is None else kstruct[0] * kstruct[1] * _round_up(kstruct[2], self.cpad)
+                    g = dense_geom(kin, l.cfg["units"])
+                else:
+                    g = spec.conv_geom(l, cur)
+                act, alpha = l.cfg.get("activation", "linear") or "linear", 0.3
+                if act == "softmax":
+                    if nxt is not None:
+                        raise ValueError("softmax is only supported on the final Dense layer")
+                    self.softmax_head, act = True, "linear"
+                elif act == "linear" and nxt is not None and nxt.kind == "leaky_relu":
+                    act, alpha, consumed = "leaky", nxt.cfg["alpha"], 2
+                elif act == "tanh" and nxt is not None and nxt.kind == "lambda_affine" \
+                        and nxt.cfg["scale"] == 0.5 and nxt.cfg["shift"] == 0.5:
+                    act, consumed = "tanh01", 2
+                self.ops.append(ConvOp(l, k, g, act, alpha, self.cpad, kstruct))
+            elif k == "batch_norm":
+                op = BNOp(l, cur[-1], _round_up(cur[-1], self.cpad), len(cur) == 3)
+                op.mode = self.bn_mode
+                prev = self.ops[-1] if self.ops else None
+                if isinstance(prev, ConvOp) and prev.act not in (None, "linear"):
+                    op.prev_act, op.prev_alpha, prev.act_bwd_fused = prev.act, prev.alpha, True
+                if nxt is not None and nxt.kind == "leaky_relu":
+                    op.post_act, op.post_alpha, consumed = "leaky", nxt.cfg["alpha"], 2
+                elif nxt is not None and nxt.kind == "activation" and nxt.cfg["activation"] != "softmax":
+                    op.post_act, consumed = nxt.cfg["activation"], 2
+                self.ops.append(op)
+                new_flat_from = flat_from
+            elif k == "flatten":
+                if len(cur) == 3:
+                    new_flat_from = cur
+                    ph = self._phys(cur)
+                    self.ops.append(ViewOp(l, (ph[0] * ph[1] * ph[2],)))
+                else:
+                    self.ops.append(ViewOp(l, self._phys(shapes[l.name])))
+            elif k == "reshape":
+                tgt = shapes[l.name]
+                if self.cpad > 1 and (cur[-1] % self.cpad or tgt[-1] % self.cpad):
+                    raise ValueError("device Reshape needs channel dims that are multiples of 8")
+                self.ops.append(ViewOp(l, tgt))
+            elif k == "zero_padding2d":
+                self.ops.append(PadOp(l))
+            elif k == "leaky_relu":
+                self.ops.append(ActOp(l, "leaky", l.cfg["alpha"], cur[-1]))
+            elif k == "activation":
+                self.ops.append(ActOp(l, l.cfg["activation"], 0.3, cur[-1]))
+            elif k == "lambda_affine":
+                self.ops.append(AffineOp(l, cur[-1]))
+            else:
+                raise ValueError(f"cannot execute layer kind {k}")
+            cur = shapes[chain[i + consumed - 1].name]
+            flat_from = new_flat_from
+            i += consumed
+        self.out_shape = cur
+
+    # ------------------------------------------------------------------ parameter storage
+    def _allocate(self):
+        train, state = [], []
+        for op in self.ops:
+            if isinstance(op, ConvOp):
+                g = op.g
+                phys, logical = op.shapes()
+                cin, cout = op.in_channels(), op.out_channels()
+                ks = {"conv2d": (g.KH, g.KW, cin, cout), "conv2d_transpose": (g.KH, g.KW, cout, cin),
+                      "depthwise_conv2d": (g.KH, g.KW, cin, 1),
+                      "dense": (int(np.prod(logical[1:])), cout)}[op.kind]
+                kname = "depthwise_kernel" if op.kind == "depthwise_conv2d" else "kernel"
+                train.append(_Param(op.name, kname, phys, logical, True, ks))
+                train.append(_Param(op.name, "bias", (cout,), (cout,), True, (cout,)))
+            elif isinstance(op, BNOp):
+                train.append(_Param(op.name, "gamma", (op.Cp,), (op.C,), True, (op.C,)))
+                train.append(_Param(op.name, "beta", (op.Cp,), (op.C,), True, (op.C,)))
+                state.append(_Param(op.name, "moving_mean", (op.Cp,), (op.C,), False, (op.C,)))
+                state.append(_Param(op.name, "moving_variance", (op.Cp,), (op.C,), False, (op.C,)))
+        off = 0
+        for p in train:
+            p.offset = off
+            off = _round_up(off + p.numel, ALIGN)
+        self.n_train = max(off, ALIGN)
+        off = 0
+        for p in state:
+            p.offset = off
+            off = _round_up(off + p.numel, ALIGN)
+        self.n_state = max(off, ALIGN)
+        dev = self.device
+        self.P = torch.zeros(self.n_train, dtype=torch.float32, device=dev)
+        self.G = torch.zeros(self.n_train, dtype=torch.float32, device=dev)
+        self.S = torch.zeros(self.n_state, dtype=torch.float32, device=dev)
+        self._params = train + state
+        self._pmap = {(p.layer, p.wname): p for p in self._params}
+        # compute-dtype working copies
+        self.Pc = torch.zeros(self.n_train, dtype=self.cdtype, device=dev) if self.on_gpu else self.P
+        alt_off = 0
+        self._alt: List[Tuple[ConvOp, int]] = []
+        for op in self.ops:
+            if isinstance(op, ConvOp) and op.kind != "depthwise_conv2d":
+                self._alt.append((op, alt_off))
+                alt_off = _round_up(alt_off + int(np.prod(op.alt_shape())), ALIGN)
+        self.Palt = torch.zeros(max(alt_off, ALIGN), dtype=self.cdtype, device=dev) if self.on_gpu else None
+        self._bind_views()
+
+    def _view(self, buf, p: _Param):
+        return buf[p.offset:p.offset + p.numel].view(p.shape)
+
+    def _bind_views(self):
+        alt_off = {id(op): o for op, o in self._alt}
+        for op in self.ops:
+            if isinstance(op, ConvOp):
+                kname = "depthwise_kernel" if op.kind == "depthwise_conv2d" else "kernel"
+                pk, pb = self._pmap[(op.name, kname)], self._pmap[(op.name, "bias")]
+                op.kernel, op.bias = self._view(self.P, pk), self._view(self.P, pb)   # bias consumed in fp32
+                op.gkernel, op.gbias = self._view(self.G, pk), self._view(self.G, pb)
+                op.w_main = self._view(self.Pc, pk)
+                if op.kind == "dense" and op.kstruct is not None:
+                    op.w_main = op.w_main.reshape(pk.shape[0], -1)
+                    op.kernel2d = op.kernel.reshape(pk.shape[0], -1)
+                if op.kind == "depthwise_conv2d":
+                    op.w_alt = op.w_main
+                elif self.on_gpu:
+                    ashape = op.alt_shape()
+                    o = alt_off[id(op)]
+                    op.w_alt = self.Palt[o:o + int(np.prod(ashape))].view(ashape)
+                else:
+                    op.w_alt = op.kernel.t() if op.kind == "dense" else op.kernel.permute(3, 1, 2, 0)
+            elif isinstance(op, BNOp):
+                pg, pb = self._pmap[(op.name, "gamma")], self._pmap[(op.name, "beta")]
+                op.gamma, op.beta = self._view(self.P, pg), self._view(self.P, pb)
+                op.ggamma, op.gbeta = self._view(self.G, pg), self._view(self.G, pb)
+                op.moving_mean = self._view(self.S, self._pmap[(op.name, "moving_mean")])
+                op.moving_var = self._view(self.S, self._pmap[(op.name, "moving_variance")])
+
+    def _scatter(self, buf: torch.Tensor, p: _Param, logical: torch.Tensor):
+        v = buf[p.offset:p.offset + p.numel].view(p.shape)
+        v.zero_()
+        v[p.corner()] = logical.reshape(p.lshape)
+
+    def init_weights(self, seed: int):
+        """Glorot-uniform kernels, zero biases, BN gamma=1 beta=0 mean=0 var=1."""
+        gen = torch.Generator().manual_seed(int(seed))
+        P = torch.zeros(self.n_train, dtype=torch.float32)
+        S = torch.zeros(self.n_state, dtype=torch.float32)
+        for p in self._params:
+            nl = int(np.prod(p.lshape))
+            if p.wname in ("kernel", "depthwise_kernel"):
+                ks = p.keras_shape
+                rf = int(np.prod(ks[:-2])) if len(ks) > 2 else 1
+                fan_in, fan_out = ks[-2] * rf, ks[-1] * rf
+                lim = math.sqrt(6.0 / (fan_in + fan_out))
+                self._scatter(P, p, (torch.rand(nl, generator=gen) * 2 - 1) * lim)
+            elif p.wname == "gamma":
+                P[p.offset:p.offset + p.numel] = 1.0
+            elif p.wname == "moving_variance":
+                S[p.offset:p.offset + p.numel] = 1.0
+        self.P.copy_(P)
+        self.S.copy_(S)
+        self.refresh_working_copies()
+
+    def refresh_working_copies(self, cast: bool = True):
+        """Re-derive the bf16 working copies from the fp32 master (device only).  The fused
+        optimizer already writes `Pc`, in which case `cast=False` only redoes the relayouts."""
+        if not self.on_gpu:
+            return
+        hip = F.hip_backend()
+        if cast:
+            hip.cast_f32_to_bf16(self.P, self.Pc)
+        hip.relayout_alt(self)
+
+    # ------------------------------------------------------------------ execution
+    def set_bn_mode(self, mode: str):
+        self.bn_mode = mode
+        for op in self.ops:
+            if isinstance(op, BNOp):
+                op.mode = mode
+
+    def prepare_input(self, x: torch.Tensor, index: Optional[torch.Tensor] = None, scale: float = 1.0):
+        """Logical input (fp32 / uint8 / bf16, [N, *in_shape] or a 1-channel image to be
+        replicated) -> the device layout (bf16, padded channels).  `index` gathers samples on
+        device (dataset resident in HBM)."""
+        c_true = self.in_shape[-1]
+        if self.on_gpu:
+            x = x.to(self.device)
+            if x.dim() == len(self.in_shape):          # [N,H,W] grayscale without channel axis
+                x = x.unsqueeze(-1)
+            if (x.dtype == torch.bfloat16 and x.shape[-1] == _round_up(c_true, 8) and index is None
+                    and scale == 1.0 and (c_true % 8 == 0)):
+                return x.contiguous()
+            return F.hip_backend().pad_channels(x.contiguous(), _round_up(c_true, 8), index, scale, c_true)
+        if x.dim() == len(self.in_shape):
+            x = x.unsqueeze(-1)
+        if index is not None:
+            x = x[index]
+        x = x.float() * scale if scale != 1.0 else x.float()
+        if x.shape[-1] == 1 and c_true > 1:
+            x = x.expand(*x.shape[:-1], c_true)
+        return x.contiguous()
+
+    def to_logical(self, y: torch.Tensor, c_true: Optional[int] = None) -> torch.Tensor:
+        """Device layout -> fp32 logical tensor (padding stripped)."""
+        c_true = self.out_shape[-1] if c_true is None else c_true
+        if self.on_gpu:
+            return F.hip_backend().strip_channels(y, c_true)
+        return y.float()
+
+    def forward(self, x, training: bool = False, start: int = 0, stop: Optional[int] = None):
+        stop = len(self.ops) if stop is None else (stop if stop >= 0 else len(self.ops) + stop)
+        for op in self.ops[start:stop]:
+            x = op.fwd(x, training)
+        return x
+
+    def backward(self, dy, need_input_grad: bool = False, need_dw: bool = True,
+                 start: Optional[int] = None):
+        """Back-propagate from op index `start` (exclusive upper bound, default: all ops)."""
+        start = len(self.ops) if start is None else (start if start >= 0 else len(self.ops) + start)
+        first_param = next((i for i, op in enumerate(self.ops) if op.has_params), len(self.ops))
+        for i in range(start - 1, -1, -1):
+            op = self.ops[i]
+            need_dx = need_input_grad or i > first_param
+            if not need_dx and not (need_dw and op.has_params):
+                break
+            dy = op.bwd(dy, need_dx=need_dx, need_dw=need_dw)
+        return dy
+
+    def release(self):
+        for op in self.ops:
+            op.release()
+
+    def predict(self, x, batch_size: int = 4096, prepared: bool = False):
+        """Inference forward; applies the softmax of a softmax head (Keras `model.predict`).
+        Returns fp32 logical outputs."""
+        outs = []
+        n_out = self.out_shape[-1]
+        for i in range(0, x.shape[0], batch_size):
+            xb = x[i:i + batch_size]
+            y = self.forward(xb if prepared else self.prepare_input(xb), training=False)
+            y = F.softmax(y, n_out) if self.softmax_head else self.to_logical(y)
+            outs.append(y.float())
+        return torch.cat(outs, 0)
+
+    # ------------------------------------------------------------------ weights I/O
+    def param_table(self):
+        return list(self._params)
+
+    def _logical(self, p: _Param) -> np.ndarray:
+        buf = self.P if p.trainable else self.S
+        v = buf[p.offset:p.offset + p.numel].view(p.shape)[p.corner()]
+        return v.detach().float().cpu().numpy()
+
+    def _to_keras(self, p: _Param) -> np.ndarray:
+        a = self._logical(p)
+        if p.wname == "kernel":
+            op = self._op(p.layer)
+            if op.kind == "dense":
+                a = a.reshape(a.shape[0], -1).T           # [N][K] -> (K, N)
+            elif op.kind == "conv2d":
+                a = a.transpose(1, 2, 3, 0)               # [O][KH][KW][I] -> (kh,kw,in,out)
+            else:
+                a = a.transpose(1, 2, 0, 3)               # [F][KH][KW][Cin] -> (kh,kw,filters,in)
+        elif p.wname == "depthwise_kernel":
+            a = a[..., None]                              # [KH][KW][C] -> (kh,kw,C,1)
+        return np.ascontiguousarray(a, dtype=np.float32)
+
+    def _from_keras(self, p: _Param, a: np.ndarray) -> torch.Tensor:
+        a = np.asarray(a, dtype=np.float32)
+        if tuple(a.shape) != p.keras_shape:
+            raise ValueError(f"{p.layer}/{p.wname}: expected Keras shape {p.keras_shape}, got {a.shape}")
+        if p.wname == "kernel":
+            op = self._op(p.layer)
+            if op.kind == "dense":
+                a = a.T
+            elif op.kind == "conv2d":
+                a = a.transpose(3, 0, 1, 2)
+            else:
+                a = a.transpose(2, 0, 1, 3)
+        elif p.wname == "depthwise_kernel":
+            a = a[..., 0]
+        return torch.from_numpy(np.ascontiguousarray(a)).reshape(p.lshape)
+
+    def _op(self, name):
+        for op in self.ops:
+            if op.name == name:
+                return op
+        raise KeyError(name)
+
+    def get_keras_weights(self) -> List[Tuple[str, str, np.ndarray]]:
+        """[(layer_name, weight_name, array in Keras layout)] in Keras weight order."""
+        out = []
+        for op in self.ops:
+            for p in [q for q in self._params if q.layer == op.name]:
+                out.append((p.layer, p.wname, self._to_keras(p)))
+        return out
+
+    def set_keras_weights(self, weights: Dict[Tuple[str, str], np.ndarray], strict: bool = True):
+        P, S = self.P.detach().cpu().clone(), self.S.detach().cpu().clone()
+        for p in self._params:
+            key = (p.layer, p.wname)
+            if key not in weights:
+                if strict:
+                    raise KeyError(f"missing weight {key}")
+                continue
+            self._scatter(P if p.trainable else S, p, self._from_keras(p, weights[key]))
+        self.P.copy_(P)
+        self.S.copy_(S)
+        self.refresh_working_copies()
+
+    def logical_state(self) -> Dict[Tuple[str, str], torch.Tensor]:
+        """Device-independent snapshot {(layer, weight): logical fp32 CPU tensor} -- what a
+        transfer-learning child or another rank needs to rebuild this network."""
+        return {(p.layer, p.wname): torch.from_numpy(self._logical(p).copy()) for p in self._params}
+
+    def load_logical_state(self, state: Dict[Tuple[str, str], torch.Tensor], strict: bool = True):
+        P, S = self.P.detach().cpu().clone(), self.S.detach().cpu().clone()
+        for p in self._params:
+            key = (p.layer, p.wname)
+            if key not in state:
+                if strict:
+                    raise KeyError(f"missing weight {key}")
+                continue
+            t = state[key]
+            if tuple(t.shape) != p.lshape:
+                raise ValueError(f"{key}: shape {tuple(t.shape)} != {p.lshape}")
+            self._scatter(P if p.trainable else S, p, t.float())
+        self.P.copy_(P)
+        self.S.copy_(S)
+        self.refresh_working_copies()
+
+    def num_params(self, trainable_only=False):
+        return sum(int(np.prod(p.lshape)) for p in self._params if p.trainable or not trainable_only)

@@ -1,0 +1,86 @@
+"""Flat-buffer optimizers (one fused multi-tensor launch per network on device).
+
+Covers the optimizer set of the reference: Keras `Adam` / `SGD` / `RMSprop` with an lr override
+(/root/reference/DDL.py:39-42, eps 1e-7), TF-1 `AdamOptimizer(2e-4)` (eps 1e-8,
+/root/reference/GAN_distributed.py:93), and the GAN's accidental "fresh Adam applied twice"
+semantics as `adam_fresh_double`.  On device the update kernel also emits the bf16
+working copy of the parameters, and can fold in an in-place weight average (`avg_with`) for the
+periodic-averaging / local-SGD mode [R-ns].
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Optional
+
+import torch
+
+from ..ops import cpu_ref
+from ..ops import functional as F
+
+
+@dataclass
+class OptimConfig:
+    kind: str = "adam"            # adam | sgd | rmsprop | adam_fresh_double
+    lr: float = 1e-3
+    beta1: float = 0.9
+    beta2: float = 0.999
+    eps: float = 1e-7             # Keras default; TF-1 AdamOptimizer uses 1e-8
+    rho: float = 0.9
+
+    @staticmethod
+    def keras(name: str, lr: float) -> "OptimConfig":
+        name = name.lower()
+        if name not in ("adam", "sgd", "rmsprop"):
+            raise ValueError(name)
+        return OptimConfig(kind=name, lr=lr, eps=1e-7)
+
+    @staticmethod
+    def tf_adam(lr: float = 2e-4, fresh_double: bool = False) -> "OptimConfig":
+        return OptimConfig(kind="adam_fresh_double" if fresh_double else "adam", lr=lr, eps=1e-8)
+
+
+class FlatOptimizer:
+    def __init__(self, net, cfg: OptimConfig):
+        self.net, self.cfg = net, cfg
+        self.t = 0
+        dev = net.P.device
+        need_m = cfg.kind == "adam"
+        need_v = cfg.kind in ("adam", "rmsprop")
+        self.m = torch.zeros_like(net.P) if need_m else None
+        self.v = torch.zeros_like(net.P) if need_v else None
+        # device-side step counter so a captured hipGraph advances bias correction on replay
+        self.step_dev = torch.zeros(1, dtype=torch.int32, device=dev) if net.on_gpu else None
+
+    def zero_grad(self):
+        self.net.G.zero_()
+
+    def step(self, grad_scale: float = 1.0):
+        net, c = self.net, self.cfg
+        self.t += 1
+        if net.on_gpu:
+            F.hip_backend().optimizer_step(self, grad_scale)
+            net.refresh_working_copies(cast=False)
+            return
+        g = net.G if grad_scale == 1.0 else net.G * grad_scale
+        if c.kind == "adam":
+            cpu_ref.adam_step(net.P, g, self.m, self.v, self.t, c.lr, c.beta1, c.beta2, c.eps)
+        elif c.kind == "sgd":
+            cpu_ref.sgd_step(net.P, g, c.lr)
+        elif c.kind == "rmsprop":
+            cpu_ref.rmsprop_step(net.P, g, self.v, c.lr, c.rho, c.eps)
+        elif c.kind == "adam_fresh_double":
+            cpu_ref.adam_fresh_double_step(net.P, g, c.lr, c.beta1, c.beta2, c.eps)
+        else:
+            raise ValueError(c.kind)
+
+    def state_dict(self):
+        return {"t": self.t, "m": self.m, "v": self.v, "cfg": vars(self.cfg)}
+
+    def load_state_dict(self, sd):
+        self.t = int(sd["t"])
+        if self.m is not None and sd.get("m") is not None:
+            self.m.copy_(sd["m"])
+        if self.v is not None and sd.get("v") is not None:
+            self.v.copy_(sd["v"])
+        if self.step_dev is not None:
+            self.step_dev.fill_(self.t)

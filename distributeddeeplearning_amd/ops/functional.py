@@ -1,0 +1,173 @@
+"""Device dispatch for every framework op.
+
+CPU tensors run the fp32 oracle (ops/cpu_ref.py); device tensors run the hand-written gfx950
+kernels through ops/hip.py.  There is deliberately no third path: a device tensor with the HIP
+extension missing raises instead of silently falling back to eager PyTorch.
+
+Device tensors are bf16 with the channel (last) dimension physically padded to a multiple of 8
+(zeros in the padding lanes), so every kernel access is a 16-byte vector and every reduction
+dimension is MFMA-friendly; `c_true` arguments carry the logical channel count where an op must
+keep the padding lanes at exactly zero.  CPU tensors are unpadded fp32.
+"""
+from __future__ import annotations
+
+import torch
+
+from . import cpu_ref
+
+_hip = None
+
+
+def hip_backend():
+    global _hip
+    if _hip is None:
+        from . import hip as _h   # raises with a clear message if the .so is missing
+        _hip = _h
+    return _hip
+
+
+def _b(t: torch.Tensor):
+    return hip_backend() if t.is_cuda else cpu_ref
+
+
+# conv family -------------------------------------------------------------------------------
+def conv_fprop(x, wA, bias, g, act=None, alpha=0.3):
+    return _b(x).conv_fprop(x, wA, bias, g, act, alpha)
+
+
+def conv_dgrad(dy, wB, g, bias=None, act=None, alpha=0.3):
+    """`wB` is the core weight in [I][KH][KW][O] order (reduction channel contiguous);
+    depthwise: [KH][KW][C]."""
+    if dy.is_cuda:
+        return hip_backend().conv_dgrad(dy, wB, g, bias, act, alpha)
+    wA = wB if g.depthwise else wB.permute(3, 1, 2, 0)
+    return cpu_ref.conv_dgrad(dy, wA, g, bias, act, alpha)
+
+
+def conv_wgrad(x, dy, g, layout="A", out=None):
+    """Weight gradient of the core correlation, written in layout A=[O][KH][KW][I] or
+    B=[I][KH][KW][O] (depthwise: [KH][KW][C]), fp32.  `out` (a view into the flat gradient
+    buffer) is overwritten."""
+    if x.is_cuda:
+        return hip_backend().conv_wgrad(x, dy, g, layout, out)
+    dw = cpu_ref.conv_wgrad(x, dy, g)
+    if layout == "B" and not g.depthwise:
+        dw = dw.permute(3, 1, 2, 0)
+    if out is not None:
+        out.copy_(dw.reshape(out.shape))
+        return out
+    return dw.contiguous()
+
+
+def bias_grad(dy, out):
+    if dy.is_cuda:
+        return hip_backend().bias_grad(dy, out)
+    out.copy_(cpu_ref.bias_grad(dy))
+    return out
+
+
+# activations -------------------------------------------------------------------------------
+def act_fwd(x, kind, alpha=0.3, c_true=None):
+    if x.is_cuda:
+        return hip_backend().act_fwd(x, kind, alpha, c_true)
+    return cpu_ref.act_fwd(x, kind, alpha)
+
+
+def act_bwd(dy, y, kind, alpha=0.3):
+    return _b(dy).act_bwd(dy, y, kind, alpha)
+
+
+def affine(x, scale, shift, c_true=None):
+    if x.is_cuda:
+        return hip_backend().affine(x, scale, shift, c_true)
+    return x * scale + shift
+
+
+def spatial_pad(x, pt, pb, pl, pr):
+    """ZeroPadding2D on NHWC (negative values crop: used for its backward)."""
+    if x.is_cuda:
+        return hip_backend().spatial_pad(x, pt, pb, pl, pr)
+    return torch.nn.functional.pad(x, (0, 0, pl, pr, pt, pb))
+
+
+# batch norm --------------------------------------------------------------------------------
+def bn_train_affine(x, gamma, beta, mm, mv, momentum, eps, bessel, update_moving=True):
+    """Batch statistics of x -> (scale, shift, mean, invstd) with y = x*scale + shift, plus the
+    Keras moving-average update  moving = moving*momentum + batch*(1-momentum)  (variance
+    Bessel-corrected for 4-D inputs, as TF's fused batch norm does)."""
+    if x.is_cuda:
+        return hip_backend().bn_train_affine(x, gamma, beta, mm, mv, momentum, eps, bessel, update_moving)
+    mean, var = cpu_ref.bn_stats(x)
+    count = x.numel() // x.shape[-1]
+    invstd = torch.rsqrt(var + eps)
+    scale = gamma * invstd
+    shift = beta - mean * scale
+    if update_moving:
+        mm.mul_(momentum).add_(mean, alpha=1 - momentum)
+        v = var * (count / max(count - 1, 1)) if bessel else var
+        mv.mul_(momentum).add_(v, alpha=1 - momentum)
+    return scale, shift, mean, invstd
+
+
+def bn_infer_affine(gamma, beta, mm, mv, eps):
+    """(scale, shift, invstd) from the moving statistics (inference-phase BN)."""
+    if gamma.is_cuda:
+        return hip_backend().bn_infer_affine(gamma, beta, mm, mv, eps)
+    invstd = torch.rsqrt(mv + eps)
+    scale = gamma * invstd
+    return scale, beta - mm * scale, invstd
+
+
+def bn_apply(x, scale, shift, act=None, alpha=0.3, c_true=None):
+    if x.is_cuda:
+        return hip_backend().bn_apply(x, scale, shift, act, alpha, c_true)
+    return cpu_ref.bn_apply(x, scale, shift, act, alpha)
+
+
+def bn_bwd(dy, x, y, mean, invstd, gamma, act, alpha, train_stats, prev_act=None, prev_alpha=0.3,
+           out_dgamma=None, out_dbeta=None):
+    if dy.is_cuda:
+        return hip_backend().bn_bwd(dy, x, y, mean, invstd, gamma, act, alpha, train_stats, prev_act,
+                                    prev_alpha, out_dgamma, out_dbeta)
+    dx, dgamma, dbeta = cpu_ref.bn_bwd(dy, x, y, mean, invstd, gamma, act, alpha, train_stats, prev_act,
+                                       prev_alpha)
+    if out_dgamma is not None:
+        out_dgamma.copy_(dgamma)
+        out_dbeta.copy_(dbeta)
+    return dx, dgamma, dbeta
+
+
+# losses ------------------------------------------------------------------------------------
+def softmax(logits, n_true=None):
+    if logits.is_cuda:
+        return hip_backend().softmax(logits, n_true)
+    return cpu_ref.softmax(logits)
+
+
+def softmax_ce(logits, onehot, want_grad=True):
+    return _b(logits).softmax_ce(logits, onehot, want_grad)
+
+
+def softmax_mse(logits, target, want_grad=True):
+    return _b(logits).softmax_mse(logits, target, want_grad)
+
+
+def sigmoid_bce(logits, labels, want_grad=True):
+    return _b(logits).sigmoid_bce(logits, labels, want_grad)
+
+
+def dense1_bce_fwd_bwd(x, w, b, label_first, label_second, n_first, want_dx=True, want_dw=True,
+                       out_dw=None, out_db=None):
+    if x.is_cuda:
+        return hip_backend().dense1_bce_fwd_bwd(x, w, b, label_first, label_second, n_first, want_dx, want_dw,
+                                                out_dw, out_db)
+    loss, dx, dw, db, logits = cpu_ref.dense1_bce_fwd_bwd(x, w, b, label_first, label_second, n_first,
+                                                          want_dx, want_dw)
+    if want_dw and out_dw is not None:
+        out_dw.copy_(dw.reshape(out_dw.shape))
+        out_db.copy_(db.reshape(out_db.shape))
+    return loss, dx, dw, db, logits
+
+
+def argmax_match_count(pred, onehot):
+    return _b(pred).argmax_match_count(pred, onehot)

@@ -1,0 +1,580 @@
+"""ctypes bindings to libddl_hip.so (the gfx950 kernels in csrc/hip) for device tensors.
+
+The kernels have a plain C ABI (raw pointers + hipStream_t) so the native library has no
+PyTorch/pybind dependency: tensors are passed as `data_ptr()`, launches go to the *current*
+torch stream (so they are captured by `torch.cuda.graph`).  Every wrapper validates shapes,
+dtypes and contiguity on the host before launching -- a kernel is never started on operands
+it was not written for.
+
+Device tensor convention: bf16, channel (last) dim padded to a multiple of 8, padding lanes zero.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from pathlib import Path
+from typing import Dict, Optional, Tuple
+
+import numpy as np
+import torch
+
+from .geometry import ConvGeom
+
+_LIB_PATH = Path(__file__).resolve().parent.parent / "_C" / "libddl_hip.so"
+if not _LIB_PATH.exists():
+    raise ImportError(
+        f"{_LIB_PATH} is missing: the HIP kernels are not built.  Run `python build.py` "
+        "(hipcc --offload-arch=gfx950).  Device tensors have no PyTorch fallback by design.")
+_lib = C.CDLL(str(_LIB_PATH))
+
+_SYNC_CHECK = os.environ.get("DDL_SYNC_CHECK", "0") == "1"
+
+ACT_CODE = {None: 0, "linear": 0, "relu": 1, "sigmoid": 2, "softplus": 3, "tanh": 4, "softsign": 5,
+            "leaky": 6, "tanh01": 7}
+
+vp, ci, cl, cf = C.c_void_p, C.c_int, C.c_long, C.c_float
+
+
+def _sig(name, restype, *argtypes):
+    fn = getattr(_lib, name)
+    fn.restype = restype
+    fn.argtypes = list(argtypes)
+    return fn
+
+
+_act_fwd = _sig("ddl_act_fwd", None, vp, vp, cl, ci, ci, ci, cf, vp)
+_act_bwd = _sig("ddl_act_bwd", None, vp, vp, vp, cl, ci, cf, vp)
+_colreduce_blocks = _sig("ddl_colreduce_blocks", ci, cl, ci)
+_bn_batch_stats = _sig("ddl_bn_batch_stats", None, vp, cl, ci, vp, vp, vp, vp, vp, cf, cf, ci, ci, vp, vp, vp, vp, vp)
+_bn_infer_affine = _sig("ddl_bn_infer_affine", None, vp, vp, vp, vp, cf, ci, vp, vp, vp, vp)
+_bn_apply = _sig("ddl_bn_apply", None, vp, vp, vp, vp, cl, ci, ci, ci, cf, vp)
+_bn_bwd = _sig("ddl_bn_bwd", None, vp, vp, vp, vp, cl, ci, vp, vp, vp, ci, cf, ci, ci, cf, vp, vp, vp, vp, vp, vp)
+_bias_grad = _sig("ddl_bias_grad", None, vp, cl, ci, ci, vp, vp, vp)
+_cast = _sig("ddl_cast_f32_bf16", None, vp, vp, cl, vp)
+_relayout = _sig("ddl_relayout_alt", None, vp, vp, vp, ci, cl, vp)
+_pad_channels = _sig("ddl_pad_channels", None, vp, ci, vp, vp, cl, ci, ci, ci, ci, cf, vp)
+_strip_channels = _sig("ddl_strip_channels", None, vp, vp, cl, ci, ci, vp)
+_spatial_pad = _sig("ddl_spatial_pad", None, vp, vp, ci, ci, ci, ci, ci, ci, ci, ci, vp)
+_affine = _sig("ddl_affine", None, vp, vp, cl, ci, ci, cf, cf, vp)
+_softmax_loss = _sig("ddl_softmax_loss", None, vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, vp)
+_sigmoid_bce = _sig("ddl_sigmoid_bce", None, vp, vp, vp, vp, vp, ci, vp)
+_dense1_blocks = _sig("ddl_dense1_bce_blocks", ci, ci)
+_dense1_bce = _sig("ddl_dense1_bce", ci, vp, vp, vp, cf, cf, ci, ci, ci, vp, vp, vp, vp, vp, vp, vp, vp, ci, ci, vp)
+_argmax_match = _sig("ddl_argmax_match", None, vp, vp, ci, ci, vp, vp)
+_optim_step = _sig("ddl_optim_step", None, vp, vp, vp, vp, vp, vp, cl, ci, cf, cf, cf, cf, cf, cf, vp, cf, vp)
+_scale_emit = _sig("ddl_scale_emit", None, vp, vp, cl, cf, vp)
+_philox = _sig("ddl_philox_uniform", None, vp, cl, vp, cf, cf, vp)
+_igemm = _sig("ddl_igemm_conv", ci, vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci,
+              ci, ci, ci, ci, cf, ci, vp)
+_wgrad_ksplit = _sig("ddl_wgrad_ksplit", ci, ci, ci, ci, ci)
+_wgrad = _sig("ddl_conv_wgrad", ci, vp, vp, vp, vp, cl, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci,
+              ci, ci, ci, ci, cl, cl, cl, vp)
+_dw_blocks = _sig("ddl_dw_wgrad_blocks", ci, cl, ci)
+_depthwise = _sig("ddl_depthwise", ci, ci, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci,
+                  ci, ci, ci, ci, cf, vp)
+
+IGEMM_TILE = int(os.environ.get("DDL_IGEMM_TILE", "0"))     # 0 = heuristic; tuning knob
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _done():
+    if _SYNC_CHECK:
+        torch.cuda.synchronize()
+
+
+def _p(t: Optional[torch.Tensor]):
+    return None if t is None else t.data_ptr()
+
+
+def pad8(c: int) -> int:
+    return (c + 7) // 8 * 8
+
+
+def _chk_act(t: torch.Tensor, name="tensor"):
+    if not (t.is_cuda and t.dtype == torch.bfloat16 and t.is_contiguous()):
+        raise ValueError(f"{name}: device kernels need a contiguous bf16 cuda tensor, got "
+                         f"{t.dtype} {t.device} contiguous={t.is_contiguous()}")
+    if t.shape[-1] % 8:
+        raise ValueError(f"{name}: channel dim {t.shape[-1]} is not padded to a multiple of 8")
+    if t.data_ptr() % 16:
+        raise ValueError(f"{name}: not 16-byte aligned")
+
+
+def _chk_f32(t: torch.Tensor, n=None, name="tensor"):
+    if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()):
+        raise ValueError(f"{name}: need contiguous fp32 cuda tensor")
+    if n is not None and t.numel() < n:
+        raise ValueError(f"{name}: {t.numel()} elements, need >= {n}")
+
+
+def _rows_c(t):
+    return t.numel() // t.shape[-1], t.shape[-1]
+
+
+# ------------------------------------------------------------------------------ activations
+def act_fwd(x, kind, alpha=0.3, c_true=None):
+    if kind in (None, "linear"):
+        return x
+    _chk_act(x, "x")
+    y = torch.empty_like(x)
+    rows, Cp = _rows_c(x)
+    _act_fwd(x.data_ptr(), y.data_ptr(), rows, Cp, Cp if c_true is None else c_true, ACT_CODE[kind], alpha,
+             _stream())
+    _done()
+    return y
+
+
+def act_bwd(dy, y, kind, alpha=0.3):
+    if kind in (None, "linear"):
+        return dy
+    _chk_act(dy, "dy")
+    _chk_act(y, "y")
+    if dy.shape != y.shape:
+        raise ValueError("act_bwd shape mismatch")
+    dx = torch.empty_like(dy)
+    _act_bwd(dy.data_ptr(), y.data_ptr(), dx.data_ptr(), dy.numel(), ACT_CODE[kind], alpha, _stream())
+    _done()
+    return dx
+
+
+def affine(x, scale, shift, c_true=None):
+    _chk_act(x, "x")
+    y = torch.empty_like(x)
+    rows, Cp = _rows_c(x)
+    _affine(x.data_ptr(), y.data_ptr(), rows, Cp, Cp if c_true is None else c_true, scale, shift, _stream())
+    _done()
+    return y
+
+
+def spatial_pad(x, pt, pb, pl, pr):
+    _chk_act(x, "x")
+    B, H, W, Cp = x.shape
+    Hd, Wd = H + pt + pb, W + pl + pr
+    if Hd <= 0 or Wd <= 0:
+        raise ValueError("spatial_pad produces an empty tensor")
+    y = torch.empty(B, Hd, Wd, Cp, dtype=x.dtype, device=x.device)
+    _spatial_pad(x.data_ptr(), y.data_ptr(), B, H, W, Hd, Wd, Cp, pt, pl, _stream())
+    _done()
+    return y
+
+
+# ------------------------------------------------------------------------------ batch norm
+def _part(rows, Cp, device):
+    nb = _colreduce_blocks(rows, Cp)
+    return torch.empty(nb * 2 * Cp, dtype=torch.float32, device=device)
+
+
+def bn_train_affine(x, gamma, beta, mm, mv, momentum, eps, bessel, update_moving=True):
+    _chk_act(x, "x")
+    rows, Cp = _rows_c(x)
+    for t, n in ((gamma, "gamma"), (beta, "beta"), (mm, "moving_mean"), (mv, "moving_var")):
+        _chk_f32(t, Cp, n)
+    out = torch.empty(4, Cp, dtype=torch.float32, device=x.device)
+    part = _part(rows, Cp, x.device)
+    _bn_batch_stats(x.data_ptr(), rows, Cp, part.data_ptr(), gamma.data_ptr(), beta.data_ptr(), mm.data_ptr(),
+                    mv.data_ptr(), momentum, eps, int(bool(bessel)), int(bool(update_moving)),
+                    out[0].data_ptr(), out[1].data_ptr(), out[2].data_ptr(), out[3].data_ptr(), _stream())
+    _done()
+    return out[0], out[1], out[2], out[3]
+
+
+def bn_infer_affine(gamma, beta, mm, mv, eps):
+    Cp = gamma.numel()
+    out = torch.empty(3, Cp, dtype=torch.float32, device=gamma.device)
+    _bn_infer_affine(gamma.data_ptr(), beta.data_ptr(), mm.data_ptr(), mv.data_ptr(), eps, Cp,
+                     out[0].data_ptr(), out[1].data_ptr(), out[2].data_ptr(), _stream())
+    _done()
+    return out[0], out[1], out[2]
+
+
+def bn_apply(x, scale, shift, act=None, alpha=0.3, c_true=None):
+    _chk_act(x, "x")
+    rows, Cp = _rows_c(x)
+    _chk_f32(scale, Cp, "scale")
+    _chk_f32(shift, Cp, "shift")
+    y = torch.empty_like(x)
+    _bn_apply(x.data_ptr(), y.data_ptr(), scale.data_ptr(), shift.data_ptr(), rows, Cp,
+              Cp if c_true is None else c_true, ACT_CODE[act], alpha, _stream())
+    _done()
+    return y
+
+
+def bn_bwd(dy, x, y, mean, invstd, gamma, act, alpha, train_stats, prev_act=None, prev_alpha=0.3,
+           out_dgamma=None, out_dbeta=None):
+    _chk_act(dy, "dy")
+    _chk_act(x, "x")
+    if dy.shape != x.shape:
+        raise ValueError(f"bn_bwd: dy {tuple(dy.shape)} vs x {tuple(x.shape)}")
+    if ACT_CODE[act] != 0:
+        _chk_act(y, "y")
+    rows, Cp = _rows_c(x)
+    for t, n in ((mean, "mean"), (invstd, "invstd"), (gamma, "gamma")):
+        _chk_f32(t, Cp, n)
+    dev = x.device
+    dx = torch.empty_like(x)
+    part = _part(rows, Cp, dev)
+    coef = torch.empty(2, Cp, dtype=torch.float32, device=dev)
+    if out_dgamma is None:
+        out_dgamma = torch.empty(Cp, dtype=torch.float32, device=dev)
+        out_dbeta = torch.empty(Cp, dtype=torch.float32, device=dev)
+    else:
+        _chk_f32(out_dgamma, Cp, "dgamma")
+        _chk_f32(out_dbeta, Cp, "dbeta")
+    _bn_bwd(dy.data_ptr(), x.data_ptr(), _p(y), dx.data_ptr(), rows, Cp, mean.data_ptr(), invstd.data_ptr(),
+            gamma.data_ptr(), ACT_CODE[act], alpha, int(bool(train_stats)), ACT_CODE[prev_act], prev_alpha,
+            part.data_ptr(), out_dgamma.data_ptr(), out_dbeta.data_ptr(), coef[0].data_ptr(),
+            coef[1].data_ptr(), _stream())
+    _done()
+    return dx, out_dgamma, out_dbeta
+
+
+def bias_grad(dy, out):
+    _chk_act(dy, "dy")
+    rows, Cp = _rows_c(dy)
+    _chk_f32(out, None, "bias grad")
+    if out.numel() > Cp:
+        raise ValueError("bias grad longer than channel dim")
+    part = _part(rows, Cp, dy.device)
+    _bias_grad(dy.data_ptr(), rows, Cp, out.numel(), part.data_ptr(), out.data_ptr(), _stream())
+    _done()
+    return out
+
+
+# ------------------------------------------------------------------------------ casts / layout
+def cast_f32_to_bf16(src, dst):
+    if src.numel() != dst.numel() or src.numel() % 8:
+        raise ValueError("cast: flat buffers must match and be padded to 8")
+    _cast(src.data_ptr(), dst.data_ptr(), src.numel(), _stream())
+    _done()
+
+
+def relayout_alt(net):
+    """Refresh every alternate-layout weight copy of `net` in one launch."""
+    tab = getattr(net, "_relayout_tab", None)
+    if tab is None:
+        descs, mx = [], 0
+        for op, alt_off in net._alt:
+            R, T, Cc, Rp = op.relayout_dims()
+            poff = net._pmap[(op.name, "kernel")].offset
+            descs.append((poff, alt_off, R, T, Cc, Rp))
+            mx = max(mx, Cc * T * Rp)
+        arr = np.zeros(len(descs), dtype=[("s", "<i8"), ("d", "<i8"), ("R", "<i4"), ("T", "<i4"), ("C", "<i4"),
+                                          ("Rp", "<i4")])
+        for i, d in enumerate(descs):
+            arr[i] = d
+        dev = torch.from_numpy(arr.view(np.uint8).copy()).to(net.device) if len(descs) else None
+        tab = net._relayout_tab = (dev, len(descs), mx)
+    dev, n, mx = tab
+    if n:
+        _relayout(net.P.data_ptr(), net.Palt.data_ptr(), dev.data_ptr(), n, mx, _stream())
+        _done()
+
+
+def pad_channels(x, c_phys, index=None, scale=1.0, c_true=None):
+    """[N,...,c_in] fp32/u8/bf16 (or a row gather of it via `index`) -> bf16 [...,c_phys];
+    a 1-channel source is replicated to `c_true` channels (DDL.py:119 stacks MNIST x3)."""
+    if not x.is_cuda or not x.is_contiguous():
+        raise ValueError("pad_channels: contiguous cuda tensor required")
+    c_in = x.shape[-1]
+    c_true = c_in if c_true is None else c_true
+    code = {torch.float32: 0, torch.uint8: 1, torch.bfloat16: 2}.get(x.dtype)
+    if code is None:
+        raise ValueError(f"pad_channels: unsupported dtype {x.dtype}")
+    if c_in != 1 and c_in != c_true:
+        raise ValueError("pad_channels: c_true must equal source channels unless replicating 1 channel")
+    pix = int(np.prod(x.shape[1:-1])) if x.dim() > 2 else 1
+    n = x.shape[0] if index is None else index.numel()
+    if index is not None:
+        if index.dtype != torch.int64 or not index.is_cuda:
+            raise ValueError("index must be int64 cuda")
+    out = torch.empty((n,) + tuple(x.shape[1:-1]) + (c_phys,), dtype=torch.bfloat16, device=x.device)
+    _pad_channels(x.data_ptr(), code, _p(index), out.data_ptr(), n * pix, pix, c_in, c_true, c_phys, scale,
+                  _stream())
+    _done()
+    return out
+
+
+def strip_channels(x, c_true):
+    _chk_act(x, "x")
+    rows, Cp = _rows_c(x)
+    out = torch.empty(tuple(x.shape[:-1]) + (c_true,), dtype=torch.float32, device=x.device)
+    _strip_channels(x.data_ptr(), out.data_ptr(), rows, Cp, c_true, _stream())
+    _done()
+    return out
+
+
+# ------------------------------------------------------------------------------ losses
+def _softmax_common(logits, target, mode, want_grad, want_probs=True, n_true=None):
+    _chk_act(logits, "logits")
+    B, Cs = logits.shape
+    N = n_true if target is None else target.shape[1]
+    if N > 64 or N > Cs:
+        raise ValueError("softmax kernels support up to 64 classes")
+    dev = logits.device
+    probs = torch.empty(B, N, dtype=torch.float32, device=dev) if want_probs else None
+    if mode == 0:
+        _softmax_loss(logits.data_ptr(), None, probs.data_ptr(), None, None, None, B, Cs, N, 0, 0, _stream())
+        _done()
+        return None, None, probs
+    if not (target.is_cuda and target.dtype == torch.float32 and target.is_contiguous() and target.shape[0] == B):
+        raise ValueError("target must be contiguous fp32 cuda [B,N]")
+    dl = torch.empty_like(logits) if want_grad else None
+    rowloss = torch.empty(B, dtype=torch.float32, device=dev)
+    loss = torch.empty((), dtype=torch.float32, device=dev)
+    _softmax_loss(logits.data_ptr(), target.data_ptr(), _p(probs), _p(dl), rowloss.data_ptr(), loss.data_ptr(),
+                  B, Cs, N, mode, int(want_grad), _stream())
+    _done()
+    return loss, dl, probs
+
+
+def softmax(logits, n_true=None):
+    return _softmax_common(logits, None, 0, False, True, n_true or logits.shape[1])[2]
+
+
+def softmax_ce(logits, onehot, want_grad=True):
+    return _softmax_common(logits, onehot, 1, want_grad)
+
+
+def softmax_mse(logits, target, want_grad=True):
+    return _softmax_common(logits, target, 2, want_grad)
+
+
+def sigmoid_bce(logits, labels, want_grad=True):
+    x = logits.float().reshape(-1).contiguous()
+    z = labels.float().reshape(-1).contiguous()
+    n = x.numel()
+    rowloss = torch.empty(n, dtype=torch.float32, device=x.device)
+    dl = torch.empty(n, dtype=torch.float32, device=x.device) if want_grad else None
+    loss = torch.empty((), dtype=torch.float32, device=x.device)
+    _sigmoid_bce(x.data_ptr(), z.data_ptr(), rowloss.data_ptr(), _p(dl), loss.data_ptr(), n, _stream())
+    _done()
+    return loss, (dl.reshape(logits.shape) if want_grad else None)
+
+
+def dense1_bce_fwd_bwd(x, w, b, label_first, label_second, n_first, want_dx=True, want_dw=True,
+                       out_dw=None, out_db=None):
+    _chk_act(x, "x")
+    M = x.shape[0]
+    K = x.numel() // M
+    if w.numel() != K or w.dtype != torch.bfloat16 or not w.is_contiguous():
+        raise ValueError(f"dense1_bce: weight must be bf16 with {K} elements")
+    _chk_f32(b, 1, "bias")
+    dev = x.device
+    dx = torch.empty_like(x) if want_dx else None
+    nb = _dense1_blocks(M)
+    dw_part = torch.empty(nb * K, dtype=torch.float32, device=dev) if want_dw else None
+    aux = torch.empty(3, M, dtype=torch.float32, device=dev)       # logits, rowloss, dlogit
+    loss = torch.empty((), dtype=torch.float32, device=dev)
+    if want_dw and out_dw is None:
+        out_dw = torch.empty(K, dtype=torch.float32, device=dev)
+        out_db = torch.empty(1, dtype=torch.float32, device=dev)
+    if want_dw:
+        _chk_f32(out_dw, K, "dw")
+        _chk_f32(out_db, 1, "db")
+    rc = _dense1_bce(x.data_ptr(), w.data_ptr(), b.data_ptr(), label_first, label_second, n_first, M, K,
+                     _p(dx), _p(dw_part), aux[0].data_ptr(), aux[1].data_ptr(), aux[2].data_ptr(),
+                     loss.data_ptr(), _p(out_dw) if want_dw else None, _p(out_db) if want_dw else None,
+                     int(want_dx), int(want_dw), _stream())
+    if rc != 0:
+        raise ValueError(f"dense1_bce: unsupported K={K} (rc={rc})")
+    _done()
+    return loss, dx, out_dw, out_db, aux[0]
+
+
+def argmax_match_count(pred, onehot):
+    pred = pred.float().contiguous()
+    onehot = onehot.float().contiguous()
+    if pred.shape != onehot.shape:
+        raise ValueError("argmax_match_count shape mismatch")
+    cnt = torch.zeros(1, dtype=torch.int32, device=pred.device)
+    _argmax_match(pred.data_ptr(), onehot.data_ptr(), pred.shape[0], pred.shape[1], cnt.data_ptr(), _stream())
+    _done()
+    return cnt[0]
+
+
+# ------------------------------------------------------------------------------ optimizer / rng
+_OPT_KIND = {"adam": 0, "sgd": 1, "rmsprop": 2, "adam_fresh_double": 3}
+
+
+def optimizer_step(opt, grad_scale=1.0, avg_with=None, avg_weight=0.0):
+    net, c = opt.net, opt.cfg
+    n = net.P.numel()
+    if avg_with is not None:
+        _chk_f32(avg_with, n, "avg_with")
+    _optim_step(net.P.data_ptr(), net.G.data_ptr(), _p(opt.m), _p(opt.v), net.Pc.data_ptr(),
+                opt.step_dev.data_ptr(), n, _OPT_KIND[c.kind], c.lr, c.beta1, c.beta2, c.eps, c.rho, grad_scale,
+                _p(avg_with), avg_weight, _stream())
+    _done()
+
+
+def scale_emit(P, Pc, scale):
+    _scale_emit(P.data_ptr(), _p(Pc), P.numel(), scale, _stream())
+    _done()
+
+
+def philox_uniform(shape, dtype, state, lo=-1.0, hi=1.0):
+    if dtype != torch.bfloat16:
+        raise ValueError("device noise is generated in bf16")
+    out = torch.empty(shape, dtype=dtype, device=state.device)
+    _philox(out.data_ptr(), out.numel(), state.data_ptr(), lo, hi, _stream())
+    _done()
+    return out
+
+
+# ------------------------------------------------------------------------------ conv family
+_TAB_CACHE: Dict[Tuple, Tuple] = {}
+
+
+def _tables(g: ConvGeom, mode: str, B: int, device):
+    """Class descriptors + tap tables for the implicit-GEMM kernel (see igemm_conv.hip)."""
+    key = (g, mode, B, str(device))
+    hit = _TAB_CACHE.get(key)
+    if hit is not None:
+        return hit
+    classes, taps = [], []
+    if mode == "fprop":
+        tl = [(kh * g.dh - g.pt, kw * g.dw - g.pl, kh * g.KW + kw, 0) for kh in range(g.KH) for kw in range(g.KW)]
+        classes.append((0, 0, g.OH, g.OW, len(tl), 0, B * g.OH * g.OW, 0))
+        taps += tl
+    else:
+        for ph in range(g.sh):
+            for pw in range(g.sw):
+                Hc = (g.H - ph + g.sh - 1) // g.sh
+                Wc = (g.W - pw + g.sw - 1) // g.sw
+                if Hc <= 0 or Wc <= 0:
+                    continue
+                tl = []
+                for kh in range(g.KH):
+                    th = ph + g.pt - kh * g.dh
+                    if th % g.sh:
+                        continue
+                    for kw in range(g.KW):
+                        tw = pw + g.pl - kw * g.dw
+                        if tw % g.sw:
+                            continue
+                        tl.append((th // g.sh, tw // g.sw, kh * g.KW + kw, 0))
+                classes.append((ph, pw, Hc, Wc, len(tl), len(taps), B * Hc * Wc, 0))
+                taps += tl
+    if not taps:
+        taps = [(0, 0, 0, 0)]
+    ct = torch.tensor(classes, dtype=torch.int32).to(device)
+    tt = torch.tensor(taps, dtype=torch.int32).to(device)
+    res = (ct, tt, len(classes), max(c[6] for c in classes), max(max(c[4] for c in classes), 1))
+    _TAB_CACHE[key] = res
+    return res
+
+
+def _igemm_call(src, wgt, bias, dst, g, mode, B, Hs, Ws, Cs, Hd, Wd, Nd, Nw, ss, sd, act, alpha):
+    ct, tt, ncls, maxM, maxT = _tables(g, mode, B, src.device)
+    rc = _igemm(src.data_ptr(), wgt.data_ptr(), _p(bias), dst.data_ptr(), ct.data_ptr(), tt.data_ptr(), ncls,
+                maxM, maxT, B, Hs, Ws, Cs, Hd, Wd, Nd, Nw, ss[0], ss[1], sd[0], sd[1], g.KH * g.KW,
+                ACT_CODE[act], alpha, IGEMM_TILE, _stream())
+    if rc != 0:
+        raise ValueError(f"igemm_conv rejected the problem (rc={rc}): {g} mode={mode} B={B}")
+    _done()
+
+
+def _chk_w(w, shape, name):
+    if not (w.is_cuda and w.dtype == torch.bfloat16 and w.is_contiguous()):
+        raise ValueError(f"{name}: weights must be contiguous bf16 cuda")
+    if tuple(w.shape) != tuple(shape):
+        raise ValueError(f"{name}: weight shape {tuple(w.shape)} != expected {tuple(shape)}")
+
+
+def conv_fprop(x, wA, bias, g: ConvGeom, act=None, alpha=0.3):
+    _chk_act(x, "x")
+    B = x.shape[0]
+    Ip, Op = pad8(g.I), pad8(g.O)
+    if tuple(x.shape[1:]) != (g.H, g.W, Ip):
+        raise ValueError(f"conv_fprop: x {tuple(x.shape)} does not match geometry {g} (padded I={Ip})")
+    if bias is not None:
+        _chk_f32(bias, g.O, "bias")
+    y = torch.empty(B, g.OH, g.OW, Op, dtype=torch.bfloat16, device=x.device)
+    if g.depthwise:
+        _chk_w(wA, (g.KH, g.KW, Ip), "depthwise kernel")
+        rc = _depthwise(0, x.data_ptr(), wA.data_ptr(), _p(bias), y.data_ptr(), None, B, g.H, g.W, Ip, g.OH, g.OW,
+                        g.KH, g.KW, g.sh, g.sw, g.dh, g.dw, g.pt, g.pl, g.O, ACT_CODE[act], alpha, _stream())
+        if rc:
+            raise ValueError("depthwise fprop rejected")
+        _done()
+        return y
+    if wA.dim() != 4 or wA.shape[1:] != (g.KH, g.KW, Ip) or wA.shape[0] > Op:
+        raise ValueError(f"conv_fprop: weight {tuple(wA.shape)} vs geometry {g}")
+    _chk_w(wA, wA.shape, "kernel")
+    _igemm_call(x, wA, bias, y, g, "fprop", B, g.H, g.W, Ip, g.OH, g.OW, Op, min(wA.shape[0], g.O),
+                (g.sh, g.sw), (1, 1), act, alpha)
+    return y
+
+
+def conv_dgrad(dy, wB, g: ConvGeom, bias=None, act=None, alpha=0.3):
+    _chk_act(dy, "dy")
+    B = dy.shape[0]
+    Ip, Op = pad8(g.I), pad8(g.O)
+    if tuple(dy.shape[1:]) != (g.OH, g.OW, Op):
+        raise ValueError(f"conv_dgrad: dy {tuple(dy.shape)} does not match geometry {g} (padded O={Op})")
+    if bias is not None:
+        _chk_f32(bias, g.I, "bias")
+    dx = torch.empty(B, g.H, g.W, Ip, dtype=torch.bfloat16, device=dy.device)
+    if g.depthwise:
+        _chk_w(wB, (g.KH, g.KW, Ip), "depthwise kernel")
+        if bias is not None or act not in (None, "linear"):
+            raise ValueError("depthwise dgrad has no fused epilogue")
+        rc = _depthwise(1, dy.data_ptr(), wB.data_ptr(), None, dx.data_ptr(), None, B, g.H, g.W, Ip, g.OH, g.OW,
+                        g.KH, g.KW, g.sh, g.sw, g.dh, g.dw, g.pt, g.pl, g.O, 0, 0.0, _stream())
+        if rc:
+            raise ValueError("depthwise dgrad rejected")
+        _done()
+        return dx
+    if wB.dim() != 4 or wB.shape[1:] != (g.KH, g.KW, Op) or wB.shape[0] > Ip:
+        raise ValueError(f"conv_dgrad: weight {tuple(wB.shape)} vs geometry {g}")
+    _chk_w(wB, wB.shape, "kernel")
+    _igemm_call(dy, wB, bias, dx, g, "dgrad", B, g.OH, g.OW, Op, g.H, g.W, Ip, min(wB.shape[0], g.I),
+                (1, 1), (g.sh, g.sw), act, alpha)
+    return dx
+
+
+def conv_wgrad(x, dy, g: ConvGeom, layout="A", out=None):
+    _chk_act(x, "x")
+    _chk_act(dy, "dy")
+    B = x.shape[0]
+    Ip, Op = pad8(g.I), pad8(g.O)
+    if tuple(x.shape) != (B, g.H, g.W, Ip) or tuple(dy.shape) != (B, g.OH, g.OW, Op):
+        raise ValueError(f"conv_wgrad: x {tuple(x.shape)} / dy {tuple(dy.shape)} vs geometry {g}")
+    dev = x.device
+    T = g.KH * g.KW
+    if g.depthwise:
+        if out is None:
+            out = torch.empty(g.KH, g.KW, Ip, dtype=torch.float32, device=dev)
+        _chk_f32(out, T * Ip, "dW")
+        nb = _dw_blocks(B * g.OH * g.OW, Ip)
+        part = torch.empty(nb * T * Ip, dtype=torch.float32, device=dev)
+        rc = _depthwise(2, dy.data_ptr(), x.data_ptr(), None, out.data_ptr(), part.data_ptr(), B, g.H, g.W, Ip,
+                        g.OH, g.OW, g.KH, g.KW, g.sh, g.sw, g.dh, g.dw, g.pt, g.pl, g.O, 0, 0.0, _stream())
+        if rc:
+            raise ValueError("depthwise wgrad rejected")
+        _done()
+        return out
+    if layout == "A":            # [O][T][Ip]
+        shape = (g.O, g.KH, g.KW, Ip)
+        n_lim, c_lim, sn, st, sc = g.O, Ip, T * Ip, Ip, 1
+    else:                        # [I][T][Op]
+        shape = (g.I, g.KH, g.KW, Op)
+        n_lim, c_lim, sn, st, sc = Op, g.I, 1, Op, T * Op
+    numel = int(np.prod(shape))
+    if out is None:
+        out = torch.empty(shape, dtype=torch.float32, device=dev)
+    if out.numel() != numel:
+        raise ValueError(f"conv_wgrad: out has {out.numel()} elements, expected {numel} for layout {layout}")
+    _chk_f32(out, numel, "dW")
+    M = B * g.OH * g.OW
+    ksplit = _wgrad_ksplit(M, T, n_lim, c_lim)
+    slab = torch.empty(ksplit * numel, dtype=torch.float32, device=dev) if ksplit > 1 else None
+    rc = _wgrad(dy.data_ptr(), x.data_ptr(), out.data_ptr(), _p(slab), numel, ksplit, B, g.OH, g.OW, Op, g.H,
+                g.W, Ip, g.KH, g.KW, g.sh, g.sw, g.dh, g.dw, g.pt, g.pl, n_lim, c_lim, sn, st, sc, _stream())
+    if rc:
+        raise ValueError(f"conv_wgrad rejected the problem (rc={rc}): {g}")
+    _done()
+    return out

@@ -1,0 +1,322 @@
+"""HIP kernels vs the fp32 CPU oracle (ops/cpu_ref.py) on bf16-rounded inputs.
+
+Inputs are rounded to bf16 first, so the only differences left are fp32 accumulation order and
+the final bf16 rounding of the kernel output (rel ~ 2^-8)."""
+import math
+
+import pytest
+import torch
+
+from distributeddeeplearning_amd.ops import cpu_ref
+from distributeddeeplearning_amd.ops import geometry as G
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def hip():
+    from distributeddeeplearning_amd.ops import hip as h
+    return h
+
+
+def r16(t):
+    return t.bfloat16().float()
+
+
+def dev(hip, x):
+    """logical fp32 [.., C] -> device bf16 padded"""
+    return hip.pad_channels(x.contiguous().cuda(), hip.pad8(x.shape[-1]))
+
+
+def host(hip, y, c):
+    return hip.strip_channels(y, c).cpu()
+
+
+def padw(hip, w, lead_true=True):
+    """[R][KH][KW][C] logical -> bf16 device with C padded"""
+    Cp = hip.pad8(w.shape[-1])
+    out = torch.zeros(*w.shape[:-1], Cp)
+    out[..., :w.shape[-1]] = w
+    return out.bfloat16().cuda().contiguous()
+
+
+def close(a, b, rtol=2e-2, atol=None):
+    scale = b.abs().max().item() + 1e-6
+    atol = atol if atol is not None else 1e-2 * scale
+    assert a.shape == b.shape, (a.shape, b.shape)
+    err = (a - b).abs()
+    bad = err > (atol + rtol * b.abs())
+    assert not bad.any(), f"max err {err.max().item():.4g} (scale {scale:.4g}), {int(bad.sum())} bad"
+
+
+CONV_CASES = [
+    # H, W, I, O, k, s, d, padding, act
+    (28, 28, 1, 32, (5, 5), (2, 2), (1, 1), "same", "leaky"),        # D1
+    (14, 14, 32, 64, (5, 5), (2, 2), (1, 1), "same", "linear"),      # D3
+    (7, 7, 64, 128, (5, 5), (2, 2), (1, 1), "same", "linear"),       # D6
+    (28, 28, 3, 19, (29, 27), (1, 1), (1, 1), "same", "softsign"),   # DDL.py kernel larger than image
+    (28, 28, 1, 32, (1, 1), (1, 1), (2, 2), "valid", "sigmoid"),     # model1 conv2d_1
+    (28, 28, 32, 128, (1, 1), (3, 3), (1, 1), "valid", "relu"),      # model1 conv2d_2
+    (26, 26, 128, 8, (3, 3), (3, 3), (1, 1), "valid", "sigmoid"),    # model3 conv2d_5
+    (13, 11, 16, 24, (3, 2), (1, 2), (2, 1), "valid", "tanh"),
+    (9, 9, 40, 72, (3, 3), (1, 1), (1, 1), "same", "softplus"),
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+@pytest.mark.parametrize("B", [3, 70])
+def test_conv_fprop_dgrad_wgrad(hip, case, B):
+    H, W, I, O, k, s, d, pad, act = case
+    g = G.conv2d_geom(H, W, I, O, k, s, d, pad)
+    torch.manual_seed(1)
+    x = r16(torch.randn(B, H, W, I))
+    w = r16(torch.randn(O, k[0], k[1], I) / math.sqrt(k[0] * k[1] * I))
+    b = torch.randn(O)
+    y_ref = cpu_ref.conv_fprop(x, w, b, g, act)
+    y = hip.conv_fprop(dev(hip, x), padw(hip, w), b.cuda(), g, act)
+    assert y.shape[-1] == hip.pad8(O)
+    if hip.pad8(O) != O:
+        assert float(y[..., O:].float().abs().max()) == 0.0
+    close(host(hip, y, O), y_ref)
+    # dgrad (weights in layout B = [I][KH][KW][Op])
+    dy = r16(torch.randn(B, g.OH, g.OW, O))
+    dx_ref = cpu_ref.conv_dgrad(dy, w, g)
+    wB = padw(hip, w.permute(3, 1, 2, 0).contiguous())
+    dx = hip.conv_dgrad(dev(hip, dy), wB, g)
+    close(host(hip, dx, I), dx_ref)
+    # wgrad, both layouts
+    dw_ref = cpu_ref.conv_wgrad(x, dy, g)
+    dwA = hip.conv_wgrad(dev(hip, x), dev(hip, dy), g, "A").cpu()
+    close(dwA[..., :I], dw_ref, rtol=1e-2)
+    if hip.pad8(I) != I:
+        assert float(dwA[..., I:].abs().max()) == 0.0
+    dwB = hip.conv_wgrad(dev(hip, x), dev(hip, dy), g, "B").cpu()
+    close(dwB[..., :O], dw_ref.permute(3, 1, 2, 0), rtol=1e-2)
+
+
+CONVT_CASES = [
+    # H, W, Cin, filters, k, s, d, padding, act   (layer view)
+    (7, 7, 128, 64, (5, 5), (2, 2), (1, 1), "same", "relu"),         # G2
+    (14, 14, 64, 32, (5, 5), (2, 2), (1, 1), "same", "relu"),        # G4
+    (28, 28, 32, 1, (5, 5), (1, 1), (1, 1), "same", "tanh01"),       # G6
+    (28, 28, 1, 64, (3, 3), (2, 2), (1, 1), "valid", "softplus"),    # model0 conv2d_transpose_1
+    (8, 8, 8, 128, (1, 1), (2, 2), (2, 2), "valid", "relu"),         # model3 conv2d_transpose_4 (empty parity classes)
+    (16, 16, 128, 32, (2, 2), (2, 2), (3, 3), "valid", "softplus"),  # model3 conv2d_transpose_5
+    (3, 3, 128, 32, (3, 3), (2, 2), (2, 2), "valid", "softsign"),    # model1 conv2d_transpose_3
+    (5, 6, 24, 12, (3, 2), (3, 1), (1, 1), "valid", "sigmoid"),
+]
+
+
+@pytest.mark.parametrize("case", CONVT_CASES)
+def test_conv_transpose(hip, case):
+    H, W, Cin, Fo, k, s, d, pad, act = case
+    g = G.conv2d_transpose_geom(H, W, Cin, Fo, k, s, d, pad)
+    B = 5
+    torch.manual_seed(2)
+    x = r16(torch.randn(B, H, W, Cin))
+    w = r16(torch.randn(Fo, k[0], k[1], Cin) / math.sqrt(k[0] * k[1] * Cin))   # canonical [filters][KH][KW][in]
+    b = torch.randn(Fo)
+    wA = w.permute(3, 1, 2, 0).contiguous()                                       # core [O=in][T][I=filters]
+    y_ref = cpu_ref.conv_dgrad(x, wA, g, b, act)
+    y = hip.conv_dgrad(dev(hip, x), padw(hip, w), g, b.cuda(), act)
+    assert tuple(y.shape[1:3]) == (g.H, g.W)
+    close(host(hip, y, Fo), y_ref)
+    if hip.pad8(Fo) != Fo:
+        assert float(y[..., Fo:].float().abs().max()) == 0.0
+    dout = r16(torch.randn(B, g.H, g.W, Fo))
+    dx_ref = cpu_ref.conv_fprop(dout, wA, None, g)
+    dx = hip.conv_fprop(dev(hip, dout), padw(hip, wA), None, g)
+    close(host(hip, dx, Cin), dx_ref)
+    dw_ref = cpu_ref.conv_wgrad(dout, x, g).permute(3, 1, 2, 0)                  # -> canonical
+    dw = hip.conv_wgrad(dev(hip, dout), dev(hip, x), g, "B").cpu()
+    close(dw[..., :Cin], dw_ref, rtol=1e-2)
+
+
+@pytest.mark.parametrize("case", [(57, 57, 128, (3, 3), (2, 2)), (28, 28, 12, (3, 3), (1, 1)),
+                                  (10, 10, 128, (2, 2), (3, 3)), (18, 18, 16, (3, 2), (1, 2))])
+def test_depthwise(hip, case):
+    H, W, Cc, k, s = case
+    g = G.depthwise_geom(H, W, Cc, k, s, (2, 2), "valid", keras224_compat=True)
+    B = 3
+    torch.manual_seed(3)
+    x = r16(torch.randn(B, H, W, Cc))
+    w = r16(torch.randn(k[0], k[1], Cc))
+    b = torch.randn(Cc)
+    y_ref = cpu_ref.conv_fprop(x, w, b, g, "tanh")
+    y = hip.conv_fprop(dev(hip, x), padw(hip, w), b.cuda(), g, "tanh")
+    close(host(hip, y, Cc), y_ref)
+    dy = r16(torch.randn(B, g.OH, g.OW, Cc))
+    close(host(hip, hip.conv_dgrad(dev(hip, dy), padw(hip, w), g), Cc), cpu_ref.conv_dgrad(dy, w, g))
+    dw = hip.conv_wgrad(dev(hip, x), dev(hip, dy), g).cpu()
+    close(dw[..., :Cc], cpu_ref.conv_wgrad(x, dy, g), rtol=1e-2)
+
+
+def test_dense_large_k(hip):
+    g = G.dense_geom(86528, 10)           # model0 dense_1
+    B = 32
+    torch.manual_seed(4)
+    x = r16(torch.randn(B, 1, 1, 86528))
+    w = r16(torch.randn(10, 1, 1, 86528) / 300)
+    y = hip.conv_fprop(dev(hip, x), padw(hip, w), None, g)
+    close(host(hip, y, 10), cpu_ref.conv_fprop(x, w, None, g))
+    dy = r16(torch.randn(B, 1, 1, 10))
+    dw = hip.conv_wgrad(dev(hip, x), dev(hip, dy), g, "A").cpu()
+    close(dw, cpu_ref.conv_wgrad(x, dy, g), rtol=1e-2)
+
+
+@pytest.mark.parametrize("shape", [(2000, 7, 7, 64), (64, 13), (33, 5, 5, 19)])
+@pytest.mark.parametrize("post,prev", [(None, "relu"), ("leaky", None), (None, "softsign")])
+@pytest.mark.parametrize("train", [True, False])
+def test_batchnorm(hip, shape, post, prev, train):
+    Cc = shape[-1]
+    Cp = hip.pad8(Cc)
+    torch.manual_seed(5)
+    x = r16(torch.rand(*shape) * 3 + 0.1) if prev else r16(torch.randn(*shape) * 2 + 1)
+    if prev:
+        x = r16(cpu_ref.act_fwd(x, prev))
+    gamma, beta = torch.rand(Cc) + 0.5, torch.randn(Cc)
+    mm, mv = torch.randn(Cc) * 0.1, torch.rand(Cc) + 0.5
+
+    def p(t, fill=0.0):
+        o = torch.full((Cp,), fill)
+        o[:Cc] = t
+        return o.cuda()
+
+    gd, bd, mmd, mvd = p(gamma, 1.0), p(beta), p(mm), p(mv, 1.0)
+    xd = dev(hip, x)
+    bessel = len(shape) == 4
+    if train:
+        mean, var = cpu_ref.bn_stats(x)
+        invstd = torch.rsqrt(var + 1e-3)
+        scale, shift, mean_d, invstd_d = hip.bn_train_affine(xd, gd, bd, mmd, mvd, 0.99, 1e-3, bessel, True)
+        close(mean_d[:Cc].cpu(), mean, rtol=1e-4, atol=1e-4)
+        close(invstd_d[:Cc].cpu(), invstd, rtol=1e-3, atol=1e-4)
+        n = x.numel() // Cc
+        v = var * n / (n - 1) if bessel else var
+        close(mmd[:Cc].cpu(), mm * 0.99 + mean * 0.01, rtol=1e-4, atol=1e-5)
+        close(mvd[:Cc].cpu(), mv * 0.99 + v * 0.01, rtol=1e-4, atol=1e-5)
+    else:
+        mean, invstd = mm, torch.rsqrt(mv + 1e-3)
+        scale, shift, invstd_d = hip.bn_infer_affine(gd, bd, mmd, mvd, 1e-3)
+        mean_d = mmd
+    sc = gamma * invstd
+    y_ref = cpu_ref.bn_apply(x, sc, beta - mean * sc, post)
+    y = hip.bn_apply(xd, scale, shift, post, 0.3, Cc)
+    close(host(hip, y, Cc), y_ref)
+    dy = r16(torch.randn(*shape))
+    dx_ref, dg_ref, db_ref = cpu_ref.bn_bwd(dy, x, r16(y_ref), mean, invstd, gamma, post, 0.3, train, prev)
+    dx, dg, db = hip.bn_bwd(dev(hip, dy), xd, y, mean_d, invstd_d, gd, post, 0.3, train, prev)
+    close(host(hip, dx, Cc), dx_ref, rtol=3e-2)
+    close(dg[:Cc].cpu(), dg_ref, rtol=2e-2)
+    close(db[:Cc].cpu(), db_ref, rtol=2e-2)
+
+
+@pytest.mark.parametrize("kind", ["relu", "sigmoid", "softplus", "tanh", "softsign", "leaky", "tanh01"])
+def test_activations(hip, kind):
+    torch.manual_seed(6)
+    x = r16(torch.randn(37, 9, 11) * 3)
+    y_ref = cpu_ref.act_fwd(x, kind)
+    y = hip.act_fwd(dev(hip, x), kind, 0.3, 11)
+    close(host(hip, y, 11), y_ref, atol=1e-2)
+    assert float(y[..., 11:].float().abs().max()) == 0.0
+    dy = r16(torch.randn_like(x))
+    dx = hip.act_bwd(dev(hip, dy), y, kind)
+    close(host(hip, dx, 11), cpu_ref.act_bwd(dy, host(hip, y, 11), kind), atol=2e-2)
+
+
+def test_bias_grad_and_pad(hip):
+    torch.manual_seed(7)
+    dy = r16(torch.randn(500, 7, 7, 19))
+    out = torch.zeros(19, device="cuda")
+    hip.bias_grad(dev(hip, dy), out)
+    close(out.cpu(), cpu_ref.bias_grad(dy), rtol=1e-3)
+    x = r16(torch.randn(4, 5, 6, 8))
+    y = hip.spatial_pad(dev(hip, x), 1, 2, 3, 0)
+    ref = torch.nn.functional.pad(x, (0, 0, 3, 0, 1, 2))
+    assert torch.equal(host(hip, y, 8), ref)
+    z = hip.spatial_pad(y, -1, -2, -3, 0)
+    assert torch.equal(host(hip, z, 8), x)
+    # uint8 gather + 1->3 channel replicate
+    img = torch.randint(0, 256, (10, 28, 28, 1), dtype=torch.uint8)
+    idx = torch.tensor([3, 3, 9, 0])
+    o = hip.pad_channels(img.cuda(), 8, idx.cuda(), 1.0, 3)
+    ref = img[idx].float().expand(-1, -1, -1, 3)
+    assert torch.equal(host(hip, o, 3), ref)
+    assert float(o[..., 3:].float().abs().max()) == 0.0
+
+
+def test_softmax_losses(hip):
+    torch.manual_seed(8)
+    B, N = 300, 10
+    logits = r16(torch.randn(B, N) * 4)
+    onehot = torch.nn.functional.one_hot(torch.randint(0, N, (B,)), N).float()
+    ld = dev(hip, logits)
+    loss, dl, p = hip.softmax_ce(ld, onehot.cuda())
+    lr, dlr, pr = cpu_ref.softmax_ce(logits, onehot)
+    assert abs(float(loss) - float(lr)) < 1e-4 * max(1, abs(float(lr)))
+    close(p.cpu(), pr, rtol=1e-4, atol=1e-6)
+    close(host(hip, dl, N), dlr, rtol=1e-2, atol=1e-5)
+    loss, dl, p = hip.softmax_mse(ld, onehot.cuda())
+    lr, dlr, pr = cpu_ref.softmax_mse(logits, onehot)
+    assert abs(float(loss) - float(lr)) < 1e-5
+    close(host(hip, dl, N), dlr, rtol=1e-2, atol=1e-6)
+    close(hip.softmax(ld, N).cpu(), pr, rtol=1e-4, atol=1e-6)
+    cnt = hip.argmax_match_count(p, onehot.cuda())
+    assert int(cnt) == int(cpu_ref.argmax_match_count(pr, onehot))
+    x = torch.randn(77, 1) * 3
+    z = (torch.rand(77, 1) > 0.5).float()
+    l1, d1 = hip.sigmoid_bce(x.cuda(), z.cuda())
+    l2, d2 = cpu_ref.sigmoid_bce(x, z)
+    assert abs(float(l1) - float(l2)) < 1e-5
+    close(d1.cpu(), d2, rtol=1e-4, atol=1e-7)
+
+
+@pytest.mark.parametrize("M,nf", [(2000, 1000), (1000, 1000), (7, 3)])
+def test_dense1_bce(hip, M, nf):
+    torch.manual_seed(9)
+    K = 2048
+    x = r16(torch.randn(M, 4, 4, 128))
+    w = r16(torch.randn(1, K) * 0.05)
+    b = torch.tensor([0.3])
+    lr, dxr, dwr, dbr, lgr = cpu_ref.dense1_bce_fwd_bwd(x, w, b, 1.0, 0.0, nf)
+    loss, dx, dw, db, lg = hip.dense1_bce_fwd_bwd(dev(hip, x), w.bfloat16().cuda(), b.cuda(), 1.0, 0.0, nf)
+    close(lg.cpu(), lgr, rtol=1e-3, atol=1e-3)
+    assert abs(float(loss) - float(lr)) < 1e-4
+    close(host(hip, dx, 128), dxr, rtol=1e-2)
+    close(dw.cpu().reshape(-1), dwr.reshape(-1), rtol=1e-3)
+    close(db.cpu(), dbr, rtol=1e-3, atol=1e-6)
+
+
+@pytest.mark.parametrize("kind", ["adam", "sgd", "rmsprop", "adam_fresh_double"])
+def test_optimizers_match_oracle(hip, kind):
+    from distributeddeeplearning_amd.models import ir
+    from distributeddeeplearning_amd.models.network import Network
+    from distributeddeeplearning_amd.models.optim import FlatOptimizer, OptimConfig
+    n = ir.NameScope()
+    spec = ir.ModelSpec("m", [ir.Input(n("input"), (16,))]).append(ir.Dense(n("dense"), 24, "relu")).append(
+        ir.Dense(n("dense"), 8))
+    cpu, gpu = Network(spec, "cpu", 3), Network(spec, "cuda", 3)
+    assert torch.allclose(gpu.P.cpu(), cpu.P)
+    cfg = OptimConfig(kind=kind, lr=1e-2, eps=1e-7)
+    oc, og = FlatOptimizer(cpu, cfg), FlatOptimizer(gpu, cfg)
+    for it in range(4):
+        g = torch.randn_like(cpu.P)
+        cpu.G.copy_(g)
+        gpu.G.copy_(g)
+        oc.step()
+        og.step()
+        assert torch.allclose(gpu.P.cpu(), cpu.P, rtol=1e-5, atol=1e-6), (kind, it)
+        assert torch.allclose(gpu.Pc.float().cpu(), cpu.P, rtol=1e-2, atol=1e-3)
+    # alternate layout copy follows the master
+    op = gpu.ops[0]
+    assert torch.allclose(op.w_alt.float().cpu(), op.kernel.t().cpu(), rtol=1e-2, atol=1e-3)
+
+
+def test_philox(hip):
+    st = torch.zeros(2, dtype=torch.int64, device="cuda")
+    st[0] = 1234
+    a = hip.philox_uniform((1000, 128), torch.bfloat16, st).float()
+    b = hip.philox_uniform((1000, 128), torch.bfloat16, st).float()
+    assert int(st[1]) == 2
+    assert a.min() >= -1 and a.max() <= 1 and not torch.equal(a, b)
+    assert abs(float(a.mean())) < 0.01 and abs(float(a.var()) - 1 / 3) < 0.01
