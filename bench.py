@@ -1,0 +1,93 @@
+#!/usr/bin/env python3
+"""Headline benchmark: DCGAN 28x28 (GAN_distributed graphs) data-parallel training, bf16, images/s.
+
+    python bench.py --gpus N --steps K --warmup W            (N == 1)
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One step = the reference iteration (/root/reference/GAN_distributed.py:133-135): a D update on
+[B real ; B generated] and a G update on B noise vectors, Adam(2e-4), per rank, with one flat
+RCCL all-reduce per network per step.  B = 1000 per GPU as in the reference (weak scaling: the
+global batch grows with N).  `value` = real images consumed per second by the whole job.
+Other BASELINE.json configs: --config dcgan64 | classifier | localsgd.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--config", default="dcgan28", choices=["dcgan28", "dcgan64", "classifier", "localsgd"])
+    ap.add_argument("--batch", type=int, default=0, help="per-GPU real images per step (0 = config default)")
+    ap.add_argument("--graph", default="on", choices=["on", "off", "full"],
+                    help="hipGraph capture: on = segments around collectives, full = capture RCCL too")
+    ap.add_argument("--comm-dtype", default="fp32", choices=["fp32", "bf16"])
+    ap.add_argument("--avg-every", type=int, default=8, help="local-SGD averaging period (config localsgd)")
+    ap.add_argument("--device", default="cuda")
+    a = ap.parse_args()
+
+    from distributeddeeplearning_amd.parallel import ddp
+    on_gpu = a.device == "cuda"
+    if on_gpu and not torch.cuda.is_available():
+        print("bench.py needs a GPU (use --device cpu for a plumbing run)", file=sys.stderr)
+        sys.exit(2)
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    device = torch.device(f"cuda:{local}") if on_gpu else torch.device("cpu")
+    if on_gpu:
+        torch.cuda.set_device(device)
+    rank, world, _ = ddp.init_process_group(device=device)
+    if world != a.gpus:
+        if rank == 0:
+            print(f"warning: --gpus {a.gpus} but WORLD_SIZE={world}; using {world}", file=sys.stderr)
+    dp = None
+    if world > 1:
+        dp = ddp.FlatDataParallel(comm_dtype=torch.bfloat16 if a.comm_dtype == "bf16" else None)
+
+    from distributeddeeplearning_amd import benchmarks
+    runner = benchmarks.make(a.config, device, dp, rank, a)
+    runner.setup()
+
+    def sync():
+        if world > 1:
+            torch.distributed.barrier()
+        if on_gpu:
+            torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        runner.step()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        runner.step()
+    sync()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=device)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = float(t.item())
+    info = runner.describe()
+    images = info["images_per_step_per_rank"] * world * a.steps
+    if rank == 0:
+        out = {"metric": info["metric"], "value": images / dt, "unit": "images/s", "n_gpus": world,
+               "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,
+               "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+               "dtype": "bf16" if on_gpu else "fp32", "data": "synthetic", "config": info["config"]}
+        out["config"]["parallelism"] = f"dp{world}"
+        out["config"]["global_batch"] = info["images_per_step_per_rank"] * world
+        out.update(info.get("extra", {}))
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

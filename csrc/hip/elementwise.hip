@@ -100,14 +100,44 @@ __global__ __launch_bounds__(EW_BLOCK) void colreduce_kernel(
 #pragma unroll
     for (int j = 0; j < 8; ++j) { red[threadIdx.x][j] = s0[j]; red[threadIdx.x][8 + j] = s1[j]; }
     __syncthreads();
-    if (rl == 0 && g < cg) {
-        for (int q = 1; q < rpi; ++q) {
+    // tree reduction over the row-lane dimension (rpi lanes share one channel group)
+    int half = 1;
+    while (half < rpi) half <<= 1;
+    for (half >>= 1; half > 0; half >>= 1) {
+        if (rl < half && rl + half < rpi) {
 #pragma unroll
-            for (int j = 0; j < 16; ++j) red[threadIdx.x][j] += red[threadIdx.x + q * cgl][j];
+            for (int j = 0; j < 16; ++j) red[threadIdx.x][j] += red[threadIdx.x + half * cgl][j];
         }
+        __syncthreads();
+    }
+    if (rl == 0 && g < cg) {
         float* p = part + (size_t)blockIdx.x * 2 * C;
 #pragma unroll
         for (int j = 0; j < 8; ++j) { p[g * 8 + j] = red[threadIdx.x][j]; p[C + g * 8 + j] = red[threadIdx.x][8 + j]; }
+    }
+}
+
+// Sum block partials part[b][2][C] for channel c with 8 cooperating lanes per channel
+// (blockDim = 256 = 32 channels x 8 partial lanes); result valid where lane_b == 0.
+#define FIN_BLOCK 256
+__device__ __forceinline__ void reduce_partials(const float* __restrict__ part, int nblocks, int C, int c,
+                                                bool two, double& s0, double& s1) {
+    __shared__ double fin[2][8][33];
+    const int cl = threadIdx.x & 31, lb = threadIdx.x >> 5;
+    double a0 = 0, a1 = 0;
+    if (c < C) {
+        for (int b = lb; b < nblocks; b += 8) {
+            a0 += part[(size_t)b * 2 * C + c];
+            if (two) a1 += part[(size_t)b * 2 * C + C + c];
+        }
+    }
+    fin[0][lb][cl] = a0;
+    fin[1][lb][cl] = a1;
+    __syncthreads();
+    s0 = s1 = 0;
+    if (lb == 0) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) { s0 += fin[0][q][cl]; s1 += fin[1][q][cl]; }
     }
 }
 
@@ -117,7 +147,7 @@ static inline void colreduce_grid(long rows, int C, dim3* grid) {
     int rpi = EW_BLOCK / cgl;
     long nb = (rows + (long)rpi * 8 - 1) / ((long)rpi * 8);      // >= 8 rows per thread
     if (nb < 1) nb = 1;
-    if (nb > 1024) nb = 1024;
+    if (nb > 512) nb = 512;
     *grid = dim3((unsigned)nb, (unsigned)((cg + EW_BLOCK - 1) / EW_BLOCK), 1);
 }
 
@@ -134,10 +164,10 @@ __global__ void bn_stats_finalize_kernel(const float* __restrict__ part, int nbl
                                          float eps, int bessel, int update_moving, float* __restrict__ scale,
                                          float* __restrict__ shift, float* __restrict__ mean_out,
                                          float* __restrict__ invstd_out) {
-    int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    double s0 = 0, s1 = 0;
-    for (int b = 0; b < nblocks; ++b) { s0 += part[(size_t)b * 2 * C + c]; s1 += part[(size_t)b * 2 * C + C + c]; }
+    int c = blockIdx.x * 32 + (threadIdx.x & 31);
+    double s0, s1;
+    reduce_partials(part, nblocks, C, c, true, s0, s1);
+    if (c >= C || (threadIdx.x >> 5) != 0) return;
     double mean = s0 / (double)rows;
     double var = s1 / (double)rows - mean * mean;
     if (var < 0) var = 0;
@@ -162,7 +192,7 @@ DDL_API void ddl_bn_batch_stats(const void* x, long rows, int C, float* part, co
     colreduce_grid(rows, C, &grid);
     colreduce_kernel<0><<<grid, EW_BLOCK, 0, s>>>((const uint4*)x, nullptr, nullptr, nullptr, nullptr, part,
                                                   rows, C, 0, 0.f);
-    bn_stats_finalize_kernel<<<(C + 127) / 128, 128, 0, s>>>(part, grid.x, C, rows, gamma, beta, mm, mv,
+    bn_stats_finalize_kernel<<<(C + 31) / 32, FIN_BLOCK, 0, s>>>(part, grid.x, C, rows, gamma, beta, mm, mv,
                                                              momentum, eps, bessel, update_moving, scale,
                                                              shift, mean, invstd);
 }
@@ -213,10 +243,10 @@ DDL_API void ddl_bn_apply(const void* x, void* y, const float* scale, const floa
 __global__ void bn_bwd_finalize_kernel(const float* __restrict__ part, int nblocks, int C, long rows,
                                        int train_stats, float* __restrict__ dgamma, float* __restrict__ dbeta,
                                        float* __restrict__ c1, float* __restrict__ c2) {
-    int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    double s0 = 0, s1 = 0;
-    for (int b = 0; b < nblocks; ++b) { s0 += part[(size_t)b * 2 * C + c]; s1 += part[(size_t)b * 2 * C + C + c]; }
+    int c = blockIdx.x * 32 + (threadIdx.x & 31);
+    double s0, s1;
+    reduce_partials(part, nblocks, C, c, true, s0, s1);
+    if (c >= C || (threadIdx.x >> 5) != 0) return;
     if (dbeta) dbeta[c] = (float)s0;
     if (dgamma) dgamma[c] = (float)s1;
     c1[c] = train_stats ? (float)(s0 / (double)rows) : 0.f;
@@ -260,7 +290,7 @@ DDL_API void ddl_bn_bwd(const void* dy, const void* x, const void* y, void* dx, 
     colreduce_grid(rows, C, &grid);
     colreduce_kernel<1><<<grid, EW_BLOCK, 0, s>>>((const uint4*)dy, (const uint4*)x, (const uint4*)y, mean,
                                                   invstd, part, rows, C, act, alpha);
-    bn_bwd_finalize_kernel<<<(C + 127) / 128, 128, 0, s>>>(part, grid.x, C, rows, train_stats, dgamma, dbeta,
+    bn_bwd_finalize_kernel<<<(C + 31) / 32, FIN_BLOCK, 0, s>>>(part, grid.x, C, rows, train_stats, dgamma, dbeta,
                                                            c1, c2);
     long n8 = rows * (C / 8);
     bn_bwd_apply_kernel<<<ew_grid(n8), EW_BLOCK, 0, s>>>((const uint4*)dy, (const uint4*)x, (const uint4*)y,
@@ -271,10 +301,10 @@ DDL_API void ddl_bn_bwd(const void* dy, const void* x, const void* y, void* dx, 
 // bias gradient = per-channel column sum of dY
 __global__ void colsum_finalize_kernel(const float* __restrict__ part, int nblocks, int C, int c_out,
                                        float* __restrict__ out) {
-    int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= c_out) return;
-    double s0 = 0;
-    for (int b = 0; b < nblocks; ++b) s0 += part[(size_t)b * 2 * C + c];
+    int c = blockIdx.x * 32 + (threadIdx.x & 31);
+    double s0, s1;
+    reduce_partials(part, nblocks, C, c, false, s0, s1);
+    if (c >= c_out || (threadIdx.x >> 5) != 0) return;
     out[c] = (float)s0;
 }
 
@@ -284,7 +314,7 @@ DDL_API void ddl_bias_grad(const void* dy, long rows, int C, int c_out, float* p
     colreduce_grid(rows, C, &grid);
     colreduce_kernel<2><<<grid, EW_BLOCK, 0, s>>>((const uint4*)dy, nullptr, nullptr, nullptr, nullptr, part,
                                                   rows, C, 0, 0.f);
-    colsum_finalize_kernel<<<(c_out + 127) / 128, 128, 0, s>>>(part, grid.x, C, c_out, out);
+    colsum_finalize_kernel<<<(c_out + 31) / 32, FIN_BLOCK, 0, s>>>(part, grid.x, C, c_out, out);
 }
 
 // ------------------------------------------------------------------------------ casts / layout

@@ -179,26 +179,37 @@ __global__ __launch_bounds__(HEAD_ROWS * 64) void dense1_bce_kernel(
     for (int i = threadIdx.x; i < K; i += blockDim.x) dw_part[(size_t)blockIdx.x * K + i] = red[i];
 }
 
-__global__ void head_finalize_kernel(const float* __restrict__ dw_part, int nblocks, int K,
-                                     const float* __restrict__ dlogit, int M, float* __restrict__ dw,
-                                     float* __restrict__ db) {
-    int k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k < K) {
-        double s = 0;
-        for (int b = 0; b < nblocks; ++b) s += dw_part[(size_t)b * K + k];
-        dw[k] = (float)s;
+// dw[k] = sum_b dw_part[b][k]: 256 threads = 32 k-columns x 8 partial lanes; block 0 also sums db.
+__global__ __launch_bounds__(256) void head_finalize_kernel(const float* __restrict__ dw_part, int nblocks, int K,
+                                                            const float* __restrict__ dlogit, int M,
+                                                            float* __restrict__ dw, float* __restrict__ db) {
+    __shared__ double fin[8][33];
+    __shared__ float wsum[4];
+    const int cl = threadIdx.x & 31, lb = threadIdx.x >> 5;
+    const int k = blockIdx.x * 32 + cl;
+    double s = 0;
+    if (k < K) for (int b = lb; b < nblocks; b += 8) s += dw_part[(size_t)b * K + k];
+    fin[lb][cl] = s;
+    __syncthreads();
+    if (lb == 0 && k < K) {
+        double t = 0;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) t += fin[q][cl];
+        dw[k] = (float)t;
     }
-    if (blockIdx.x == 0 && threadIdx.x < 64) {
-        double s = 0;
-        for (int i = threadIdx.x; i < M; i += 64) s += dlogit[i];
-        float t = wave_sum((float)s);
-        if (threadIdx.x == 0) db[0] = t;
+    if (blockIdx.x == 0) {
+        float t = 0.f;
+        for (int i = threadIdx.x; i < M; i += 256) t += dlogit[i];
+        t = wave_sum(t);
+        if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = t;
+        __syncthreads();
+        if (threadIdx.x == 0) db[0] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
     }
 }
 
 DDL_API int ddl_dense1_bce_blocks(int M) {
     int nb = (M + HEAD_ROWS - 1) / HEAD_ROWS;
-    return nb > 512 ? 512 : (nb < 1 ? 1 : nb);
+    return nb > 256 ? 256 : (nb < 1 ? 1 : nb);
 }
 
 DDL_API int ddl_dense1_bce(const void* x, const void* w, const float* bias, float label_first,
@@ -211,7 +222,7 @@ DDL_API int ddl_dense1_bce(const void* x, const void* w, const float* bias, floa
                                                     label_second, n_first, M, K, (uint4*)dx, dw_part, logits,
                                                     rowloss, dlogit, want_dx, want_dw);
     mean_kernel<<<1, LB, 0, s>>>(rowloss, M, 1.0 / (double)M, loss_out);
-    if (want_dw) head_finalize_kernel<<<(K + 255) / 256, 256, 0, s>>>(dw_part, nb, K, dlogit, M, dw, db);
+    if (want_dw) head_finalize_kernel<<<(K + 31) / 32, 256, 0, s>>>(dw_part, nb, K, dlogit, M, dw, db);
     return 0;
 }
 

@@ -149,21 +149,87 @@ class GANTrainer:
         self.g_loss = loss
         return loss
 
-    def train_step(self, real):
-        """One reference iteration: train_discriminator() then train_generator()."""
-        real = self.D.prepare_input(real)
-        self.d_backward(real)
-        if self.dp is not None:
-            self.dp.all_reduce_mean_(self.D.G)
-        self.optD.step()
-        self.g_backward(real.shape[0])
-        if self.dp is not None:
-            self.dp.all_reduce_mean_(self.G.G)
-        self.optG.step()
+    # ---- one reference iteration = train_discriminator() then train_generator() ------------
+    def phase_a(self, real):
+        """D forward/backward (local gradients in D.G)."""
+        return self.d_backward(real)
+
+    def phase_b(self, B):
+        """D update, then G forward / D dgrad / G backward (local gradients in G.G)."""
+        self.optD.step(self._gscale)
+        return self.g_backward(B)
+
+    def phase_c(self):
+        self.optG.step(self._gscale)
         self.D.release()
         self.G.release()
+
+    @property
+    def _gscale(self):
+        return 1.0 if self.dp is None else self.dp.grad_scale
+
+    def train_step(self, real, prepared: bool = False):
+        if not prepared:
+            real = self.D.prepare_input(real)
+        self.phase_a(real)
+        if self.dp is not None:
+            self.dp.all_reduce_sum_(self.D.G)
+        self.phase_b(real.shape[0])
+        if self.dp is not None:
+            self.dp.all_reduce_sum_(self.G.G)
+        self.phase_c()
         return self.d_loss, self.g_loss
 
     def generate(self, n: int):
         z = self.rng.uniform((n, self.cfg.noise_dim), self.G.cdtype)
         return self.G.to_logical(self.G.forward(z, training=False))
+
+
+class GraphedGANStep:
+    """The training iteration captured as hipGraphs (torch.cuda.CUDAGraph == hipGraph on ROCm).
+
+    A DCGAN step at the reference's batch is ~100 short kernels: launch-bound when issued
+    eagerly.  Shapes are static, the noise RNG and the Adam step counter live
+    in device memory, so the whole iteration replays from a graph.  Single rank: one graph.
+    Multi rank: three graph segments with the two flat-gradient all-reduces issued between them
+    (`capture_collectives=True` captures the RCCL calls too and replays a single graph).
+    """
+
+    def __init__(self, trainer: GANTrainer, real_prepared: torch.Tensor, warmup: int = 3,
+                 capture_collectives: bool = False):
+        self.t, self.real = trainer, real_prepared
+        self.B = real_prepared.shape[0]
+        self.full = trainer.dp is None or capture_collectives
+        t = trainer
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(warmup):          # populates table caches / allocator before capture
+                t.train_step(self.real, prepared=True)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        pool = torch.cuda.graph_pool_handle()
+        self.graphs = []
+        if self.full:
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, pool=pool):
+                t.train_step(self.real, prepared=True)
+            self.graphs = [g]
+        else:
+            for fn in (lambda: t.phase_a(self.real), lambda: t.phase_b(self.B), t.phase_c):
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, pool=pool):
+                    fn()
+                self.graphs.append(g)
+
+    def step(self):
+        t = self.t
+        if self.full:
+            self.graphs[0].replay()
+        else:
+            self.graphs[0].replay()
+            t.dp.all_reduce_sum_(t.D.G)
+            self.graphs[1].replay()
+            t.dp.all_reduce_sum_(t.G.G)
+            self.graphs[2].replay()
+        return t.d_loss, t.g_loss

@@ -609,7 +609,13 @@ class Network:
     def logical_state(self) -> Dict[Tuple[str, str], torch.Tensor]:
         """Device-independent snapshot {(layer, weight): logical fp32 CPU tensor} -- what a
         transfer-learning child or another rank needs to rebuild this network."""
-        return {(p.layer, p.wname): torch.from_numpy(self._logical(p).copy()) for p in self._params}
+        out = {}
+        for p in self._params:
+            t = torch.from_numpy(self._logical(p).copy())
+            if p.wname == "kernel" and self._op(p.layer).kind == "dense":
+                t = t.reshape(t.shape[0], -1)          # structured-K Dense kernels travel as [N][K]
+            out[(p.layer, p.wname)] = t
+        return out
 
     def load_logical_state(self, state: Dict[Tuple[str, str], torch.Tensor], strict: bool = True):
         P, S = self.P.detach().cpu().clone(), self.S.detach().cpu().clone()
@@ -620,6 +626,8 @@ class Network:
                     raise KeyError(f"missing weight {key}")
                 continue
             t = state[key]
+            if t.numel() == int(np.prod(p.lshape)) and p.wname == "kernel" and t.dim() == 2:
+                t = t.reshape(p.lshape)
             if tuple(t.shape) != p.lshape:
                 raise ValueError(f"{key}: shape {tuple(t.shape)} != {p.lshape}")
             self._scatter(P if p.trainable else S, p, t.float())

@@ -56,7 +56,7 @@ class FlatOptimizer:
 
     def step(self, grad_scale: float = 1.0):
         net, c = self.net, self.cfg
-        self.t += 1
+        self.t += 1       # host mirror; the device counter `step_dev` is what the kernel reads
         if net.on_gpu:
             F.hip_backend().optimizer_step(self, grad_scale)
             net.refresh_working_copies(cast=False)

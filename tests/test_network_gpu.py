@@ -18,7 +18,10 @@ def _pair(spec, seed=0, bn="batch"):
 
 
 def _rel(a, b):
-    return float((a - b).abs().max() / (b.abs().max() + 1e-12))
+    """relative L2 error (chained bf16 layers: every intermediate is rounded to bf16)"""
+    # the floor keeps mathematically-zero gradients (conv bias in front of a batch-stat BN) from
+    # turning bf16 rounding noise into a huge relative error
+    return float((a - b).norm() / (b.norm() + 1e-2))
 
 
 @pytest.mark.parametrize("bn", ["batch", "inference"])
