@@ -1,0 +1,178 @@
+"""`RandomModel`: one ensemble member = a network, its optimizer/loss, its private data split.
+
+Behaviour of /root/reference/DDL_Ray3.py:125-161 and DDL_Normal4.py:126-177:
+  * `train()`        : up to epochs/mini_epochs rounds of `fit(epochs=mini_epochs)` (batch 32,
+                       reshuffled every epoch, partial last batch kept), prints `i [loss_e1, loss_e2]`,
+                       early stop when `1 - loss_last/loss_first < early_stop_rate`;
+  * `predict(x)`     : softmax probabilities;
+  * `get_accuracy()` : argmax agreement on the member's own validation split or a given (x, y);
+  * `get_model()`    : (spec, weights) -- what a transfer child or another rank needs;
+  * `save()`         : models/model<N>/{architecture.json, weights.h5, graph.*}.
+
+Device execution: the dataset is resident in HBM, a batch is formed by one gather kernel from an
+index slice, and the whole train step (gather -> forward -> fused softmax-CE -> backward -> fused
+optimizer) is replayed from a hipGraph, so the reference's launch-bound batch-32 regime costs one
+graph launch per step.  Optional data parallelism: flat gradient all-reduce every step, or
+periodic weight averaging (local SGD) through `averager`.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, List, Optional, Tuple
+
+import torch
+
+from ..config import SearchSpace
+from ..ops import functional as F
+from ..utils.data import Data, Sample
+from .network import Network
+from .optim import FlatOptimizer
+from .search import CompiledSpec
+
+
+class RandomModel:
+    def __init__(self, data: Data, sample: Sample, space: SearchSpace, compiled: CompiledSpec,
+                 device="cpu", number: Optional[int] = None, seed: int = 0,
+                 parent_state: Optional[Dict] = None, inherited: Optional[set] = None,
+                 dp=None, averager=None, use_graph: Optional[bool] = None, verbose: bool = True):
+        self.data, self.sample, self.space, self.compiled = data, sample, space, compiled
+        self.device = torch.device(device)
+        self.number = number
+        self.verbose = verbose
+        self.dp, self.averager = dp, averager
+        self.net = Network(compiled.spec, device, seed)
+        if parent_state is not None:
+            # clone_model + set_weights(get_weights()): inherited layers start from the parent's
+            # weights (BN moving statistics included); the new head keeps its fresh init.
+            keep = {k: v for k, v in parent_state.items() if inherited is None or k[0] in inherited}
+            self.net.load_logical_state(keep, strict=False)
+        self.opt = FlatOptimizer(self.net, compiled.optimizer)
+        self.loss_name = compiled.loss
+        self.gen = torch.Generator().manual_seed(seed + 7)
+        self.history: List[List[float]] = []
+        self.use_graph = (self.device.type == "cuda") if use_graph is None else use_graph
+        self._graph = None
+        self._gB = None
+        if averager is not None:
+            averager.attach(self.net)
+
+    # ------------------------------------------------------------------ one optimisation step
+    def _loss(self, logits, y, want_grad=True):
+        if self.loss_name == "mean_squared_error":
+            return F.softmax_mse(logits, y, want_grad)
+        return F.softmax_ce(logits, y, want_grad)
+
+    def _step_body(self, idx):
+        net = self.net
+        x = net.prepare_input(self.data.train_x, index=idx)
+        y = self.data.train_y.index_select(0, idx)
+        logits = net.forward(x, training=True)
+        loss, dlogits, _ = self._loss(logits, y)
+        net.backward(dlogits)
+        if self.dp is not None and self.averager is None:
+            self.dp.all_reduce_sum_(net.G)
+            self.opt.step(self.dp.grad_scale)
+        else:
+            self.opt.step()
+        net.release()
+        return loss
+
+    def _graphed_step(self, idx):
+        B = idx.numel()
+        if self._graph is None or self._gB != B:
+            if self._graph is not None or self.dp is not None:
+                return self._step_body(idx)          # only the full-batch shape is graphed
+            self._idx = idx.clone()
+            self._loss_acc = torch.zeros((), dtype=torch.float32, device=self.device)
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            # warm-up runs really train (they are the first steps of the epoch)
+            with torch.cuda.stream(side):
+                first = self._step_body(self._idx)
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                self._static_loss = self._step_body(self._idx)
+            self._graph, self._gB = g, B
+            self._pending_first = first
+            return first
+        self._idx.copy_(idx)
+        self._graph.replay()
+        return self._static_loss
+
+    def train_step(self, idx):
+        if self.use_graph:
+            loss = self._graphed_step(idx)
+        else:
+            loss = self._step_body(idx)
+        if self.averager is not None:
+            self.averager.after_step()
+        return loss
+
+    # ------------------------------------------------------------------ fit / train
+    def fit(self, epochs: int, batch_size: Optional[int] = None) -> List[float]:
+        B = batch_size or self.space.batch_size
+        tr = self.sample.train_idx
+        n = tr.numel()
+        losses = []
+        for _ in range(epochs):
+            perm = tr[torch.randperm(n, generator=self.gen).to(tr.device)]
+            acc = torch.zeros((), dtype=torch.float32, device=self.device)
+            for i in range(0, n, B):
+                idx = perm[i:i + B]
+                loss = self.train_step(idx)
+                acc = acc + loss.detach() * idx.numel()      # Keras: sample-weighted epoch mean
+            losses.append(float(acc) / n)
+        return losses
+
+    def train(self):
+        sp = self.space
+        for i in range(int(sp.epochs / sp.mini_epochs)):
+            hist = self.fit(sp.mini_epochs)
+            self.history.append(hist)
+            if self.verbose:
+                print(i, hist, flush=True)
+            if not all(math.isfinite(h) for h in hist):
+                break
+            if 1 - (hist[-1] / hist[0]) < sp.early_stop_rate:
+                break
+        if self.averager is not None:
+            self.averager.finish()
+
+    # ------------------------------------------------------------------ inference
+    def predict(self, x=None, index: Optional[torch.Tensor] = None, batch_size: int = 4096) -> torch.Tensor:
+        """Softmax outputs [N,10] (fp32, on device).  `x` is a resident uint8 image tensor (default:
+        the training pool) optionally gathered by `index`."""
+        x = self.data.train_x if x is None else x
+        n = x.shape[0] if index is None else index.numel()
+        outs = []
+        for i in range(0, n, batch_size):
+            if index is None:
+                xb = self.net.prepare_input(x[i:i + batch_size])
+            else:
+                xb = self.net.prepare_input(x, index=index[i:i + batch_size])
+            y = self.net.forward(xb, training=False)
+            outs.append(F.softmax(y, self.net.out_shape[-1]))
+        return torch.cat(outs, 0)
+
+    def get_accuracy(self, validation_data: Optional[Tuple[torch.Tensor, torch.Tensor]] = None) -> float:
+        if validation_data is None:
+            idx = self.sample.val_idx
+            if idx.numel() == 0:
+                return float("nan")
+            pred = self.predict(self.data.train_x, index=idx)
+            target = self.data.train_y.index_select(0, idx)
+        else:
+            x, target = validation_data
+            pred = self.predict(x)
+        correct = F.argmax_match_count(pred, target)
+        return int(correct) / pred.shape[0]
+
+    def get_model(self):
+        return self.compiled, self.net.logical_state()
+
+    def save(self, directory: Optional[str] = None):
+        from ..utils import ckpt
+        d = directory or self.space.model_save_directory
+        return ckpt.save_model(self.net, f"{d}/model{self.number}")
