@@ -387,3 +387,26 @@ DDL_API void ddl_philox_uniform(void* out, long n, long* state, float lo, float 
     philox_uniform_kernel<<<grid, 256, 0, s>>>((bf16_t*)out, n, state, lo, hi);
     philox_advance_kernel<<<1, 1, 0, s>>>(state);
 }
+
+// Delayed (overlapped) periodic averaging, local-SGD style [R-ns]: while ranks kept training, an
+// all-reduce summed the snapshot `snap` taken k steps ago into `sum`.  Fold the correction in:
+// P += sum/world - snap, and re-emit the bf16 working copy.
+__global__ void avg_delta_kernel(float4* __restrict__ P, uint2* __restrict__ Pc, const float4* __restrict__ sum,
+                                 const float4* __restrict__ snap, long n4, float inv_world) {
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+        float4 p = P[i], s = sum[i], o = snap[i];
+        p.x += s.x * inv_world - o.x; p.y += s.y * inv_world - o.y;
+        p.z += s.z * inv_world - o.z; p.w += s.w * inv_world - o.w;
+        P[i] = p;
+        if (Pc) Pc[i] = make_uint2(pack2bf(p.x, p.y), pack2bf(p.z, p.w));
+    }
+}
+
+DDL_API void ddl_avg_delta(float* P, void* Pc, const float* sum, const float* snap, long n, float inv_world,
+                           hipStream_t s) {
+    long n4 = n / 4;
+    long g = (n4 + 255) / 256;
+    int grid = (int)(g > 2048 ? 2048 : (g < 1 ? 1 : g));
+    avg_delta_kernel<<<grid, 256, 0, s>>>((float4*)P, (uint2*)Pc, (const float4*)sum, (const float4*)snap, n4,
+                                          inv_world);
+}

@@ -62,43 +62,70 @@ class RandomModel:
             return F.softmax_mse(logits, y, want_grad)
         return F.softmax_ce(logits, y, want_grad)
 
-    def _step_body(self, idx):
+    def _fwd_bwd(self, idx):
         net = self.net
         x = net.prepare_input(self.data.train_x, index=idx)
         y = self.data.train_y.index_select(0, idx)
         logits = net.forward(x, training=True)
         loss, dlogits, _ = self._loss(logits, y)
         net.backward(dlogits)
-        if self.dp is not None and self.averager is None:
-            self.dp.all_reduce_sum_(net.G)
+        return loss
+
+    def _update(self):
+        if self._sync_dp:
             self.opt.step(self.dp.grad_scale)
         else:
             self.opt.step()
-        net.release()
+        self.net.release()
+
+    @property
+    def _sync_dp(self):
+        return self.dp is not None and self.dp.world > 1 and self.averager is None
+
+    def _step_body(self, idx):
+        loss = self._fwd_bwd(idx)
+        if self._sync_dp:
+            self.dp.all_reduce_sum_(self.net.G)          # ONE flat collective per step
+        self._update()
         return loss
 
     def _graphed_step(self, idx):
+        """hipGraph replay of the step for the steady-state batch shape.  Single rank / local SGD:
+        one graph.  Synchronous DP: two graph segments with the flat all-reduce issued between."""
         B = idx.numel()
-        if self._graph is None or self._gB != B:
-            if self._graph is not None or self.dp is not None:
-                return self._step_body(idx)          # only the full-batch shape is graphed
+        if self._graph is None:
             self._idx = idx.clone()
-            self._loss_acc = torch.zeros((), dtype=torch.float32, device=self.device)
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
-            # warm-up runs really train (they are the first steps of the epoch)
-            with torch.cuda.stream(side):
+            with torch.cuda.stream(side):        # warm-up really trains (first step of the epoch)
                 first = self._step_body(self._idx)
             torch.cuda.current_stream().wait_stream(side)
             torch.cuda.synchronize()
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
-                self._static_loss = self._step_body(self._idx)
-            self._graph, self._gB = g, B
-            self._pending_first = first
-            return first
+            pool = torch.cuda.graph_pool_handle()
+            if self._sync_dp:
+                ga, gb = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+                with torch.cuda.graph(ga, pool=pool):
+                    self._static_loss = self._fwd_bwd(self._idx)
+                with torch.cuda.graph(gb, pool=pool):
+                    self._update()
+                self._graph = (ga, gb)
+            else:
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, pool=pool):
+                    self._static_loss = self._step_body(self._idx)
+                self._graph = (g,)
+            self._gB = B
+            return first                         # capture records, it does not execute
+        if B != self._gB:
+            return self._step_body(idx)          # ragged last batch of an epoch runs eagerly
+        return self._replay(idx)
+
+    def _replay(self, idx):
         self._idx.copy_(idx)
-        self._graph.replay()
+        self._graph[0].replay()
+        if len(self._graph) == 2:
+            self.dp.all_reduce_sum_(self.net.G)
+            self._graph[1].replay()
         return self._static_loss
 
     def train_step(self, idx):

@@ -180,6 +180,20 @@ class GANTrainer:
         self.phase_c()
         return self.d_loss, self.g_loss
 
+    # ---- checkpoint / resume (the reference never checkpoints its GAN) ---------
+    def save_checkpoint(self, path, iteration: int):
+        from ..utils import ckpt
+        ckpt.save_training_state(str(path) + ".G", self.G, self.optG, {"iteration": iteration})
+        ckpt.save_training_state(str(path) + ".D", self.D, self.optD, {"iteration": iteration})
+        with open(path, "w") as f:
+            f.write(str(iteration))
+
+    def load_checkpoint(self, path) -> int:
+        from ..utils import ckpt
+        it = ckpt.load_training_state(str(path) + ".G", self.G, self.optG)["iteration"]
+        ckpt.load_training_state(str(path) + ".D", self.D, self.optD)
+        return int(it)
+
     def generate(self, n: int):
         z = self.rng.uniform((n, self.cfg.noise_dim), self.G.cdtype)
         return self.G.to_logical(self.G.forward(z, training=False))

@@ -63,6 +63,7 @@ _dense1_bce = _sig("ddl_dense1_bce", ci, vp, vp, vp, cf, cf, ci, ci, ci, vp, vp,
 _argmax_match = _sig("ddl_argmax_match", None, vp, vp, ci, ci, vp, vp)
 _optim_step = _sig("ddl_optim_step", None, vp, vp, vp, vp, vp, vp, cl, ci, cf, cf, cf, cf, cf, cf, vp, cf, vp)
 _scale_emit = _sig("ddl_scale_emit", None, vp, vp, cl, cf, vp)
+_avg_delta = _sig("ddl_avg_delta", None, vp, vp, vp, vp, cl, cf, vp)
 _philox = _sig("ddl_philox_uniform", None, vp, cl, vp, cf, cf, vp)
 _igemm = _sig("ddl_igemm_conv", ci, vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci,
               ci, ci, ci, ci, cf, ci, vp)
@@ -412,6 +413,15 @@ def optimizer_step(opt, grad_scale=1.0, avg_with=None, avg_weight=0.0):
 
 def scale_emit(P, Pc, scale):
     _scale_emit(P.data_ptr(), _p(Pc), P.numel(), scale, _stream())
+    _done()
+
+
+def avg_delta(P, Pc, total, snap, inv_world):
+    """P += total*inv_world - snap (delayed weight averaging), bf16 copy re-emitted."""
+    n = P.numel()
+    _chk_f32(total, n, "sum")
+    _chk_f32(snap, n, "snapshot")
+    _avg_delta(P.data_ptr(), _p(Pc), total.data_ptr(), snap.data_ptr(), n, inv_world, _stream())
     _done()
 
 

@@ -1,0 +1,122 @@
+"""Periodic model averaging (local SGD) across data-parallel ranks [R-ns].
+
+BASELINE.json config 5: "asynchronous/periodic model averaging (local-SGD, every k steps) across
+8 GPUs with overlapped all-reduce on a side HIP stream".  The reference itself never exchanges
+weights; this is the north-star replacement for its Ray object-store traffic.
+
+Every rank trains on its own shard without any per-step collective.  Every `every` steps:
+  * `overlap=False` : blocking all-reduce of the flat fp32 master buffer, P <- mean(P), bf16 copy
+                      re-emitted by one fused kernel (`scale_emit`);
+  * `overlap=True`  : the buffer is snapshotted and all-reduced on a SIDE stream while training
+                      continues; `delay` steps later the correction  P += mean(snapshot) - snapshot
+                      is folded in by one fused kernel (`avg_delta`).  The collective (4.3 MB for the
+                      DCGAN generator, ~30 us on xGMI) is entirely hidden behind compute.
+BN moving statistics are averaged at the same points.
+"""
+from __future__ import annotations
+
+from typing import List, Optional
+
+import torch
+
+from ..ops import functional as F
+
+
+class PeriodicAverager:
+    def __init__(self, dp, every: int = 8, overlap: bool = True, delay: int = 1):
+        if every < 1 or delay < 1 or delay > every:
+            raise ValueError("need every >= 1 and 1 <= delay <= every")
+        self.dp, self.every, self.overlap, self.delay = dp, every, overlap, delay
+        self.nets: List = []
+        self.t = 0
+        self._pending = None          # (launch step, [(net, snap, total, work)], event)
+        self._side = None
+        self.n_averages = 0
+
+    def attach(self, net):
+        self.nets.append(net)
+        if net.on_gpu and self._side is None:
+            self._side = torch.cuda.Stream(device=net.device)
+
+    # ------------------------------------------------------------------ blocking form
+    def _average_now(self):
+        inv = 1.0 / self.dp.world
+        for net in self.nets:
+            self.dp.all_reduce_sum_(net.P)
+            self.dp.all_reduce_sum_(net.S)
+            net.S.mul_(inv)
+            if net.on_gpu:
+                F.hip_backend().scale_emit(net.P, net.Pc, inv)
+                net.refresh_working_copies(cast=False)
+            else:
+                net.P.mul_(inv)
+        self.n_averages += 1
+
+    # ------------------------------------------------------------------ overlapped form
+    def _launch(self):
+        items = []
+        gpu = any(n.on_gpu for n in self.nets)
+        if gpu:
+            self._side.wait_stream(torch.cuda.current_stream())
+        ctx = torch.cuda.stream(self._side) if gpu else _null()
+        with ctx:
+            for net in self.nets:
+                snap = net.P.clone()
+                total = snap.clone()
+                stats = net.S.clone()
+                self.dp.all_reduce_sum_(total)
+                self.dp.all_reduce_sum_(stats)
+                items.append((net, snap, total, stats))
+            ev = None
+            if gpu:
+                ev = torch.cuda.Event()
+                ev.record(self._side)
+        self._pending = (self.t, items, ev)
+
+    def _apply(self):
+        _, items, ev = self._pending
+        self._pending = None
+        if ev is not None:
+            torch.cuda.current_stream().wait_event(ev)
+        inv = 1.0 / self.dp.world
+        for net, snap, total, stats in items:
+            if net.on_gpu:
+                F.hip_backend().avg_delta(net.P, net.Pc, total, snap, inv)
+                net.refresh_working_copies(cast=False)
+                # tensors allocated on the side stream are consumed here
+                for t in (snap, total, stats):
+                    t.record_stream(torch.cuda.current_stream())
+            else:
+                net.P.add_(total * inv - snap)
+            net.S.copy_(stats * inv)
+        self.n_averages += 1
+
+    # ------------------------------------------------------------------ hooks
+    def after_step(self):
+        self.t += 1
+        if self.dp is None or self.dp.world == 1:
+            return
+        if not self.overlap:
+            if self.t % self.every == 0:
+                self._average_now()
+            return
+        if self._pending is not None and self.t - self._pending[0] >= self.delay:
+            self._apply()
+        if self.t % self.every == 0 and self._pending is None:
+            self._launch()
+
+    def finish(self):
+        """Drain an in-flight average and end on a common model (all ranks identical)."""
+        if self.dp is None or self.dp.world == 1:
+            return
+        if self._pending is not None:
+            self._apply()
+        self._average_now()
+
+
+class _null:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        return False

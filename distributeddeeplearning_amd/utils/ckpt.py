@@ -55,7 +55,7 @@ def save_training_state(path, net: Network, opt=None, extra: Optional[dict] = No
 
 
 def load_training_state(path, net: Network, opt=None) -> dict:
-    sd = torch.load(path, map_location="cpu", weights_only=False)
+    sd = torch.load(path, map_location="cpu", weights_only=True)
     net.load_logical_state(sd["logical"])
     if opt is not None and "opt" in sd:
         o = sd["opt"]

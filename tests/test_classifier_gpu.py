@@ -1,0 +1,55 @@
+"""Classifier worker on the device: imported reference replicas vs the CPU oracle, and a short
+training run through the hipGraph-replayed step."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from distributeddeeplearning_amd.config import get_space
+from distributeddeeplearning_amd.models import search
+from distributeddeeplearning_amd.models.classifier import RandomModel
+from distributeddeeplearning_amd.utils import ckpt
+from distributeddeeplearning_amd.utils.data import Data
+
+pytestmark = pytest.mark.gpu
+REF = os.path.join(os.path.dirname(os.path.abspath(__file__)), "fixtures", "reference_models")
+
+
+@pytest.mark.parametrize("i", range(5))
+def test_reference_replica_forward_matches_oracle(i):
+    if not os.path.isdir(f"{REF}/model{i}"):
+        pytest.skip("reference checkpoints not present on this box")
+    c = ckpt.load_model(f"{REF}/model{i}", "cpu")
+    g = ckpt.load_model(f"{REF}/model{i}", "cuda")
+    torch.manual_seed(i)
+    x = torch.randint(0, 256, (16, 28, 28, 1), dtype=torch.uint8)
+    pc = c.predict(x)
+    pg = g.predict(x.cuda()).cpu()
+    assert pg.shape == pc.shape == (16, 10)
+    assert float((pg - pc).abs().max()) < 5e-2
+
+
+def test_mlp_member_trains_on_device():
+    sp = get_space("ddl_ray", ["data_train_size=1600", "early_stop_rate=0.0", "epochs=4"])
+    data = Data("cuda", channels=3, n_train=2000, n_test=400, synthetic=True)
+    rng = np.random.default_rng(3)
+    cs = search.make_new_model(sp, rng, data.input_shape, 10)
+    cs.optimizer.kind, cs.optimizer.lr = "adam", 1e-3
+    m = RandomModel(data, data.get_random_sample(1600, seed=1), sp, cs, "cuda", number=0, seed=0, verbose=False)
+    m.train()
+    first, last = m.history[0][0], m.history[-1][-1]
+    assert np.isfinite(last) and last < first
+    acc = m.get_accuracy((data.test_x, data.test_y))
+    assert 0.0 <= acc <= 1.0
+
+
+def test_cnn_member_step_matches_oracle_direction():
+    sp = get_space("ddl_normal4", ["data_train_size=256", "epochs=2"])
+    data = Data("cuda", channels=1, n_train=320, n_test=64, synthetic=True)
+    rng = np.random.default_rng(5)
+    for k in range(3):
+        cs = search.make_new_model(sp, rng, data.input_shape, 10)
+        m = RandomModel(data, data.get_random_sample(256, seed=k), sp, cs, "cuda", number=k, seed=k, verbose=False)
+        m.train()
+        assert all(np.isfinite(h).all() for h in m.history), cs.spec.summary()

@@ -36,9 +36,9 @@ def test_discriminator_fwd_bwd(bn):
     dxc = c.backward(dy, need_input_grad=True)
     import distributeddeeplearning_amd.ops.hip as hip
     dxg = g.backward(hip.pad_channels(dy.cuda(), 8), need_input_grad=True)
-    assert _rel(g.to_logical(dxg, 1).cpu(), dxc) < 6e-2
+    assert _rel(g.to_logical(dxg, 1).cpu(), dxc) < 8e-2
     for (k, gc), (_, gg) in zip(_grads(c).items(), _grads(g).items()):
-        assert _rel(gg, gc) < 6e-2, k
+        assert _rel(gg, gc) < 8e-2, k
 
 
 def _grads(net):

@@ -1,0 +1,58 @@
+#!/usr/bin/env python3
+"""Summarise a rocprofv3 kernel trace (results.db or *_kernel_trace.csv) into a per-kernel table.
+
+    python tools/rocprof_summary.py gpurun_out/prof2 [--skip-first N] > profiles/xyz.md
+"""
+import csv
+import glob
+import re
+import sqlite3
+import sys
+from collections import defaultdict
+
+
+def load(path):
+    rows = []          # (name, start, end)
+    dbs = glob.glob(f"{path}/**/*_results.db", recursive=True)
+    if dbs:
+        db = sqlite3.connect(dbs[0])
+        cols = [r[1] for r in db.execute("pragma table_info(kernels)")]
+        name = "name" if "name" in cols else "kernel_name"
+        for n, s, e in db.execute(f"select {name}, start, end from kernels order by start"):
+            rows.append((n, s, e))
+        return rows
+    for f in glob.glob(f"{path}/**/*_kernel_trace.csv", recursive=True):
+        with open(f) as fh:
+            for r in csv.DictReader(fh):
+                rows.append((r["Kernel_Name"], int(r["Start_Timestamp"]), int(r["End_Timestamp"])))
+    rows.sort(key=lambda r: r[1])
+    return rows
+
+
+def short(n):
+    n = re.sub(r"\(.*", "", n)
+    n = n.replace("void ", "")
+    return n[:70]
+
+
+def main():
+    path = sys.argv[1]
+    rows = load(path)
+    if not rows:
+        sys.exit("no kernel records found")
+    agg = defaultdict(lambda: [0, 0, 10**18, 0])
+    for n, s, e in rows:
+        a = agg[short(n)]
+        d = e - s
+        a[0] += 1; a[1] += d; a[2] = min(a[2], d); a[3] = max(a[3], d)
+    tot = sum(a[1] for a in agg.values())
+    span = rows[-1][2] - rows[0][1]
+    print(f"kernels: {len(rows)} dispatches, {tot/1e6:.3f} ms busy, {span/1e6:.3f} ms first-to-last span\n")
+    print("| kernel | calls | total us | avg us | min us | max us | % |")
+    print("|---|---:|---:|---:|---:|---:|---:|")
+    for n, a in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+        print(f"| `{n}` | {a[0]} | {a[1]/1e3:.1f} | {a[1]/a[0]/1e3:.2f} | {a[2]/1e3:.2f} | {a[3]/1e3:.2f} | {100*a[1]/tot:.1f} |")
+
+
+if __name__ == "__main__":
+    main()
