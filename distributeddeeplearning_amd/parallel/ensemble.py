@@ -215,20 +215,41 @@ class EnsembleModel:
         self._settle()
         self.accuracy_with_models.sort(key=lambda e: _sort_key(e[0]))     # stable; never compares models
 
+    def _gather(self, entries, method, *args):
+        """Call `method` on every entry's member; -> [(entry, value)].  Members whose worker died are
+        removed from the pool (drop_failed) -- ensemble members are independent, so losing one only
+        shrinks the vote -- or the error is re-raised."""
+        futs = [(e, e[1].call(method, *args)) for e in entries]
+        out = []
+        for e, f in futs:
+            try:
+                out.append((e, _resolve(f)))
+            except (R.WorkerDiedError, R.RemoteError) as err:
+                if not self.drop_failed:
+                    raise
+                if self.verbose:
+                    print(f"dropping failed ensemble member: {err}", flush=True)
+                if e in self.accuracy_with_models:
+                    self.accuracy_with_models.remove(e)
+        return out
+
     def member_test_accuracies(self) -> List[float]:
         self._settle()
-        return [float(_resolve(f)) for f in [h.call("get_accuracy", True) for _, h, _ in self.accuracy_with_models]]
+        return [float(v) for _, v in self._gather(list(self.accuracy_with_models), "get_accuracy", True)]
 
     def get_accuracy(self, k: Optional[int] = None) -> float:
         k = self.space.predict_model_size if k is None else k
         self.sort_models()
-        top = self.accuracy_with_models[:k]
-        if not top:
+        got = self._gather(self.accuracy_with_models[:k], "predict_test")
+        if len(got) < k:                                 # refill the vote from the next-best live members
+            have = {id(e) for e, _ in got}
+            rest = [e for e in self.accuracy_with_models if id(e) not in have][:k - len(got)]
+            got += self._gather(rest, "predict_test")
+        if not got:
             return float("nan")
-        futs = [h.call("predict_test") for _, h, _ in top]
         votes = None
-        for f in futs:
-            p = torch.from_numpy(np.asarray(_resolve(f), dtype=np.float32))
+        for _, p in got:
+            p = torch.from_numpy(np.asarray(p, dtype=np.float32))
             votes = p if votes is None else votes + p
         target = self.data.test_y.cpu()
         return int(F.argmax_match_count(votes, target)) / votes.shape[0]

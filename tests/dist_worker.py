@@ -1,0 +1,141 @@
+"""Rank body for tests/test_dist_gloo.py (spawned with torch.multiprocessing, gloo backend)."""
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def _init(rank, world, port):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    torch.set_num_threads(2)
+    from distributeddeeplearning_amd.parallel import ddp
+    r, w, _ = ddp.init_process_group(backend="gloo")
+    assert (r, w) == (rank, world)
+    return ddp.FlatDataParallel()
+
+
+def _mlp_spec():
+    from distributeddeeplearning_amd.models import ir
+    m = ir.ModelSpec("m", [ir.Input("in", (6, 6, 1))])
+    for l in (ir.Flatten("f"), ir.Dense("d1", 16, "tanh"), ir.Dense("o", 10, "softmax")):
+        m.append(l)
+    return m
+
+
+def collectives(rank, world, port, out):
+    dp = _init(rank, world, port)
+    t = torch.arange(8, dtype=torch.float32) + rank
+    dp.all_reduce_sum_(t)
+    ok = torch.equal(t, torch.arange(8, dtype=torch.float32) * world + sum(range(world)))
+    b = torch.full((4,), float(rank))
+    dp.broadcast_(b, src=1)
+    ok &= bool((b == 1).all())
+    g = dp.all_gather_scalars(torch.tensor([rank * 1.0, 7.0]))
+    ok &= g.shape == (world, 2) and g[:, 0].tolist() == list(map(float, range(world)))
+    sh = dp.reduce_scatter_sum(torch.arange(4 * world, dtype=torch.float32))
+    ok &= torch.equal(sh, torch.arange(4 * world, dtype=torch.float32)[rank * 4:(rank + 1) * 4] * world)
+    full = torch.empty(4 * world)
+    dp.all_gather_flat(sh, full)
+    ok &= torch.equal(full, torch.arange(4 * world, dtype=torch.float32) * world)
+    if rank == 0:
+        dp.send(torch.tensor([3.5]), 1)
+    elif rank == 1:
+        r = torch.zeros(1)
+        dp.recv(r, 0)
+        ok &= float(r) == 3.5
+    m = torch.tensor([float(rank)])
+    dp.all_reduce_mean_(m)
+    ok &= abs(float(m) - (world - 1) / 2) < 1e-6
+    dp.barrier()
+    np.save(f"{out}/ok{rank}.npy", np.array([int(ok)]))
+    dist.destroy_process_group()
+
+
+def dp_grad_equals_full_batch(rank, world, port, out):
+    """Sync DP: mean of per-rank gradients on half batches == single-process full-batch gradient,
+    and after the fused update every replica holds identical weights."""
+    dp = _init(rank, world, port)
+    from distributeddeeplearning_amd.models.network import Network
+    from distributeddeeplearning_amd.models.optim import FlatOptimizer, OptimConfig
+    from distributeddeeplearning_amd.ops import functional as F
+    g = torch.Generator().manual_seed(0)
+    X = torch.rand(16, 6, 6, 1, generator=g)
+    Y = torch.nn.functional.one_hot(torch.randint(0, 10, (16,), generator=g), 10).float()
+    net = Network(_mlp_spec(), "cpu", seed=rank)             # deliberately different init per rank...
+    dp.broadcast_(net.P, net.S)                              # ...made identical by the broadcast
+    opt = FlatOptimizer(net, OptimConfig.keras("sgd", 0.1))
+    n = 16 // world
+    xs, ys = X[rank * n:(rank + 1) * n], Y[rank * n:(rank + 1) * n]
+    loss, dl, _ = F.softmax_ce(net.forward(net.prepare_input(xs), training=True), ys)
+    net.backward(dl)
+    dp.all_reduce_sum_(net.G)
+    np.save(f"{out}/grad{rank}.npy", (net.G * dp.grad_scale).numpy())
+    opt.step(dp.grad_scale)
+    np.save(f"{out}/P{rank}.npy", net.P.numpy())
+    if rank == 0:
+        ref = Network(_mlp_spec(), "cpu", seed=0)
+        loss, dl, _ = F.softmax_ce(ref.forward(ref.prepare_input(X), training=True), Y)
+        ref.backward(dl)
+        np.save(f"{out}/grad_ref.npy", ref.G.numpy())
+    dist.destroy_process_group()
+
+
+def local_sgd(rank, world, port, out, overlap):
+    dp = _init(rank, world, port)
+    from distributeddeeplearning_amd.models.network import Network
+    from distributeddeeplearning_amd.models.optim import FlatOptimizer, OptimConfig
+    from distributeddeeplearning_amd.ops import functional as F
+    from distributeddeeplearning_amd.parallel.averaging import PeriodicAverager
+    net = Network(_mlp_spec(), "cpu", seed=0)
+    dp.broadcast_(net.P, net.S)
+    opt = FlatOptimizer(net, OptimConfig.keras("sgd", 0.05))
+    avg = PeriodicAverager(dp, every=3, overlap=overlap, delay=2)
+    avg.attach(net)
+    g = torch.Generator().manual_seed(100 + rank)            # each rank sees different data
+    trace = []
+    for step in range(7):
+        x = torch.rand(8, 6, 6, 1, generator=g)
+        y = torch.nn.functional.one_hot(torch.randint(0, 10, (8,), generator=g), 10).float()
+        loss, dl, _ = F.softmax_ce(net.forward(net.prepare_input(x), training=True), y)
+        net.backward(dl)
+        opt.step()
+        net.release()
+        avg.after_step()
+        trace.append(net.P.clone())
+    avg.finish()
+    np.save(f"{out}/trace{rank}.npy", torch.stack(trace).numpy())
+    np.save(f"{out}/final{rank}.npy", net.P.numpy())
+    np.save(f"{out}/navg{rank}.npy", np.array([avg.n_averages]))
+    dist.destroy_process_group()
+
+
+def spmd_ensemble(rank, world, port, out):
+    _init(rank, world, port)
+    from distributeddeeplearning_amd import config
+    from distributeddeeplearning_amd.parallel.ensemble import SpmdEnsemble
+    sp = config.get_space("ddl_ray3", ["data_train_size=600", "random_model_size=3", "transfer_model_size=2",
+                                       "predict_model_size=2", "early_stop_rate=-1.0", "epochs=4", "seed=11"])
+    ens = SpmdEnsemble(sp, "cpu", data_kw={"synthetic": True, "n_train": 700, "n_test": 120})
+    ens.make_and_train_new_models()
+    ens.make_and_train_transfer_models()
+    ens.sort_models()
+    res = [m["acc"] for m in ens.members] + ens.member_test_accuracies() + [ens.get_accuracy()]
+    owners = [m["owner"] for m in ens.members]
+    np.save(f"{out}/ens{rank}.npy", np.array(res + owners, dtype=np.float64))
+    dist.destroy_process_group()
+
+
+def gan_dp(rank, world, port, out):
+    dp = _init(rank, world, port)
+    from distributeddeeplearning_amd.models.dcgan import GANConfig, GANTrainer
+    t = GANTrainer(GANConfig(batch=4, seed=3), "cpu", dp, rank)
+    real = torch.rand(4, 28, 28, 1, generator=torch.Generator().manual_seed(rank))
+    for _ in range(2):
+        dl, gl = t.train_step(real)
+    np.save(f"{out}/gan{rank}.npy", np.concatenate([t.G.P.numpy(), t.D.P.numpy(), [float(dl), float(gl)]]))
+    dist.destroy_process_group()

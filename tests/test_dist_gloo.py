@@ -1,0 +1,70 @@
+"""Multi-process plumbing on the gloo backend, world_size 2 (BASELINE.json config 1: runs without a
+GPU).  The same FlatDataParallel / PeriodicAverager / SpmdEnsemble code runs over RCCL on device."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch.multiprocessing as mp
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import dist_worker as W  # noqa: E402
+
+
+def _port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _spawn(fn, out, *extra, world=2):
+    mp.spawn(fn, args=(world, _port(), str(out), *extra), nprocs=world, join=True)
+
+
+def test_flat_collectives(tmp_path):
+    _spawn(W.collectives, tmp_path)
+    assert all(int(np.load(tmp_path / f"ok{r}.npy")[0]) == 1 for r in range(2))
+
+
+def test_sync_dp_gradient_equals_full_batch(tmp_path):
+    _spawn(W.dp_grad_equals_full_batch, tmp_path)
+    g0, g1, ref = (np.load(tmp_path / n) for n in ("grad0.npy", "grad1.npy", "grad_ref.npy"))
+    assert np.array_equal(g0, g1)
+    assert np.allclose(g0, ref, rtol=1e-4, atol=1e-6)
+    assert np.array_equal(np.load(tmp_path / "P0.npy"), np.load(tmp_path / "P1.npy"))
+
+
+@pytest.mark.parametrize("overlap", [False, True])
+def test_local_sgd_periodic_averaging(tmp_path, overlap):
+    _spawn(W.local_sgd, tmp_path, overlap)
+    t0, t1 = np.load(tmp_path / "trace0.npy"), np.load(tmp_path / "trace1.npy")
+    f0, f1 = np.load(tmp_path / "final0.npy"), np.load(tmp_path / "final1.npy")
+    assert np.array_equal(f0, f1)                              # finish() leaves one common model
+    assert not np.array_equal(t0[0], t1[0])                    # between averages replicas drift apart
+    if not overlap:
+        assert np.allclose(t0[2], t1[2]) and np.allclose(t0[5], t1[5])      # steps 3 and 6 are sync points
+        assert not np.allclose(t0[3], t1[3])
+        assert int(np.load(tmp_path / "navg0.npy")[0]) == 3    # steps 3, 6 + finish
+    else:
+        # delayed correction: replicas are pulled together 2 steps after each launch but not equal
+        d_before = np.abs(t0[3] - t1[3]).max()
+        d_after = np.abs(t0[4] - t1[4]).max()
+        assert d_after < d_before
+        assert int(np.load(tmp_path / "navg0.npy")[0]) >= 3
+
+
+def test_spmd_ensemble_two_ranks_agree(tmp_path):
+    _spawn(W.spmd_ensemble, tmp_path)
+    a, b = np.load(tmp_path / "ens0.npy"), np.load(tmp_path / "ens1.npy")
+    assert np.array_equal(a, b)                                # every rank ends with the same table
+    accs, owners = a[:5], a[-5:]
+    assert list(accs) == sorted(accs, reverse=True) and set(owners) == {0.0, 1.0}
+    assert 0 <= a[10] <= 1
+
+
+def test_gan_data_parallel_replicas_stay_identical(tmp_path):
+    _spawn(W.gan_dp, tmp_path)
+    a, b = np.load(tmp_path / "gan0.npy"), np.load(tmp_path / "gan1.npy")
+    assert np.array_equal(a[:-2], b[:-2])                      # weights identical after 2 DP steps
+    assert np.isfinite(a).all() and not np.array_equal(a[-2:], b[-2:])     # local losses differ (own shard)
