@@ -117,29 +117,34 @@ __global__ __launch_bounds__(EW_BLOCK) void colreduce_kernel(
     }
 }
 
-// Sum block partials part[b][2][C] for channel c with 8 cooperating lanes per channel
-// (blockDim = 256 = 32 channels x 8 partial lanes); result valid where lane_b == 0.
+// Sum block partials part[b][2][C] for channel c.  256 threads = 8 channels x 32 partial lanes: lane
+// `pl` adds partials pl, pl+32, ... (independent loads, fixed order), then the 32 lane sums are
+// combined by a fixed-order shuffle tree inside the half-wave -> deterministic, and short enough
+// (<= 8 loads per lane for 256 partials) that the kernel is a few microseconds instead of a
+// latency-bound serial walk.  Result valid where pl == 0.
 #define FIN_BLOCK 256
+#define FIN_CH 8
 __device__ __forceinline__ void reduce_partials(const float* __restrict__ part, int nblocks, int C, int c,
                                                 bool two, double& s0, double& s1) {
-    __shared__ double fin[2][8][33];
-    const int cl = threadIdx.x & 31, lb = threadIdx.x >> 5;
+    const int pl = threadIdx.x & 31;
     double a0 = 0, a1 = 0;
     if (c < C) {
-        for (int b = lb; b < nblocks; b += 8) {
+        for (int b = pl; b < nblocks; b += 32) {
             a0 += part[(size_t)b * 2 * C + c];
             if (two) a1 += part[(size_t)b * 2 * C + C + c];
         }
     }
-    fin[0][lb][cl] = a0;
-    fin[1][lb][cl] = a1;
-    __syncthreads();
-    s0 = s1 = 0;
-    if (lb == 0) {
 #pragma unroll
-        for (int q = 0; q < 8; ++q) { s0 += fin[0][q][cl]; s1 += fin[1][q][cl]; }
+    for (int o = 16; o > 0; o >>= 1) {
+        a0 += __shfl_down(a0, o, 32);
+        a1 += __shfl_down(a1, o, 32);
     }
+    s0 = a0;
+    s1 = a1;
 }
+#define FIN_CHANNEL() (blockIdx.x * FIN_CH + (threadIdx.x >> 5))
+#define FIN_LEADER() ((threadIdx.x & 31) == 0)
+#define FIN_GRID(C) (((C) + FIN_CH - 1) / FIN_CH)
 
 static inline void colreduce_grid(long rows, int C, dim3* grid) {
     int cg = C / 8;
@@ -147,7 +152,7 @@ static inline void colreduce_grid(long rows, int C, dim3* grid) {
     int rpi = EW_BLOCK / cgl;
     long nb = (rows + (long)rpi * 8 - 1) / ((long)rpi * 8);      // >= 8 rows per thread
     if (nb < 1) nb = 1;
-    if (nb > 512) nb = 512;
+    if (nb > 256) nb = 256;
     *grid = dim3((unsigned)nb, (unsigned)((cg + EW_BLOCK - 1) / EW_BLOCK), 1);
 }
 
@@ -164,10 +169,10 @@ __global__ void bn_stats_finalize_kernel(const float* __restrict__ part, int nbl
                                          float eps, int bessel, int update_moving, float* __restrict__ scale,
                                          float* __restrict__ shift, float* __restrict__ mean_out,
                                          float* __restrict__ invstd_out) {
-    int c = blockIdx.x * 32 + (threadIdx.x & 31);
+    int c = FIN_CHANNEL();
     double s0, s1;
     reduce_partials(part, nblocks, C, c, true, s0, s1);
-    if (c >= C || (threadIdx.x >> 5) != 0) return;
+    if (c >= C || !FIN_LEADER()) return;
     double mean = s0 / (double)rows;
     double var = s1 / (double)rows - mean * mean;
     if (var < 0) var = 0;
@@ -192,7 +197,7 @@ DDL_API void ddl_bn_batch_stats(const void* x, long rows, int C, float* part, co
     colreduce_grid(rows, C, &grid);
     colreduce_kernel<0><<<grid, EW_BLOCK, 0, s>>>((const uint4*)x, nullptr, nullptr, nullptr, nullptr, part,
                                                   rows, C, 0, 0.f);
-    bn_stats_finalize_kernel<<<(C + 31) / 32, FIN_BLOCK, 0, s>>>(part, grid.x, C, rows, gamma, beta, mm, mv,
+    bn_stats_finalize_kernel<<<FIN_GRID(C), FIN_BLOCK, 0, s>>>(part, grid.x, C, rows, gamma, beta, mm, mv,
                                                              momentum, eps, bessel, update_moving, scale,
                                                              shift, mean, invstd);
 }
@@ -232,9 +237,43 @@ __global__ void bn_apply_kernel(const uint4* __restrict__ x, uint4* __restrict__
     }
 }
 
+// Channel-stationary variant (cg divides 256): a thread keeps ONE 8-channel group for its whole
+// life, so scale/shift are loaded once and the loop body is load -> 8 fma/act -> store.
+__global__ __launch_bounds__(EW_BLOCK) void bn_apply_cs_kernel(const uint4* __restrict__ x, uint4* __restrict__ y,
+                                                               const float* __restrict__ scale,
+                                                               const float* __restrict__ shift, long rows, int cg,
+                                                               int c_true, int act, float alpha) {
+    const int g = threadIdx.x % cg, rl = threadIdx.x / cg, rpi = EW_BLOCK / cg;
+    const int c0 = g * 8;
+    const float4 sa = *(const float4*)(scale + c0), sb = *(const float4*)(scale + c0 + 4);
+    const float4 ha = *(const float4*)(shift + c0), hb = *(const float4*)(shift + c0 + 4);
+    const float sc[8] = {sa.x, sa.y, sa.z, sa.w, sb.x, sb.y, sb.z, sb.w};
+    const float sh[8] = {ha.x, ha.y, ha.z, ha.w, hb.x, hb.y, hb.z, hb.w};
+    for (long r = blockIdx.x * (long)rpi + rl; r < rows; r += (long)gridDim.x * rpi) {
+        float f[8];
+        unpack8(x[r * cg + g], f);
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            f[j] = (c0 + j < c_true) ? act_apply(fmaf(f[j], sc[j], sh[j]), act, alpha) : 0.f;
+        y[r * cg + g] = pack8(f);
+    }
+}
+
+static inline bool cs_ok(int cg) { return cg <= EW_BLOCK && EW_BLOCK % cg == 0; }
+static inline int cs_grid(long rows, int cg) {
+    long rpi = EW_BLOCK / cg;
+    long g = (rows + rpi * 4 - 1) / (rpi * 4);          // >= 4 rows per thread
+    return (int)(g < 1 ? 1 : (g > EW_MAX_GRID ? EW_MAX_GRID : g));
+}
+
 DDL_API void ddl_bn_apply(const void* x, void* y, const float* scale, const float* shift, long rows, int C,
                           int c_true, int act, float alpha, hipStream_t s) {
     long n8 = rows * (C / 8);
+    if (cs_ok(C / 8)) {
+        bn_apply_cs_kernel<<<cs_grid(rows, C / 8), EW_BLOCK, 0, s>>>((const uint4*)x, (uint4*)y, scale, shift, rows,
+                                                                   C / 8, c_true, act, alpha);
+        return;
+    }
     bn_apply_kernel<<<ew_grid(n8), EW_BLOCK, 0, s>>>((const uint4*)x, (uint4*)y, scale, shift, n8, C / 8,
                                                      c_true, act, alpha);
 }
@@ -243,10 +282,10 @@ DDL_API void ddl_bn_apply(const void* x, void* y, const float* scale, const floa
 __global__ void bn_bwd_finalize_kernel(const float* __restrict__ part, int nblocks, int C, long rows,
                                        int train_stats, float* __restrict__ dgamma, float* __restrict__ dbeta,
                                        float* __restrict__ c1, float* __restrict__ c2) {
-    int c = blockIdx.x * 32 + (threadIdx.x & 31);
+    int c = FIN_CHANNEL();
     double s0, s1;
     reduce_partials(part, nblocks, C, c, true, s0, s1);
-    if (c >= C || (threadIdx.x >> 5) != 0) return;
+    if (c >= C || !FIN_LEADER()) return;
     if (dbeta) dbeta[c] = (float)s0;
     if (dgamma) dgamma[c] = (float)s1;
     c1[c] = train_stats ? (float)(s0 / (double)rows) : 0.f;
@@ -282,6 +321,42 @@ __global__ void bn_bwd_apply_kernel(const uint4* __restrict__ dy, const uint4* _
     }
 }
 
+__global__ __launch_bounds__(EW_BLOCK) void bn_bwd_apply_cs_kernel(
+    const uint4* __restrict__ dy, const uint4* __restrict__ x, const uint4* __restrict__ yv, uint4* __restrict__ dx,
+    const float* __restrict__ mean, const float* __restrict__ invstd, const float* __restrict__ gamma,
+    const float* __restrict__ c1, const float* __restrict__ c2, long rows, int cg, int act, float alpha,
+    int prev_act, float prev_alpha) {
+    const int g = threadIdx.x % cg, rl = threadIdx.x / cg, rpi = EW_BLOCK / cg;
+    // dx = k0*g' + k1*x + k2 with  k0 = gamma*is, k1 = -gamma*is*is*c2, k2 = -gamma*is*(c1 - mean*is*c2)
+    float k0[8], k1[8], k2[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        int c = g * 8 + j;
+        float is = invstd[c], gi = gamma[c] * is;
+        k0[j] = gi;
+        k1[j] = -gi * is * c2[c];
+        k2[j] = -gi * (c1[c] - mean[c] * is * c2[c]);
+    }
+    for (long r = blockIdx.x * (long)rpi + rl; r < rows; r += (long)gridDim.x * rpi) {
+        const long i = r * cg + g;
+        float gr[8], xv[8], yy[8];
+        unpack8(dy[i], gr);
+        unpack8(x[i], xv);
+        if (act != ACT_LINEAR) {
+            unpack8(yv[i], yy);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) gr[j] *= act_grad_y(yy[j], act, alpha);
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float d = fmaf(k0[j], gr[j], fmaf(k1[j], xv[j], k2[j]));
+            if (prev_act != ACT_LINEAR) d *= act_grad_y(xv[j], prev_act, prev_alpha);
+            gr[j] = d;
+        }
+        dx[i] = pack8(gr);
+    }
+}
+
 DDL_API void ddl_bn_bwd(const void* dy, const void* x, const void* y, void* dx, long rows, int C,
                         const float* mean, const float* invstd, const float* gamma, int act, float alpha,
                         int train_stats, int prev_act, float prev_alpha, float* part, float* dgamma,
@@ -290,9 +365,15 @@ DDL_API void ddl_bn_bwd(const void* dy, const void* x, const void* y, void* dx, 
     colreduce_grid(rows, C, &grid);
     colreduce_kernel<1><<<grid, EW_BLOCK, 0, s>>>((const uint4*)dy, (const uint4*)x, (const uint4*)y, mean,
                                                   invstd, part, rows, C, act, alpha);
-    bn_bwd_finalize_kernel<<<(C + 31) / 32, FIN_BLOCK, 0, s>>>(part, grid.x, C, rows, train_stats, dgamma, dbeta,
+    bn_bwd_finalize_kernel<<<FIN_GRID(C), FIN_BLOCK, 0, s>>>(part, grid.x, C, rows, train_stats, dgamma, dbeta,
                                                            c1, c2);
     long n8 = rows * (C / 8);
+    if (cs_ok(C / 8)) {
+        bn_bwd_apply_cs_kernel<<<cs_grid(rows, C / 8), EW_BLOCK, 0, s>>>(
+            (const uint4*)dy, (const uint4*)x, (const uint4*)y, (uint4*)dx, mean, invstd, gamma, c1, c2, rows, C / 8,
+            act, alpha, prev_act, prev_alpha);
+        return;
+    }
     bn_bwd_apply_kernel<<<ew_grid(n8), EW_BLOCK, 0, s>>>((const uint4*)dy, (const uint4*)x, (const uint4*)y,
                                                          (uint4*)dx, mean, invstd, gamma, c1, c2, n8, C / 8,
                                                          act, alpha, prev_act, prev_alpha);
@@ -301,10 +382,10 @@ DDL_API void ddl_bn_bwd(const void* dy, const void* x, const void* y, void* dx, 
 // bias gradient = per-channel column sum of dY
 __global__ void colsum_finalize_kernel(const float* __restrict__ part, int nblocks, int C, int c_out,
                                        float* __restrict__ out) {
-    int c = blockIdx.x * 32 + (threadIdx.x & 31);
+    int c = FIN_CHANNEL();
     double s0, s1;
     reduce_partials(part, nblocks, C, c, false, s0, s1);
-    if (c >= c_out || (threadIdx.x >> 5) != 0) return;
+    if (c >= c_out || !FIN_LEADER()) return;
     out[c] = (float)s0;
 }
 
@@ -314,7 +395,7 @@ DDL_API void ddl_bias_grad(const void* dy, long rows, int C, int c_out, float* p
     colreduce_grid(rows, C, &grid);
     colreduce_kernel<2><<<grid, EW_BLOCK, 0, s>>>((const uint4*)dy, nullptr, nullptr, nullptr, nullptr, part,
                                                   rows, C, 0, 0.f);
-    colsum_finalize_kernel<<<(c_out + 31) / 32, FIN_BLOCK, 0, s>>>(part, grid.x, C, c_out, out);
+    colsum_finalize_kernel<<<FIN_GRID(c_out), FIN_BLOCK, 0, s>>>(part, grid.x, C, c_out, out);
 }
 
 // ------------------------------------------------------------------------------ casts / layout

@@ -67,6 +67,8 @@ _avg_delta = _sig("ddl_avg_delta", None, vp, vp, vp, vp, cl, cf, vp)
 _philox = _sig("ddl_philox_uniform", None, vp, cl, vp, cf, cf, vp)
 _igemm = _sig("ddl_igemm_conv", ci, vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci,
               ci, ci, ci, ci, cf, ci, vp)
+_pconv = _sig("ddl_pconv", ci, vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, cf,
+              ci, ci, ci, ci, ci, ci, ci, ci, vp)
 _wgrad_ksplit = _sig("ddl_wgrad_ksplit", ci, ci, ci, ci, ci)
 _wgrad = _sig("ddl_conv_wgrad", ci, vp, vp, vp, vp, cl, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci,
               ci, ci, ci, ci, cl, cl, cl, vp)
@@ -75,6 +77,9 @@ _depthwise = _sig("ddl_depthwise", ci, ci, vp, vp, vp, vp, vp, ci, ci, ci, ci, c
                   ci, ci, ci, ci, cf, vp)
 
 IGEMM_TILE = int(os.environ.get("DDL_IGEMM_TILE", "0"))     # 0 = heuristic; tuning knob
+CONV_IMPL = os.environ.get("DDL_CONV", "pconv")             # pconv (patch-resident, default) | igemm
+PCONV_LDS = int(os.environ.get("DDL_PCONV_LDS", "0"))       # LDS budget per block in bytes (0 = 80 KiB)
+PCONV_MIN_ROWS = int(os.environ.get("DDL_PCONV_MIN_ROWS", "150"))   # units with fewer output rows -> igemm
 
 
 def _stream():
@@ -472,13 +477,26 @@ def _tables(g: ConvGeom, mode: str, B: int, device):
         taps = [(0, 0, 0, 0)]
     ct = torch.tensor(classes, dtype=torch.int32).to(device)
     tt = torch.tensor(taps, dtype=torch.int32).to(device)
-    res = (ct, tt, len(classes), max(c[6] for c in classes), max(max(c[4] for c in classes), 1))
+    live = [t for c in classes for t in taps[c[5]:c[5] + c[4]]] or [(0, 0, 0, 0)]
+    meta = (min(t[0] for t in live), max(t[0] for t in live), min(t[1] for t in live), max(t[1] for t in live),
+            max(c[2] for c in classes), max(c[3] for c in classes), len(taps))
+    res = (ct, tt, len(classes), max(c[6] for c in classes), max(max(c[4] for c in classes), 1), meta)
     _TAB_CACHE[key] = res
     return res
 
 
 def _igemm_call(src, wgt, bias, dst, g, mode, B, Hs, Ws, Cs, Hd, Wd, Nd, Nw, ss, sd, act, alpha):
-    ct, tt, ncls, maxM, maxT = _tables(g, mode, B, src.device)
+    ct, tt, ncls, maxM, maxT, meta = _tables(g, mode, B, src.device)
+    if CONV_IMPL == "pconv":
+        rc = _pconv(src.data_ptr(), wgt.data_ptr(), _p(bias), dst.data_ptr(), ct.data_ptr(), tt.data_ptr(), ncls,
+                    meta[6], B, Hs, Ws, Cs, Hd, Wd, Nd, Nw, ss[0], ss[1], sd[0], sd[1], g.KH * g.KW, ACT_CODE[act],
+                    alpha, meta[0], meta[1], meta[2], meta[3], meta[4], meta[5], PCONV_LDS, PCONV_MIN_ROWS, _stream())
+        if rc == 0:
+            _done()
+            return
+        if rc < 0:
+            raise ValueError(f"pconv rejected the problem (rc={rc}): {g} mode={mode} B={B}")
+        # rc == 1: the source patch does not fit in LDS -> global-gather implicit GEMM below
     rc = _igemm(src.data_ptr(), wgt.data_ptr(), _p(bias), dst.data_ptr(), ct.data_ptr(), tt.data_ptr(), ncls,
                 maxM, maxT, B, Hs, Ws, Cs, Hd, Wd, Nd, Nw, ss[0], ss[1], sd[0], sd[1], g.KH * g.KW,
                 ACT_CODE[act], alpha, IGEMM_TILE, _stream())
