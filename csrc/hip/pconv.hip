@@ -1,55 +1,63 @@
 // Patch-resident implicit-GEMM convolution (gfx950, v_mfma_f32_16x16x32_bf16).
 //
-// Same problem statement and class/tap tables as igemm_conv.hip (fprop, sub-pixel dgrad, Dense),
-// different data movement.  igemm_conv re-fetches the pixel operand from global memory for every
-// tap, so with the small channel counts of these networks (N = 8..128) it is bound by L2->LDS
-// traffic (M x K x 2 B per launch: 0.6 GB for one DCGAN ConvTranspose at B = 1000).  Here a block
-// owns a *unit* -- IMG whole images, or a band of rows of one image -- and stages the source patch
-// (with a zero halo) into LDS exactly once; the MFMA pixel fragments of every tap and every
-// sub-pixel class are then read straight out of that patch (address = pixel base + tap offset),
-// so global traffic drops to (input once + weights per 256-row pass) and the kernel runs at the
-// LDS/MFMA rate.  Only the weights are streamed through a register-staged, double-buffered LDS
-// stage (64 k-elements per barrier).
+// Same problem statement as igemm_conv.hip (fprop, sub-pixel dgrad), different data movement.
+// igemm_conv re-fetches the pixel operand from global memory for every tap, so with the small
+// channel counts of these networks (N = 8..64) it is bound by L2->LDS traffic and by gather
+// address arithmetic.  Here a block owns a *unit* -- IMG whole images, or a band of rows of one
+// image -- and stages the source patch (with a zero halo) into LDS exactly once; the MFMA pixel
+// fragments of every tap and every sub-pixel class are then read straight out of that patch
+// (address = pixel base + per-k-unit offset), so global traffic drops to (input once + weights per
+// pass).  Weights stream through a register-staged, double-buffered LDS stage of 64 k-elements,
+// their global loads running three stages ahead of the MFMAs.
+//
+// All index arithmetic of the K loop is table driven: the host plan (ops/hip.py: _pconv_plan)
+// expands every class into stages of eight 8-element k-units and stores, per unit, the patch byte
+// offset of its tap/channel and the element offset inside a weight row.  The inner loop is then
+// one table read, FR address adds, FR + NT ds_read_b128 and FR*NT MFMAs per 32-deep sub-step.
 //
 // LDS image of the patch: [img][prow][pcol] pixels of `pitch` bytes (Cs*2 data + pad).  A fragment
 // read is one ds_read_b128 per lane at pixel(fr)*pitch + k-chunk(fq)*16; its 16-lane groups are
-// conflict-free when (src stride x pitch/16) == 2 (mod 4)  (see pick_pitch()).
+// conflict-free when (src stride x pitch/16) == 2 (mod 4) (the plan picks the pitch accordingly).
 #include "common.h"
-#include <stdio.h>
-#include <stdlib.h>
 
-struct PClassDesc { int ph, pw, Hc, Wc, ntaps, tap_off, M, pad; };
+struct PClass {
+    int ph, pw, Hc, Wc;
+    int nstages, stage_off;
+    float inv_Wc, pad;
+};
 
 struct PConvArgs {
     const bf16_t* src; const bf16_t* wgt; const float* bias; bf16_t* dst;
-    const PClassDesc* classes; const int4* taps;     // tap = {offh, offw, wtap, 0}
-    int n_classes, total_taps;
+    const PClass* classes; const int2* ktab;     // ktab[(stage)*8 + unit] = {patch byte offset, weight elem offset | -1}
+    int n_classes, total_stages;
     int B, Hs, Ws, Cs;
     int Hd, Wd, Nd, Nw;
-    int ssh, ssw, sdh, sdw, Ttot;
+    int ssh, ssw, sdh, sdw;
+    int wrow;                      // elements per weight row (Ttot * Cs)
     int act; float alpha;
     int IMG, BR, bands;            // unit = IMG images x BR class-grid rows
     int omin_h, omin_w, PH, PW;    // patch origin (min tap offset) and extent for a full band
     int pitch, img_bytes;          // bytes per patch pixel / per patch image
-    int w_off, t_off, z_off, e_off; // LDS offsets: weight stages, tap table, zero slot, epilogue scratch
+    int w_off, k_off, e_off;       // LDS offsets: weight stages, k-unit table, epilogue scratch
     float inv_per_img, inv_cs8, inv_PW;   // reciprocals for the staging loop's index split
-    int dbg;
 };
 
-// floor(x / d) for 0 <= x < 2^22 via a float reciprocal (exact: the +0.5 keeps x/d away from integers)
+// floor(x / d) for 0 <= x < 2^22 via a float reciprocal (the +0.5 keeps x/d away from integers)
 __device__ __forceinline__ int fdiv(int x, float inv) { return __float2int_rz(((float)x + 0.5f) * inv); }
 
 #define WPITCH 160                 // weight stage row: 64 k-elements (128 B) + 32 B pad  (P = 10 == 2 mod 4)
 
-template <int BN>
-__global__ __launch_bounds__(256) void pconv_kernel(const PConvArgs a) {
-    constexpr int NT = BN / 16;                        // 16-channel MFMA tiles per wave (wave = 64 px x BN ch)
+// SLOW = the activation is one of the transcendental ones (sigmoid / softplus / tanh / softsign /
+// tanh01): only that instantiation carries their (fully unrolled) code.
+template <int BN, int FR, bool SLOW>
+__global__ __launch_bounds__(256, (BN * FR >= 512 ? 1 : 2)) void pconv_kernel(const PConvArgs a) {
+    constexpr int NT = BN / 16;                        // 16-channel MFMA tiles per wave
     constexpr int RW = (BN * 8 + 255) / 256;           // 16-B weight units staged per thread per stage
+    constexpr int PASS = 4 * FR * 16;                  // rows per pass (4 waves x FR fragments x 16 px)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* sP = smem;                                   // patch
     char* sW = smem + a.w_off;                         // [2][BN][WPITCH]
-    int2* sT = (int2*)(smem + a.t_off);                // per tap: {patch byte offset, weight tap index}
-    const int z_off = a.z_off;                         // 64 B of zeros
+    const int2* sK = (const int2*)(smem + a.k_off);    // k-unit table
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int fr = lane & 15, fq = lane >> 4;
@@ -71,62 +79,56 @@ __global__ __launch_bounds__(256) void pconv_kernel(const PConvArgs a) {
             int pr = fdiv(pix, a.inv_PW), pc = pix - pr * a.PW;
             int sr = row0 + pr, sc = col0 + pc, b = b0 + img;
             uint4 v = make_uint4(0, 0, 0, 0);
-            if (!(a.dbg & 1) && b < a.B && (unsigned)sr < (unsigned)a.Hs && (unsigned)sc < (unsigned)a.Ws)
+            if (b < a.B && (unsigned)sr < (unsigned)a.Hs && (unsigned)sc < (unsigned)a.Ws)
                 v = *(const uint4*)(a.src + (((long)b * a.Hs + sr) * a.Ws + sc) * Cs + c8 * 8);
             *(uint4*)(sP + img * a.img_bytes + pix * a.pitch + c8 * 16) = v;
         }
-        for (int t = tid; t < a.total_taps; t += 256) {
-            int4 te = a.taps[t];
-            sT[t] = make_int2(((te.x - a.omin_h) * a.PW + (te.y - a.omin_w)) * a.pitch, te.z);
-        }
-        if (tid < 4) *(uint4*)(smem + z_off + tid * 16) = make_uint4(0, 0, 0, 0);
+        int2* sKw = (int2*)(smem + a.k_off);
+        for (int t = tid; t < a.total_stages * 8; t += 256) sKw[t] = a.ktab[t];
     }
     __syncthreads();
 
-    // weight staging assignment: unit q (8 k-elements) of row wr0 + 32*r
+    // weight staging assignment: k-unit wq of rows wr0 + 32*r
     const int wq = tid & 7, wr0 = tid >> 3;
+    const bf16_t* wbase[RW];
+    bool wok[RW];
+#pragma unroll
+    for (int r = 0; r < RW; ++r) {
+        int nl = wr0 + 32 * r, n = n0 + nl;
+        wok[r] = nl < BN && n < a.Nw;
+        wbase[r] = a.wgt + (long)(wok[r] ? n : 0) * a.wrow;
+    }
 
     for (int ci = 0; ci < a.n_classes; ++ci) {
-        const PClassDesc cd = a.classes[ci];
-        int nrow = min(i0 + a.BR, cd.Hc) - i0;
+        const PClass cd = a.classes[ci];
+        const int nrow = min(i0 + a.BR, cd.Hc) - i0;
         if (nrow <= 0) continue;
         const int per_img_rows = nrow * cd.Wc;
+        const float inv_rows = 1.0f / (float)per_img_rows;
         const int Mloc = a.IMG * per_img_rows;
-        const int nstages = (cd.ntaps * Cs + 63) >> 6;
+        const int nstages = cd.nstages;
+        const int2* ck = sK + cd.stage_off * 8;
 
-        for (int ms = 0; ms < Mloc; ms += 256) {
-            // ---- this lane's four pixels (one per 16-row fragment)
-            int pixbase[4];
+        for (int ms = 0; ms < Mloc; ms += PASS) {
+            // ---- this lane's FR pixels (one per 16-row fragment)
+            int pixbase[FR];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                int m = ms + wave * 64 + 16 * j + fr;
+            for (int j = 0; j < FR; ++j) {
+                int m = ms + (wave * FR + j) * 16 + fr;
                 int mm = m < Mloc ? m : 0;
-                int img = mm / per_img_rows, rem = mm - img * per_img_rows;
-                int il = rem / cd.Wc, jl = rem - il * cd.Wc;
+                int img = fdiv(mm, inv_rows), rem = mm - img * per_img_rows;
+                int il = fdiv(rem, cd.inv_Wc), jl = rem - il * cd.Wc;
                 pixbase[j] = img * a.img_bytes + (il * a.ssh * a.PW + jl * a.ssw) * a.pitch;
             }
-            // (tap, channel) cursors: two per lane for the fragment reads (sub-steps 0/1), one for staging
-            int ftap[2], fc[2];
-#pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                int k = s * 32 + fq * 8;
-                ftap[s] = k / Cs;
-                fc[s] = k - ftap[s] * Cs;
-            }
-            int wtap = (wq * 8) / Cs, wc = wq * 8 - wtap * Cs;
 
             uint4 regA[RW], regB[RW];              // stage s lives in regA (s even) / regB (s odd)
+            int wst = 0;                           // next stage to load
             auto gload = [&](uint4* reg) {
-                const bool tv = wtap < cd.ntaps;
-                const int wt = tv ? sT[cd.tap_off + wtap].y : 0;
+                const int kw = wst < nstages ? ck[wst * 8 + wq].y : -1;
+                ++wst;
 #pragma unroll
-                for (int r = 0; r < RW; ++r) {
-                    int nl = wr0 + 32 * r, n = n0 + nl;
-                    bool ok = tv && nl < BN && n < a.Nw && !(a.dbg & 2);
-                    reg[r] = ok ? *(const uint4*)(a.wgt + ((long)n * a.Ttot + wt) * Cs + wc) : make_uint4(0, 0, 0, 0);
-                }
-                wc += 64;
-                while (wc >= Cs) { wc -= Cs; ++wtap; }
+                for (int r = 0; r < RW; ++r)
+                    reg[r] = (kw >= 0 && wok[r]) ? *(const uint4*)(wbase[r] + kw) : make_uint4(0, 0, 0, 0);
             };
             auto lstore = [&](int buf, const uint4* reg) {
 #pragma unroll
@@ -136,88 +138,116 @@ __global__ __launch_bounds__(256) void pconv_kernel(const PConvArgs a) {
                 }
             };
 
-            f32x4 acc[NT][4];
+            f32x4 acc[NT][FR];
 #pragma unroll
             for (int i = 0; i < NT; ++i)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                for (int j = 0; j < FR; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-            auto compute = [&](int cur) {
-                if (a.dbg & 4) return;
+            auto compute = [&](int cur, int st) {
 #pragma unroll
                 for (int s = 0; s < 2; ++s) {
-                    const bool tv = ftap[s] < cd.ntaps;
-                    const int koff = tv ? sT[cd.tap_off + ftap[s]].x + fc[s] * 2 : 0;
-                    bf16x8_t wf[NT], xf[4];
+                    const int ka = ck[st * 8 + s * 4 + fq].x;
+                    bf16x8_t wf[NT], xf[FR];
 #pragma unroll
                     for (int i = 0; i < NT; ++i)
                         wf[i] = *(const bf16x8_t*)(sW + (cur * BN + 16 * i + fr) * WPITCH + s * 64 + fq * 16);
 #pragma unroll
-                    for (int j = 0; j < 4; ++j)
-                        xf[j] = *(const bf16x8_t*)(sP + (tv ? pixbase[j] + koff : z_off));
+                    for (int j = 0; j < FR; ++j) xf[j] = *(const bf16x8_t*)(sP + pixbase[j] + ka);
 #pragma unroll
                     for (int i = 0; i < NT; ++i)
 #pragma unroll
-                        for (int j = 0; j < 4; ++j)
+                        for (int j = 0; j < FR; ++j)
                             acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], xf[j], acc[i][j], 0, 0, 0);
-                    fc[s] += 64;
-                    while (fc[s] >= Cs) { fc[s] -= Cs; ++ftap[s]; }
                 }
             };
 
-            // Weight pipeline: global loads run three stages ahead of the MFMAs (two register sets in
-            // flight), the LDS stage is double-buffered, one barrier per stage.  Loads past the last
-            // stage return zeros (tap >= ntaps) and are never stored.
+            // Weight pipeline: loads run three stages ahead (two register sets in flight), the LDS stage
+            // is double-buffered, one barrier per stage.  Loads past the last stage are zeros, never stored.
             gload(regA);                 // stage 0
             lstore(0, regA);
             gload(regB);                 // stage 1
             gload(regA);                 // stage 2
             __syncthreads();
-            for (int st = 0; st < nstages; st += 2) {
-                if (st + 1 < nstages) lstore(1, regB);      // stage st+1
+            for (int st = 0; st < nstages; st += 2) {       // nstages is even (the plan pads with a zero stage)
+                lstore(1, regB);                            // stage st+1
                 gload(regB);                                // stage st+3
-                compute(0);
+                compute(0, st);
                 __syncthreads();
-                if (st + 1 >= nstages) break;
-                if (st + 2 < nstages) lstore(0, regA);      // stage st+2
+                lstore(0, regA);                            // stage st+2 (zeros past the end; never read)
                 gload(regA);                                // stage st+4
-                compute(1);
+                compute(1, st + 1);
                 __syncthreads();
             }
 
-            // ---- epilogue: lane holds channels 16t + 4fq .. +3 of pixel 16j + fr.  Writing that
-            // straight out would be 8-byte stores in 32-byte runs; instead each 16-pixel fragment is
-            // transposed through a per-wave LDS scratch and leaves as 16-byte stores covering every
-            // pixel's whole channel run (64..256 contiguous bytes per pixel).
+            // ---- epilogue.  A lane holds channels 16t + 4fq .. +3 of pixel 16j + fr; written directly
+            // that is 8-byte stores in 32-byte runs.  Each 16-pixel fragment is instead transposed
+            // through a per-wave LDS scratch and leaves as 16-byte stores covering every pixel's whole
+            // channel run.  Bias is hoisted, the activation switch is outside the element loops.
             {
                 constexpr int EROW = BN * 2 + 16;
                 char* sE = smem + a.e_off + wave * (16 * EROW + 64);
                 int* sPix = (int*)(sE + 16 * EROW);
+                float bv[NT][4];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    int m = ms + wave * 64 + 16 * j + fr;
+                for (int t = 0; t < NT; ++t)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        int n = n0 + 16 * t + 4 * fq + e;
+                        bv[t][e] = (a.bias && n < a.Nw) ? a.bias[n] : 0.f;
+                    }
+                const int act = a.act;
+                const float alpha = a.alpha;
+                if (SLOW) {
+                    // fully unrolled: runtime-indexed accumulators would be demoted to scratch memory
+#pragma unroll
+                    for (int t = 0; t < NT; ++t)
+#pragma unroll
+                        for (int j = 0; j < FR; ++j)
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) acc[t][j][e] = act_apply(acc[t][j][e] + bv[t][e], act, alpha);
+                } else if (act == ACT_LINEAR) {
+#pragma unroll
+                    for (int t = 0; t < NT; ++t)
+#pragma unroll
+                        for (int j = 0; j < FR; ++j)
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) acc[t][j][e] += bv[t][e];
+                } else if (act == ACT_RELU) {
+#pragma unroll
+                    for (int t = 0; t < NT; ++t)
+#pragma unroll
+                        for (int j = 0; j < FR; ++j)
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) acc[t][j][e] = fmaxf(acc[t][j][e] + bv[t][e], 0.f);
+                } else {                                    // ACT_LEAKY
+#pragma unroll
+                    for (int t = 0; t < NT; ++t)
+#pragma unroll
+                        for (int j = 0; j < FR; ++j)
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                float x = acc[t][j][e] + bv[t][e];
+                                acc[t][j][e] = x > 0.f ? x : alpha * x;
+                            }
+                }
+                // channels >= Nw (padding lanes) must be exactly zero
+                const int nlim = a.Nw - n0 - 4 * fq;       // channel 16t + e is real iff 16t + e < nlim
+#pragma unroll
+                for (int j = 0; j < FR; ++j) {
+                    int m = ms + (wave * FR + j) * 16 + fr;
                     int mm = m < Mloc ? m : 0;
-                    int img = mm / per_img_rows, rem = mm - img * per_img_rows;
-                    int il = rem / cd.Wc, jl = rem - il * cd.Wc;
+                    int img = fdiv(mm, inv_rows), rem = mm - img * per_img_rows;
+                    int il = fdiv(rem, cd.inv_Wc), jl = rem - il * cd.Wc;
                     int b = b0 + img;
-                    bool ok = m < Mloc && b < a.B && !(a.dbg & 8);
+                    bool ok = m < Mloc && b < a.B;
                     int pix = (b * a.Hd + cd.ph + a.sdh * (i0 + il)) * a.Wd + cd.pw + a.sdw * jl;
                     if (fq == 0) sPix[fr] = ok ? pix : -1;
 #pragma unroll
                     for (int t = 0; t < NT; ++t) {
-                        int nb = n0 + 16 * t + 4 * fq;
                         float v[4];
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            int n = nb + e;
-                            float x = acc[t][j][e];
-                            if (n < a.Nw) {
-                                if (a.bias) x += a.bias[n];
-                                v[e] = act_apply(x, a.act, a.alpha);
-                            } else {
-                                v[e] = 0.f;
-                            }
-                        }
+                        for (int e = 0; e < 4; ++e) v[e] = (16 * t + e < nlim) ? acc[t][j][e] : 0.f;
                         *(uint2*)(sE + fr * EROW + (16 * t + 4 * fq) * 2) =
                             make_uint2(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]));
                     }
@@ -241,106 +271,66 @@ __global__ __launch_bounds__(256) void pconv_kernel(const PConvArgs a) {
     }
 }
 
-// smallest pixel pitch (bytes, multiple of 16, >= Cs*2) whose 16-lane ds_read_b128 groups are
-// conflict-free for consecutive pixels `stride` apart: (stride * pitch/16) == 2 (mod 4)
-static int pick_pitch(int Cs, int stride) {
-    int p0 = Cs / 8;
-    for (int p = p0; p < p0 + 4; ++p)
-        if (((long)stride * p) % 4 == 2) return p * 16;
-    return (p0 | 1) * 16;
-}
-
-template <int BN>
-static int launch_pconv(PConvArgs& a, int units, size_t smem, hipStream_t s) {
+template <int BN, int FR, bool SLOW>
+static int launch_pconv2(PConvArgs& a, int units, size_t smem, hipStream_t s) {
     if (smem > 64 * 1024) {
         static bool done = false;
         if (!done) {
-            hipFuncSetAttribute((const void*)pconv_kernel<BN>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            hipFuncSetAttribute((const void*)pconv_kernel<BN, FR, SLOW>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                160 * 1024);
             done = true;
         }
     }
     dim3 grid(units, (a.Nd + BN - 1) / BN);
-    pconv_kernel<BN><<<grid, 256, smem, s>>>(a);
+    pconv_kernel<BN, FR, SLOW><<<grid, 256, smem, s>>>(a);
     return 0;
 }
 
-// Returns 0 on success; 1 if the problem does not fit the patch scheme (caller falls back to
-// ddl_igemm_conv; nothing launched); negative on an argument error.
-// omin/omax: min / max tap offsets over every class; maxHc / maxWc: largest class grid.
+template <int BN, int FR>
+static int launch_pconv(PConvArgs& a, int units, size_t smem, hipStream_t s) {
+    const bool fast = a.act == ACT_LINEAR || a.act == ACT_RELU || a.act == ACT_LEAKY;
+    return fast ? launch_pconv2<BN, FR, false>(a, units, smem, s) : launch_pconv2<BN, FR, true>(a, units, smem, s);
+}
+
+DDL_API int ddl_pconv_lds_bytes(int BN, int total_stages, long patch_bytes) {
+    long w = 2L * BN * WPITCH, k = (long)total_stages * 64, e = 4L * (16 * (BN * 2 + 16) + 64);
+    long p = (patch_bytes + 15) / 16 * 16;
+    long tot = p + w + k + e;
+    return tot > (1L << 30) ? -1 : (int)tot;
+}
+
+// The plan (unit decomposition, patch geometry, k-unit table) is made by the caller; this only
+// validates it against the LDS limit and launches.  Returns 0 on success, negative on a bad plan.
 DDL_API int ddl_pconv(const void* src, const void* wgt, const float* bias, void* dst, const void* classes,
-                      const void* taps, int n_classes, int total_taps, int B, int Hs, int Ws, int Cs, int Hd, int Wd,
-                      int Nd, int Nw, int ssh, int ssw, int sdh, int sdw, int Ttot, int act, float alpha, int omin_h,
-                      int omax_h, int omin_w, int omax_w, int maxHc, int maxWc, int lds_budget, int min_rows, hipStream_t s) {
-    if (Cs % 8 != 0 || Cs <= 0 || Nd <= 0 || n_classes <= 0 || B <= 0) return -1;
+                      const void* ktab, int n_classes, int total_stages, int B, int Hs, int Ws, int Cs, int Hd,
+                      int Wd, int Nd, int Nw, int ssh, int ssw, int sdh, int sdw, int Ttot, int act, float alpha,
+                      int IMG, int BR, int bands, int omin_h, int omin_w, int PH, int PW, int pitch, int BN, int FR,
+                      hipStream_t s) {
+    if (Cs % 8 != 0 || Cs <= 0 || Nd <= 0 || Nd % 8 != 0 || n_classes <= 0 || B <= 0 || IMG <= 0 || BR <= 0) return -1;
+    if (pitch % 16 != 0 || pitch < Cs * 2) return -1;
     if ((long)B * Hs * Ws * Cs >= (1L << 31) || (long)B * Hd * Wd * Nd >= (1L << 31)) return -3;
+    if ((long)Nw * Ttot * Cs >= (1L << 31)) return -3;
     PConvArgs a;
     a.src = (const bf16_t*)src; a.wgt = (const bf16_t*)wgt; a.bias = bias; a.dst = (bf16_t*)dst;
-    a.classes = (const PClassDesc*)classes; a.taps = (const int4*)taps;
-    a.n_classes = n_classes; a.total_taps = total_taps;
+    a.classes = (const PClass*)classes; a.ktab = (const int2*)ktab;
+    a.n_classes = n_classes; a.total_stages = total_stages;
     a.B = B; a.Hs = Hs; a.Ws = Ws; a.Cs = Cs; a.Hd = Hd; a.Wd = Wd; a.Nd = Nd; a.Nw = Nw;
-    a.ssh = ssh; a.ssw = ssw; a.sdh = sdh; a.sdw = sdw; a.Ttot = Ttot; a.act = act; a.alpha = alpha;
-    a.omin_h = omin_h; a.omin_w = omin_w;
-    const int BN = Nd <= 16 ? 16 : (Nd <= 32 ? 32 : (Nd <= 64 ? 64 : 128));
-    a.pitch = pick_pitch(Cs, ssw);
-    a.PW = (maxWc - 1) * ssw + (omax_w - omin_w) + 1;
-    const long escratch = 4L * (16 * (BN * 2 + 16) + 64);
-    const long fixed = 2L * BN * WPITCH + (long)total_taps * 8 + 64 + 64 + escratch;
-    if (lds_budget <= 0) lds_budget = 80 * 1024;             // two blocks per CU
-    const long hard = 160L * 1024;
-    auto patch_rows = [&](int br) { return (br - 1) * ssh + (omax_h - omin_h) + 1; };
-    long img_full = (long)patch_rows(maxHc) * a.PW * a.pitch;
-    long avail = lds_budget - fixed;
-    const int ntile = (Nd + BN - 1) / BN;
-    if (img_full <= avail) {
-        a.BR = maxHc; a.bands = 1;
-        long rows_per_img = (long)maxHc * maxWc;
-        long img = avail / img_full;
-        long cap = (1024 + rows_per_img - 1) / rows_per_img;         // ~4 passes of 256 rows per class
-        if (img > cap) img = cap;
-        if (img > B) img = B;
-        while (img > 1 && (long)((B + img - 1) / img) * ntile < 256) --img;      // keep every CU busy
-        // among [img/2, img] take the count that wastes the fewest rows of the 256-row passes
-        long best = img;
-        double best_eff = 0;
-        for (long c = img; c >= (img + 1) / 2 && c >= 1; --c) {
-            long rows = c * rows_per_img;
-            double eff = (double)rows / (double)((rows + 255) / 256 * 256);
-            if (eff > best_eff + 1e-9) { best_eff = eff; best = c; }
-        }
-        a.IMG = (int)best;
-    } else {
-        a.IMG = 1;
-        int br = maxHc;
-        while (br > 1 && (long)patch_rows(br) * a.PW * a.pitch > avail) --br;
-        if ((long)patch_rows(br) * a.PW * a.pitch > avail) {          // not even one row at 2 blocks/CU
-            avail = hard - fixed;
-            if ((long)patch_rows(br) * a.PW * a.pitch > avail) return 1;
-        }
-        a.BR = br; a.bands = (maxHc + br - 1) / br;
-    }
-    a.PH = patch_rows(a.BR);
-    a.img_bytes = a.PH * a.PW * a.pitch;
-    long patch = (long)a.IMG * a.img_bytes;
+    a.ssh = ssh; a.ssw = ssw; a.sdh = sdh; a.sdw = sdw; a.wrow = Ttot * Cs; a.act = act; a.alpha = alpha;
+    a.IMG = IMG; a.BR = BR; a.bands = bands; a.omin_h = omin_h; a.omin_w = omin_w; a.PH = PH; a.PW = PW;
+    a.pitch = pitch; a.img_bytes = PH * PW * pitch;
+    long patch = (long)IMG * a.img_bytes;
+    if ((long)IMG * PH * PW * (Cs / 8) >= (1L << 22)) return -2;
     a.w_off = (int)((patch + 15) / 16 * 16);
-    a.t_off = a.w_off + 2 * BN * WPITCH;
-    a.z_off = (int)((a.t_off + (long)total_taps * 8 + 15) / 16 * 16);
-    a.e_off = a.z_off + 64;
-    size_t smem = (size_t)a.e_off + escratch;
-    if (smem > (size_t)hard) return 1;
-    a.inv_per_img = 1.0f / (float)(a.PH * a.PW * (Cs / 8));
+    a.k_off = a.w_off + 2 * BN * WPITCH;
+    a.e_off = a.k_off + total_stages * 64;
+    size_t smem = (size_t)a.e_off + 4 * (16 * (BN * 2 + 16) + 64);
+    if (smem > 160 * 1024) return -2;
+    a.inv_per_img = 1.0f / (float)(PH * PW * (Cs / 8));
     a.inv_cs8 = 1.0f / (float)(Cs / 8);
-    a.inv_PW = 1.0f / (float)a.PW;
-    { const char* e = getenv("DDL_PCONV_DBG"); a.dbg = e ? atoi(e) : 0; }
-    if (getenv("DDL_PCONV_VERBOSE")) printf("pconv: BN=%d IMG=%d BR=%d bands=%d PH=%d PW=%d pitch=%d lds=%d\n", BN, a.IMG, a.BR, a.bands, a.PH, a.PW, a.pitch, (int)(a.e_off + escratch));
-    if ((long)a.IMG * a.PH * a.PW * (Cs / 8) >= (1L << 22)) return 1;
-    // The patch scheme pays when a unit offers enough rows to amortise streaming the weights; tiny
-    // images with wide channels (4x4x128, Dense) are better served by the global-gather kernel.
-    if ((long)a.IMG * maxHc * maxWc < min_rows) return 1;
-    int units = ((B + a.IMG - 1) / a.IMG) * a.bands;
-    switch (BN) {
-        case 16: return launch_pconv<16>(a, units, smem, s);
-        case 32: return launch_pconv<32>(a, units, smem, s);
-        case 64: return launch_pconv<64>(a, units, smem, s);
-        default: return launch_pconv<128>(a, units, smem, s);
-    }
+    a.inv_PW = 1.0f / (float)PW;
+    int units = ((B + IMG - 1) / IMG) * bands;
+#define PC_CASE(BN_, FR_) if (BN == BN_ && FR == FR_) return launch_pconv<BN_, FR_>(a, units, smem, s);
+    PC_CASE(16, 4) PC_CASE(16, 8) PC_CASE(32, 4) PC_CASE(32, 8) PC_CASE(64, 4) PC_CASE(64, 8) PC_CASE(128, 4)
+#undef PC_CASE
+    return -4;
 }

@@ -68,7 +68,8 @@ _philox = _sig("ddl_philox_uniform", None, vp, cl, vp, cf, cf, vp)
 _igemm = _sig("ddl_igemm_conv", ci, vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci,
               ci, ci, ci, ci, cf, ci, vp)
 _pconv = _sig("ddl_pconv", ci, vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, cf,
-              ci, ci, ci, ci, ci, ci, ci, ci, vp)
+              ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, vp)
+_pconv_lds = _sig("ddl_pconv_lds_bytes", ci, ci, ci, cl)
 _wgrad_ksplit = _sig("ddl_wgrad_ksplit", ci, ci, ci, ci, ci)
 _wgrad = _sig("ddl_conv_wgrad", ci, vp, vp, vp, vp, cl, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci,
               ci, ci, ci, ci, cl, cl, cl, vp)
@@ -80,6 +81,7 @@ IGEMM_TILE = int(os.environ.get("DDL_IGEMM_TILE", "0"))     # 0 = heuristic; tun
 CONV_IMPL = os.environ.get("DDL_CONV", "pconv")             # pconv (patch-resident, default) | igemm
 PCONV_LDS = int(os.environ.get("DDL_PCONV_LDS", "0"))       # LDS budget per block in bytes (0 = 80 KiB)
 PCONV_MIN_ROWS = int(os.environ.get("DDL_PCONV_MIN_ROWS", "150"))   # units with fewer output rows -> igemm
+PCONV_FR = int(os.environ.get("DDL_PCONV_FR", "0"))         # fragments per wave (4 | 8; 0 = heuristic)
 
 
 def _stream():
@@ -443,16 +445,13 @@ def philox_uniform(shape, dtype, state, lo=-1.0, hi=1.0):
 _TAB_CACHE: Dict[Tuple, Tuple] = {}
 
 
-def _tables(g: ConvGeom, mode: str, B: int, device):
-    """Class descriptors + tap tables for the implicit-GEMM kernel (see igemm_conv.hip)."""
-    key = (g, mode, B, str(device))
-    hit = _TAB_CACHE.get(key)
-    if hit is not None:
-        return hit
+def _class_taps(g: ConvGeom, mode: str):
+    """Python-side class / tap lists of the class-grid formulation (see igemm_conv.hip):
+    classes [(ph, pw, Hc, Wc, ntaps, tap_off)], taps [(offh, offw, wtap)]."""
     classes, taps = [], []
     if mode == "fprop":
-        tl = [(kh * g.dh - g.pt, kw * g.dw - g.pl, kh * g.KW + kw, 0) for kh in range(g.KH) for kw in range(g.KW)]
-        classes.append((0, 0, g.OH, g.OW, len(tl), 0, B * g.OH * g.OW, 0))
+        tl = [(kh * g.dh - g.pt, kw * g.dw - g.pl, kh * g.KW + kw) for kh in range(g.KH) for kw in range(g.KW)]
+        classes.append((0, 0, g.OH, g.OW, len(tl), 0))
         taps += tl
     else:
         for ph in range(g.sh):
@@ -470,38 +469,221 @@ def _tables(g: ConvGeom, mode: str, B: int, device):
                         tw = pw + g.pl - kw * g.dw
                         if tw % g.sw:
                             continue
-                        tl.append((th // g.sh, tw // g.sw, kh * g.KW + kw, 0))
-                classes.append((ph, pw, Hc, Wc, len(tl), len(taps), B * Hc * Wc, 0))
+                        tl.append((th // g.sh, tw // g.sw, kh * g.KW + kw))
+                classes.append((ph, pw, Hc, Wc, len(tl), len(taps)))
                 taps += tl
-    if not taps:
-        taps = [(0, 0, 0, 0)]
+    return classes, taps
+
+
+def _tables(g: ConvGeom, mode: str, B: int, device):
+    """Class descriptors + tap tables for the implicit-GEMM kernel (see igemm_conv.hip)."""
+    key = (g, mode, B, str(device))
+    hit = _TAB_CACHE.get(key)
+    if hit is not None:
+        return hit
+    cl_, tp_ = _class_taps(g, mode)
+    classes = [(c[0], c[1], c[2], c[3], c[4], c[5], B * c[2] * c[3], 0) for c in cl_]
+    taps = [(t[0], t[1], t[2], 0) for t in tp_] or [(0, 0, 0, 0)]
     ct = torch.tensor(classes, dtype=torch.int32).to(device)
     tt = torch.tensor(taps, dtype=torch.int32).to(device)
-    live = [t for c in classes for t in taps[c[5]:c[5] + c[4]]] or [(0, 0, 0, 0)]
-    meta = (min(t[0] for t in live), max(t[0] for t in live), min(t[1] for t in live), max(t[1] for t in live),
-            max(c[2] for c in classes), max(c[3] for c in classes), len(taps))
-    res = (ct, tt, len(classes), max(c[6] for c in classes), max(max(c[4] for c in classes), 1), meta)
+    res = (ct, tt, len(classes), max(c[6] for c in classes), max(max(c[4] for c in classes), 1))
     _TAB_CACHE[key] = res
     return res
 
 
-def _igemm_call(src, wgt, bias, dst, g, mode, B, Hs, Ws, Cs, Hd, Wd, Nd, Nw, ss, sd, act, alpha):
-    ct, tt, ncls, maxM, maxT, meta = _tables(g, mode, B, src.device)
-    if CONV_IMPL == "pconv":
-        rc = _pconv(src.data_ptr(), wgt.data_ptr(), _p(bias), dst.data_ptr(), ct.data_ptr(), tt.data_ptr(), ncls,
-                    meta[6], B, Hs, Ws, Cs, Hd, Wd, Nd, Nw, ss[0], ss[1], sd[0], sd[1], g.KH * g.KW, ACT_CODE[act],
-                    alpha, meta[0], meta[1], meta[2], meta[3], meta[4], meta[5], PCONV_LDS, PCONV_MIN_ROWS, _stream())
-        if rc == 0:
-            _done()
-            return
-        if rc < 0:
-            raise ValueError(f"pconv rejected the problem (rc={rc}): {g} mode={mode} B={B}")
-        # rc == 1: the source patch does not fit in LDS -> global-gather implicit GEMM below
+_PLAN_CACHE: Dict[Tuple, Optional[dict]] = {}
+
+
+def _pick_pitch(Cs: int, stride: int) -> int:
+    """Smallest patch pixel pitch (bytes) whose ds_read_b128 lane groups are conflict-free for pixels
+    `stride` apart: (stride * pitch/16) % 4 == 2 (see pconv.hip)."""
+    p0 = Cs // 8
+    for p in range(p0, p0 + 4):
+        if (stride * p) % 4 == 2:
+            return p * 16
+    return (p0 | 1) * 16
+
+
+def _pconv_plan(g: ConvGeom, mode: str, B: int, Cs: int, Nd: int, ss, device, budget=None, img=None, fr=None,
+                min_rows=None):
+    """Unit decomposition + patch geometry + k-unit table for the patch-resident kernel, or None when
+    the problem does not fit the scheme (Dense, patch too big for LDS, too few rows per unit).
+    `budget` = LDS bytes per block (80 KiB -> two blocks per CU), `img` = images per unit (default:
+    as many as fit, capped), `fr` = 16-row fragments per wave (4 | 8)."""
+    budget = budget or PCONV_LDS or 80 * 1024
+    min_rows = PCONV_MIN_ROWS if min_rows is None else min_rows
+    key = (g, mode, B, Cs, Nd, str(device), budget, img, fr, min_rows)
+    if key in _PLAN_CACHE:
+        return _PLAN_CACHE[key]
+    plan = None
+    classes, taps = _class_taps(g, mode)
+    live = [t for c in classes for t in taps[c[5]:c[5] + c[4]]]
+    Hs, Ws = (g.H, g.W) if mode == "fprop" else (g.OH, g.OW)
+    if live and Hs * Ws > 1:
+        ssh, ssw = ss
+        omin_h, omax_h = min(t[0] for t in live), max(t[0] for t in live)
+        omin_w, omax_w = min(t[1] for t in live), max(t[1] for t in live)
+        maxHc, maxWc = max(c[2] for c in classes), max(c[3] for c in classes)
+        BN = 16 if Nd <= 16 else (32 if Nd <= 32 else (64 if Nd <= 64 else 128))
+        ntile = (Nd + BN - 1) // BN
+        pitch = _pick_pitch(Cs, ssw)
+        PW = (maxWc - 1) * ssw + (omax_w - omin_w) + 1
+        nst = [((c[4] * Cs + 63) // 64 + 1) // 2 * 2 for c in classes]       # even: the kernel works in stage pairs
+        total_stages = sum(nst)
+        fixed = _pconv_lds(BN, total_stages, 0)
+        rows_of = lambda br: (br - 1) * ssh + (omax_h - omin_h) + 1
+        img_full = rows_of(maxHc) * PW * pitch
+        IMG, BR = 0, maxHc
+        if img_full <= budget - fixed:
+            rows_per_img = maxHc * maxWc
+            n = min((budget - fixed) // img_full, B)
+            if img is not None:
+                IMG = min(img, n)
+            else:
+                n = min(n, -(-1024 // rows_per_img))
+                while n > 1 and -(-B // n) * ntile < 256:       # keep every CU busy
+                    n -= 1
+                best, best_eff = n, 0.0
+                for c in range(n, max((n + 1) // 2, 1) - 1, -1):
+                    rows = c * rows_per_img
+                    eff = rows / (-(-rows // 256) * 256)
+                    if eff > best_eff + 1e-9:
+                        best, best_eff = c, eff
+                IMG = best
+        elif img in (None, 1):
+            br = maxHc
+            while br > 1 and rows_of(br) * PW * pitch > budget - fixed:
+                br -= 1
+            if rows_of(br) * PW * pitch <= budget - fixed:
+                IMG, BR = 1, br
+        if IMG and IMG * min(BR, maxHc) * maxWc >= min_rows:
+            bands = -(-maxHc // BR)
+            PH = rows_of(BR)
+            rows_unit = IMG * BR * maxWc
+            FR = fr or PCONV_FR or (8 if (BN <= 32 and rows_unit >= 320) else 4)
+            if BN == 128:
+                FR = 4
+            ktab = np.zeros((total_stages * 8, 2), dtype=np.int32)
+            cdesc = np.zeros(len(classes), dtype=[("ph", "<i4"), ("pw", "<i4"), ("Hc", "<i4"), ("Wc", "<i4"),
+                                                  ("nst", "<i4"), ("soff", "<i4"), ("invWc", "<f4"), ("pad", "<f4")])
+            soff = 0
+            for ci_, c in enumerate(classes):
+                cdesc[ci_] = (c[0], c[1], c[2], c[3], nst[ci_], soff, 1.0 / c[3], 0.0)
+                for st in range(nst[ci_]):
+                    for u in range(8):
+                        k = st * 64 + u * 8
+                        tap, ch = divmod(k, Cs)
+                        row = (soff + st) * 8 + u
+                        if tap < c[4]:
+                            oh, ow, wt = taps[c[5] + tap]
+                            ktab[row] = (((oh - omin_h) * PW + (ow - omin_w)) * pitch + ch * 2, wt * Cs + ch)
+                        else:
+                            ktab[row] = (0, -1)
+                soff += nst[ci_]
+            if _pconv_lds(BN, total_stages, IMG * PH * PW * pitch) <= 160 * 1024:
+                plan = dict(classes=torch.from_numpy(cdesc.view(np.uint8).copy()).to(device),
+                            ktab=torch.from_numpy(ktab).to(device), ncls=len(classes), nst=total_stages,
+                            IMG=IMG, BR=BR, bands=bands, omin_h=omin_h, omin_w=omin_w, PH=PH, PW=PW, pitch=pitch,
+                            BN=BN, FR=FR, budget=budget)
+    _PLAN_CACHE[key] = plan
+    return plan
+
+
+def _pconv_candidates(g, mode, B, Cs, Nd, ss, device):
+    """Distinct plans worth timing: two LDS budgets (2 or 1 blocks per CU) x image counts x FR."""
+    out, seen = [], set()
+    for budget in (80 * 1024, 160 * 1024):
+        base = _pconv_plan(g, mode, B, Cs, Nd, ss, device, budget=budget, min_rows=64)
+        if base is None:
+            continue
+        imgs = {base["IMG"]}
+        if base["bands"] == 1:
+            imgs |= {max(1, base["IMG"] // 2), base["IMG"] * 2}
+        for im in sorted(imgs):
+            for fr in (4, 8):
+                pl = _pconv_plan(g, mode, B, Cs, Nd, ss, device, budget=budget, img=im, fr=fr, min_rows=64)
+                if pl is None:
+                    continue
+                sig = (pl["IMG"], pl["BR"], pl["FR"], pl["budget"] if pl["bands"] > 1 else 0)
+                if sig not in seen:
+                    seen.add(sig)
+                    out.append(pl)
+    return out
+
+
+_CONV_CHOICE: Dict[Tuple, object] = {}
+AUTOTUNE = os.environ.get("DDL_AUTOTUNE", "1") == "1"
+
+
+def _run_pconv(pl, src, wgt, bias, dst, g, B, Hs, Ws, Cs, Hd, Wd, Nd, Nw, ss, sd, act, alpha):
+    rc = _pconv(src.data_ptr(), wgt.data_ptr(), _p(bias), dst.data_ptr(), pl["classes"].data_ptr(),
+                pl["ktab"].data_ptr(), pl["ncls"], pl["nst"], B, Hs, Ws, Cs, Hd, Wd, Nd, Nw, ss[0], ss[1],
+                sd[0], sd[1], g.KH * g.KW, ACT_CODE[act], alpha, pl["IMG"], pl["BR"], pl["bands"],
+                pl["omin_h"], pl["omin_w"], pl["PH"], pl["PW"], pl["pitch"], pl["BN"], pl["FR"], _stream())
+    if rc != 0:
+        raise ValueError(f"pconv rejected its plan (rc={rc}): {g} B={B} "
+                         f"{ {k: v for k, v in pl.items() if k not in ('classes', 'ktab')} }")
+
+
+def _run_igemm(src, wgt, bias, dst, g, mode, B, Hs, Ws, Cs, Hd, Wd, Nd, Nw, ss, sd, act, alpha):
+    ct, tt, ncls, maxM, maxT = _tables(g, mode, B, src.device)
     rc = _igemm(src.data_ptr(), wgt.data_ptr(), _p(bias), dst.data_ptr(), ct.data_ptr(), tt.data_ptr(), ncls,
                 maxM, maxT, B, Hs, Ws, Cs, Hd, Wd, Nd, Nw, ss[0], ss[1], sd[0], sd[1], g.KH * g.KW,
                 ACT_CODE[act], alpha, IGEMM_TILE, _stream())
     if rc != 0:
         raise ValueError(f"igemm_conv rejected the problem (rc={rc}): {g} mode={mode} B={B}")
+
+
+def _time_us(fn, reps=3):
+    fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    best = float("inf")
+    for _ in range(reps):
+        e0.record()
+        fn()
+        e1.record()
+        e1.synchronize()
+        best = min(best, e0.elapsed_time(e1) * 1e3)
+    return best
+
+
+def _igemm_call(src, wgt, bias, dst, g, mode, B, Hs, Ws, Cs, Hd, Wd, Nd, Nw, ss, sd, act, alpha):
+    """Dispatch one class-grid convolution: the patch-resident kernel with a tuned plan, or the
+    global-gather kernel.  The first (non-captured) call of each problem times the candidates on the
+    real operands and caches the winner -- these shapes are static for a whole training run."""
+    args = (src, wgt, bias, dst, g)
+    tail = (B, Hs, Ws, Cs, Hd, Wd, Nd, Nw, ss, sd, act, alpha)
+    if CONV_IMPL != "pconv":
+        _run_igemm(src, wgt, bias, dst, g, mode, *tail)
+        _done()
+        return
+    slow = ACT_CODE[act] not in (0, 1, 6)
+    key = (g, mode, B, Cs, Nd, slow, str(src.device))
+    choice = _CONV_CHOICE.get(key)
+    if choice is None:
+        if AUTOTUNE and not torch.cuda.is_current_stream_capturing():
+            cands = [("igemm", None)] + [("pconv", pl) for pl in _pconv_candidates(g, mode, B, Cs, Nd, ss, src.device)]
+            timed = []
+            for kind, pl in cands:
+                fn = (lambda: _run_igemm(src, wgt, bias, dst, g, mode, *tail)) if kind == "igemm" else \
+                     (lambda pl=pl: _run_pconv(pl, src, wgt, bias, dst, g, *tail))
+                timed.append((_time_us(fn), kind, pl))
+            timed.sort(key=lambda t: t[0])
+            choice = (timed[0][1], timed[0][2])
+            if os.environ.get("DDL_AUTOTUNE_VERBOSE"):
+                desc = [(round(t, 1), k, None if p is None else (p["IMG"], p["BR"], p["FR"], p["budget"] // 1024))
+                        for t, k, p in timed]
+                print(f"[autotune] {mode} B={B} {g.H}x{g.W}x{g.I}->{g.OH}x{g.OW}x{g.O} k{g.KH} s{g.sh}: {desc}",
+                      flush=True)
+        else:
+            pl = _pconv_plan(g, mode, B, Cs, Nd, ss, src.device)
+            choice = ("pconv", pl) if pl is not None else ("igemm", None)
+        _CONV_CHOICE[key] = choice
+    if choice[0] == "pconv":
+        _run_pconv(choice[1], *args, *tail)
+    else:
+        _run_igemm(src, wgt, bias, dst, g, mode, *tail)
     _done()
 
 
