@@ -542,3 +542,135 @@ DDL_API void ddl_affine(const void* x, void* y, long rows, int C, int c_true, fl
     long n8 = rows * (C / 8);
     affine_kernel<<<ew_grid(n8), EW_BLOCK, 0, s>>>((const uint4*)x, (uint4*)y, n8, C / 8, c_true, scale, shift);
 }
+
+// ------------------------------------------------------------------------------ one-channel convs
+// A conv whose input (Conv2D 1->N) or output (Conv2DTranspose C->1) has a single channel wastes
+// 7/8 of an implicit GEMM on channel padding.  Instead the single-channel image is expanded to a
+// "taps as channels" tensor (im2col: [B][OH][OW][Tp], Tp = taps padded to 8), which turns the layer
+// into a 1x1 convolution on the MFMA kernels, and col2im folds a taps-as-channels tensor back into
+// a single-channel image (with the layer's bias + activation fused in).
+//   im2col : col[b][oh][ow][t] = img[b][oh*sh + kh*dh - pt][ow*sw + kw*dw - pl][0]      (0 outside / t >= T)
+//   col2im : img[b][h][w][0]   = act(bias + sum_t col[b][(h + pt - kh*dh)/sh][(w + pl - kw*dw)/sw][t])
+struct OneChGeom { int H, W, OH, OW, KH, KW, sh, sw, dh, dw, pt, pl, T, Tp, Ci; };
+
+__global__ void im2col_1ch_kernel(const bf16_t* __restrict__ img, uint4* __restrict__ col, long n_units,
+                                  const OneChGeom g) {
+    const int tg = g.Tp / 8;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n_units; i += (long)gridDim.x * blockDim.x) {
+        int t8 = (int)(i % tg);
+        long p = i / tg;
+        int ow = (int)(p % g.OW);
+        long q = p / g.OW;
+        int oh = (int)(q % g.OH);
+        long b = q / g.OH;
+        const bf16_t* base = img + b * g.H * g.W * g.Ci;
+        uint32_t w[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            int t = t8 * 8 + j;
+            uint32_t v = 0;
+            if (t < g.T) {
+                int kh = t / g.KW, kw = t - kh * g.KW;
+                int ih = oh * g.sh + kh * g.dh - g.pt, iw = ow * g.sw + kw * g.dw - g.pl;
+                if ((unsigned)ih < (unsigned)g.H && (unsigned)iw < (unsigned)g.W) v = base[((long)ih * g.W + iw) * g.Ci];
+            }
+            w[j >> 1] |= v << ((j & 1) * 16);
+        }
+        col[i] = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+}
+
+// One block per image: the image's whole taps-as-channels tile is staged into LDS with coalesced
+// 16-byte loads (it is read 25x, two bytes at a time, by the fold), then every thread folds pixels.
+// LDS rows are padded by 4 B so the 2-byte gathers of neighbouring pixels spread over the banks.
+__global__ __launch_bounds__(256) void col2im_1ch_kernel(const bf16_t* __restrict__ col, uint4* __restrict__ img,
+                                                         const OneChGeom g, const float* __restrict__ bias, int act,
+                                                         float alpha, int lds_tile) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int b = blockIdx.x;
+    const int npix_col = g.OH * g.OW, row_b = g.Tp * 2, pitch = row_b + 4;
+    const bf16_t* base = col + (long)b * npix_col * g.Tp;
+    if (lds_tile) {
+        const int u_per = g.Tp / 8;
+        for (int u = threadIdx.x; u < npix_col * u_per; u += 256) {
+            int p = u / u_per, c8 = u - p * u_per;
+            uint4 v = *(const uint4*)(base + (long)p * g.Tp + c8 * 8);
+            uint32_t* d = (uint32_t*)(smem + p * pitch + c8 * 16);
+            d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+        }
+        __syncthreads();
+    }
+    const float b0 = bias ? bias[0] : 0.f;
+    for (int i = threadIdx.x; i < g.H * g.W; i += 256) {
+        int h = i / g.W, w = i - h * g.W;
+        float acc = 0.f;
+        for (int kh = 0; kh < g.KH; ++kh) {
+            int th = h + g.pt - kh * g.dh;
+            if (th < 0 || th % g.sh) continue;
+            int oh = th / g.sh;
+            if (oh >= g.OH) continue;
+            for (int kw = 0; kw < g.KW; ++kw) {
+                int tw = w + g.pl - kw * g.dw;
+                if (tw < 0 || tw % g.sw) continue;
+                int ow = tw / g.sw;
+                if (ow >= g.OW) continue;
+                int p = oh * g.OW + ow, t = kh * g.KW + kw;
+                acc += lds_tile ? bf2f(*(const bf16_t*)(smem + p * pitch + t * 2)) : bf2f(base[(long)p * g.Tp + t]);
+            }
+        }
+        float v = act_apply(acc + b0, act, alpha);
+        img[(long)b * g.H * g.W + i] = make_uint4((uint32_t)f2bf(v), 0, 0, 0);     // channel 0 real, 7 lanes zero
+    }
+}
+
+DDL_API int ddl_im2col_1ch(const void* img, void* col, int B, int H, int W, int Ci, int OH, int OW, int KH, int KW,
+                           int sh, int sw, int dh, int dw, int pt, int pl, int Tp, hipStream_t s) {
+    if (Tp % 8 || Tp < KH * KW || Ci <= 0) return -1;
+    OneChGeom g{H, W, OH, OW, KH, KW, sh, sw, dh, dw, pt, pl, KH * KW, Tp, Ci};
+    long n = (long)B * OH * OW * (Tp / 8);
+    im2col_1ch_kernel<<<ew_grid(n), EW_BLOCK, 0, s>>>((const bf16_t*)img, (uint4*)col, n, g);
+    return 0;
+}
+
+// img is written as [B][H][W][8] (one real channel).
+DDL_API int ddl_col2im_1ch(const void* col, void* img, const float* bias, int B, int H, int W, int OH, int OW,
+                           int KH, int KW, int sh, int sw, int dh, int dw, int pt, int pl, int Tp, int act,
+                           float alpha, hipStream_t s) {
+    if (Tp % 8 || Tp < KH * KW) return -1;
+    OneChGeom g{H, W, OH, OW, KH, KW, sh, sw, dh, dw, pt, pl, KH * KW, Tp, 8};
+    size_t smem = (size_t)OH * OW * (Tp * 2 + 4);
+    int tile = smem <= 150 * 1024;
+    if (tile && smem > 64 * 1024) {
+        static bool done = false;
+        if (!done) {
+            hipFuncSetAttribute((const void*)col2im_1ch_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            done = true;
+        }
+    }
+    col2im_1ch_kernel<<<B, 256, tile ? smem : 0, s>>>((const bf16_t*)col, (uint4*)img, g, bias, act, alpha, tile);
+    return 0;
+}
+
+// Generic strided weight gather fp32 master -> bf16 [R2][C2] (zero where r >= R1 or c >= C1):
+// dst[r][c] = P[src_off + r*sr + c*sc].  One launch serves every descriptor (blockIdx.y).
+struct GatherDesc { long src_off; long dst_off; int R1, C1, R2, C2; long sr, sc; };
+
+__global__ void relayout_gather_kernel(const float* __restrict__ P, bf16_t* __restrict__ out,
+                                       const GatherDesc* __restrict__ descs) {
+    const GatherDesc d = descs[blockIdx.y];
+    const long total = (long)d.R2 * d.C2;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        int c = (int)(i % d.C2);
+        int r = (int)(i / d.C2);
+        float v = (r < d.R1 && c < d.C1) ? P[d.src_off + r * d.sr + c * d.sc] : 0.f;
+        out[d.dst_off + i] = f2bf(v);
+    }
+}
+
+DDL_API void ddl_relayout_gather(const float* P, void* out, const void* descs, int n, long max_elems,
+                                 hipStream_t s) {
+    if (n <= 0) return;
+    int gx = ew_grid(max_elems);
+    if (gx > 64) gx = 64;
+    relayout_gather_kernel<<<dim3(gx, n), EW_BLOCK, 0, s>>>(P, (bf16_t*)out, (const GatherDesc*)descs);
+}

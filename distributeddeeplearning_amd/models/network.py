@@ -20,6 +20,7 @@ Replaces what Keras' `Model`/`fit` machinery did for the reference (/root/refere
 from __future__ import annotations
 
 import math
+import os
 from typing import Dict, List, Optional, Tuple
 
 import numpy as np
@@ -29,6 +30,7 @@ from ..ops import functional as F
 from ..ops.geometry import ConvGeom, dense_geom
 from .ir import LayerSpec, ModelSpec
 
+ONECH = os.environ.get("DDL_ONECH", "1") == "1"      # single-channel conv fast path (device)
 ALIGN = 8      # every tensor starts at a multiple of 8 elements (16 B in bf16, 32 B in fp32)
 
 
@@ -81,6 +83,10 @@ class ConvOp(Op):
         self.gkernel = self.gbias = None          # fp32 gradient views
         self.w_main = self.w_alt = None           # compute-dtype views
         self.x = self.y = None
+        # single-channel fast path (device only): see ops/hip.py im2col_1ch / col2im_1ch
+        self.onech = None               # None | "in" (Conv2D 1->N) | "out" (Conv2DTranspose C->1)
+        self.g1 = None                  # the equivalent 1x1 geometry on the taps-as-channels tensor
+        self.w_tap = self.w_tapT = None
 
     def _p(self, c):
         return _round_up(c, self.cpad)
@@ -123,8 +129,44 @@ class ConvOp(Op):
         """Dense weights as a 1x1 conv kernel."""
         return w.reshape(w.shape[0], 1, 1, -1)
 
+    def _fwd_onech(self, x, training):
+        g, g1, hip = self.g, self.g1, F.hip_backend()
+        if self.onech == "in":          # im2col -> 1x1 conv with the layer's bias + activation
+            xc = hip.im2col_1ch(x, g)
+            y = hip.conv_fprop(xc, self.w_tap, self.bias, g1, self.act, self.alpha)
+            if training:
+                self.x, self.y = xc, y
+        else:                           # 1x1 conv to taps -> col2im fold with bias + activation
+            z = hip.conv_fprop(x, self.w_main.reshape(g1.O, 1, 1, -1), None, g1)
+            y = hip.col2im_1ch(z, g, self.bias, self.act, self.alpha)
+            if training:
+                self.x, self.y = x, y
+        return y
+
+    def _bwd_onech(self, dy, need_dx, need_dw):
+        g, g1, hip = self.g, self.g1, F.hip_backend()
+        T = g.KH * g.KW
+        dx = None
+        if self.onech == "in":
+            if need_dw:                 # dW[n][t] -> canonical [O][KH][KW][8] slot (n, t, channel 0)
+                hip.conv_wgrad(self.x, dy, g1, "A", out=self.gkernel,
+                               box=(g.O, T, T * 8, 0, 8, self.gkernel.numel()))
+                F.bias_grad(dy, out=self.gbias)
+            if need_dx:
+                dx = hip.col2im_1ch(hip.conv_dgrad(dy, self.w_tapT, g1), g)
+        else:
+            dyc = hip.im2col_1ch(dy, g)
+            if need_dw:
+                hip.conv_wgrad(self.x, dyc, g1, "A", out=self.gkernel)
+                F.bias_grad(dy, out=self.gbias)
+            if need_dx:
+                dx = hip.conv_dgrad(dyc, self.w_tapT, g1)
+        return dx
+
     def fwd(self, x, training):
         g = self.g
+        if self.onech:
+            return self._fwd_onech(x, training)
         if self.kind == "dense":
             B = x.shape[0]
             x4 = x.reshape(B, 1, 1, -1)
@@ -143,6 +185,8 @@ class ConvOp(Op):
             dy = F.act_bwd(dy, self.y, self.act, self.alpha)
         x = self.x
         dx = None
+        if self.onech:
+            return self._bwd_onech(dy, need_dx, need_dw)
         if self.kind == "dense":
             B = x.shape[0]
             dy4, x4 = dy.reshape(B, 1, 1, -1), x.reshape(B, 1, 1, -1)
@@ -401,6 +445,35 @@ class Network:
                 self._alt.append((op, alt_off))
                 alt_off = _round_up(alt_off + int(np.prod(op.alt_shape())), ALIGN)
         self.Palt = torch.zeros(max(alt_off, ALIGN), dtype=self.cdtype, device=dev) if self.on_gpu else None
+        # one-channel convs (device): taps-as-channels weight copies gathered from the master buffer
+        self._gather: List[Tuple] = []          # (src_off, dst_off, R1, C1, R2, C2, sr, sc)
+        self._gviews = {}
+        g_off = 0
+        if self.on_gpu and ONECH:
+            for op in self.ops:
+                if not isinstance(op, ConvOp) or op.g.depthwise or op.g.I != 1:
+                    continue
+                if op.kind not in ("conv2d", "conv2d_transpose"):
+                    continue
+                g = op.g
+                T, Tp = g.KH * g.KW, _round_up(g.KH * g.KW, 8)
+                koff = self._pmap[(op.name, "kernel")].offset
+                if op.kind == "conv2d":         # canonical [O][T][8]
+                    Op = _round_up(g.O, 8)
+                    op.onech = "in"
+                    op.g1 = ConvGeom(g.OH, g.OW, T, g.OH, g.OW, g.O, 1, 1).check()
+                    specs = [("w_tap", (g.O, 1, 1, Tp), (koff, g.O, T, g.O, Tp, T * 8, 8)),
+                             ("w_tapT", (T, 1, 1, Op), (koff, T, g.O, T, Op, 8, T * 8))]
+                else:                           # canonical [1][T][Cp]; 1x1 conv C -> T uses it as is
+                    Cc, Cp = g.O, _round_up(g.O, 8)
+                    op.onech = "out"
+                    op.g1 = ConvGeom(g.OH, g.OW, Cc, g.OH, g.OW, T, 1, 1).check()
+                    specs = [("w_tapT", (Cc, 1, 1, Tp), (koff, Cc, T, Cc, Tp, 1, Cp))]
+                for attr, shape, (so, R1, C1, R2, C2, sr, sc) in specs:
+                    self._gather.append((so, g_off, R1, C1, R2, C2, sr, sc))
+                    self._gviews[(id(op), attr)] = (g_off, shape)
+                    g_off = _round_up(g_off + R2 * C2, ALIGN)
+        self.Pg = torch.zeros(max(g_off, ALIGN), dtype=self.cdtype, device=dev) if self.on_gpu else None
         self._bind_views()
 
     def _view(self, buf, p: _Param):
@@ -426,6 +499,11 @@ class Network:
                     op.w_alt = self.Palt[o:o + int(np.prod(ashape))].view(ashape)
                 else:
                     op.w_alt = op.kernel.t() if op.kind == "dense" else op.kernel.permute(3, 1, 2, 0)
+                for attr in ("w_tap", "w_tapT"):
+                    hit = self._gviews.get((id(op), attr))
+                    if hit is not None:
+                        o, shape = hit
+                        setattr(op, attr, self.Pg[o:o + int(np.prod(shape))].view(shape))
             elif isinstance(op, BNOp):
                 pg, pb = self._pmap[(op.name, "gamma")], self._pmap[(op.name, "beta")]
                 op.gamma, op.beta = self._view(self.P, pg), self._view(self.P, pb)
@@ -468,6 +546,7 @@ class Network:
         if cast:
             hip.cast_f32_to_bf16(self.P, self.Pc)
         hip.relayout_alt(self)
+        hip.relayout_gather(self)
 
     # ------------------------------------------------------------------ execution
     def set_bn_mode(self, mode: str):

@@ -64,6 +64,10 @@ _argmax_match = _sig("ddl_argmax_match", None, vp, vp, ci, ci, vp, vp)
 _optim_step = _sig("ddl_optim_step", None, vp, vp, vp, vp, vp, vp, cl, ci, cf, cf, cf, cf, cf, cf, vp, cf, vp)
 _scale_emit = _sig("ddl_scale_emit", None, vp, vp, cl, cf, vp)
 _avg_delta = _sig("ddl_avg_delta", None, vp, vp, vp, vp, cl, cf, vp)
+_im2col = _sig("ddl_im2col_1ch", ci, vp, vp, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, vp)
+_col2im = _sig("ddl_col2im_1ch", ci, vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, cf, vp)
+_gather = _sig("ddl_relayout_gather", None, vp, vp, vp, ci, cl, vp)
+_gemm_sk = _sig("ddl_gemm_sk", ci, vp, vp, vp, vp, cl, ci, ci, ci, ci, cf, vp)
 _philox = _sig("ddl_philox_uniform", None, vp, cl, vp, cf, cf, vp)
 _igemm = _sig("ddl_igemm_conv", ci, vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci,
               ci, ci, ci, ci, cf, ci, vp)
@@ -279,6 +283,57 @@ def relayout_alt(net):
     if n:
         _relayout(net.P.data_ptr(), net.Palt.data_ptr(), dev.data_ptr(), n, mx, _stream())
         _done()
+
+
+def relayout_gather(net):
+    """Refresh the strided-gather weight copies (one-channel conv path) of `net` in one launch."""
+    if not net._gather:
+        return
+    tab = getattr(net, "_gather_tab", None)
+    if tab is None:
+        arr = np.zeros(len(net._gather), dtype=[("s", "<i8"), ("d", "<i8"), ("R1", "<i4"), ("C1", "<i4"),
+                                                ("R2", "<i4"), ("C2", "<i4"), ("sr", "<i8"), ("sc", "<i8")])
+        for i, d in enumerate(net._gather):
+            arr[i] = d
+        mx = max(d[4] * d[5] for d in net._gather)
+        tab = net._gather_tab = (torch.from_numpy(arr.view(np.uint8).copy()).to(net.device), len(net._gather), mx)
+    dev, n, mx = tab
+    _gather(net.P.data_ptr(), net.Pg.data_ptr(), dev.data_ptr(), n, mx, _stream())
+    _done()
+
+
+def im2col_1ch(img, g: ConvGeom):
+    """[B][g.H][g.W][Ci] (channel 0 is the image) -> taps-as-channels [B][g.OH][g.OW][pad8(KH*KW)]."""
+    _chk_act(img, "img")
+    B = img.shape[0]
+    if tuple(img.shape[1:3]) != (g.H, g.W):
+        raise ValueError(f"im2col_1ch: image {tuple(img.shape)} vs geometry {g}")
+    Tp = pad8(g.KH * g.KW)
+    col = torch.empty(B, g.OH, g.OW, Tp, dtype=torch.bfloat16, device=img.device)
+    rc = _im2col(img.data_ptr(), col.data_ptr(), B, g.H, g.W, img.shape[-1], g.OH, g.OW, g.KH, g.KW, g.sh, g.sw,
+                 g.dh, g.dw, g.pt, g.pl, Tp, _stream())
+    if rc:
+        raise ValueError("im2col_1ch rejected")
+    _done()
+    return col
+
+
+def col2im_1ch(col, g: ConvGeom, bias=None, act=None, alpha=0.3):
+    """taps-as-channels [B][g.OH][g.OW][pad8(T)] -> single-channel image [B][g.H][g.W][8] = act(bias + fold)."""
+    _chk_act(col, "col")
+    B = col.shape[0]
+    Tp = pad8(g.KH * g.KW)
+    if tuple(col.shape[1:]) != (g.OH, g.OW, Tp):
+        raise ValueError(f"col2im_1ch: col {tuple(col.shape)} vs geometry {g}")
+    if bias is not None:
+        _chk_f32(bias, 1, "bias")
+    img = torch.empty(B, g.H, g.W, 8, dtype=torch.bfloat16, device=col.device)
+    rc = _col2im(col.data_ptr(), img.data_ptr(), _p(bias), B, g.H, g.W, g.OH, g.OW, g.KH, g.KW, g.sh, g.sw, g.dh,
+                 g.dw, g.pt, g.pl, Tp, ACT_CODE[act], alpha, _stream())
+    if rc:
+        raise ValueError("col2im_1ch rejected")
+    _done()
+    return img
 
 
 def pad_channels(x, c_phys, index=None, scale=1.0, c_true=None):
@@ -694,6 +749,15 @@ def _chk_w(w, shape, name):
         raise ValueError(f"{name}: weight shape {tuple(w.shape)} != expected {tuple(shape)}")
 
 
+GEMM_SK = os.environ.get("DDL_GEMM_SK", "1") == "1"
+
+
+def _is_1x1(g: ConvGeom) -> bool:
+    """A 1x1 / stride-1 / unpadded correlation: a row-major GEMM over pixels (also Dense)."""
+    return (g.KH == g.KW == 1 and g.sh == g.sw == 1 and g.pt == g.pl == 0 and g.OH == g.H and g.OW == g.W
+            and not g.depthwise)
+
+
 def conv_fprop(x, wA, bias, g: ConvGeom, act=None, alpha=0.3):
     _chk_act(x, "x")
     B = x.shape[0]
@@ -714,6 +778,14 @@ def conv_fprop(x, wA, bias, g: ConvGeom, act=None, alpha=0.3):
     if wA.dim() != 4 or wA.shape[1:] != (g.KH, g.KW, Ip) or wA.shape[0] > Op:
         raise ValueError(f"conv_fprop: weight {tuple(wA.shape)} vs geometry {g}")
     _chk_w(wA, wA.shape, "kernel")
+    if _is_1x1(g) and GEMM_SK:
+        rc = _gemm_sk(x.data_ptr(), wA.data_ptr(), _p(bias), y.data_ptr(), B * g.H * g.W, Ip, Op,
+                      min(wA.shape[0], g.O), ACT_CODE[act], alpha, _stream())
+        if rc < 0:
+            raise ValueError(f"gemm_sk rejected the problem (rc={rc}): {g}")
+        if rc == 0:
+            _done()
+            return y
     _igemm_call(x, wA, bias, y, g, "fprop", B, g.H, g.W, Ip, g.OH, g.OW, Op, min(wA.shape[0], g.O),
                 (g.sh, g.sw), (1, 1), act, alpha)
     return y
@@ -741,12 +813,22 @@ def conv_dgrad(dy, wB, g: ConvGeom, bias=None, act=None, alpha=0.3):
     if wB.dim() != 4 or wB.shape[1:] != (g.KH, g.KW, Op) or wB.shape[0] > Ip:
         raise ValueError(f"conv_dgrad: weight {tuple(wB.shape)} vs geometry {g}")
     _chk_w(wB, wB.shape, "kernel")
+    if _is_1x1(g) and GEMM_SK:
+        rc = _gemm_sk(dy.data_ptr(), wB.data_ptr(), _p(bias), dx.data_ptr(), B * g.H * g.W, Op, Ip,
+                      min(wB.shape[0], g.I), ACT_CODE[act], alpha, _stream())
+        if rc < 0:
+            raise ValueError(f"gemm_sk rejected the problem (rc={rc}): {g}")
+        if rc == 0:
+            _done()
+            return dx
     _igemm_call(dy, wB, bias, dx, g, "dgrad", B, g.OH, g.OW, Op, g.H, g.W, Ip, min(wB.shape[0], g.I),
                 (1, 1), (g.sh, g.sw), act, alpha)
     return dx
 
 
-def conv_wgrad(x, dy, g: ConvGeom, layout="A", out=None):
+def conv_wgrad(x, dy, g: ConvGeom, layout="A", out=None, box=None):
+    """`box` = (n_lim, c_lim, sn, st, sc, numel): write dW[n][t][c] at out[n*sn + t*st + c*sc] instead of one of
+    the two standard layouts (the caller guarantees `out` has `numel` elements and is zero elsewhere)."""
     _chk_act(x, "x")
     _chk_act(dy, "dy")
     B = x.shape[0]
@@ -774,6 +856,10 @@ def conv_wgrad(x, dy, g: ConvGeom, layout="A", out=None):
         shape = (g.I, g.KH, g.KW, Op)
         n_lim, c_lim, sn, st, sc = Op, g.I, 1, Op, T * Op
     numel = int(np.prod(shape))
+    if box is not None:
+        n_lim, c_lim, sn, st, sc, numel = box
+        if out is None or n_lim > Op or c_lim > Ip:
+            raise ValueError("conv_wgrad: a custom box needs `out` and limits inside the operands")
     if out is None:
         out = torch.empty(shape, dtype=torch.float32, device=dev)
     if out.numel() != numel:
@@ -781,7 +867,10 @@ def conv_wgrad(x, dy, g: ConvGeom, layout="A", out=None):
     _chk_f32(out, numel, "dW")
     M = B * g.OH * g.OW
     ksplit = _wgrad_ksplit(M, T, n_lim, c_lim)
-    slab = torch.empty(ksplit * numel, dtype=torch.float32, device=dev) if ksplit > 1 else None
+    # with a custom box the slab reduce also sweeps elements the kernel never writes: they must read as 0
+    slab = None
+    if ksplit > 1:
+        slab = (torch.zeros if box is not None else torch.empty)(ksplit * numel, dtype=torch.float32, device=dev)
     rc = _wgrad(dy.data_ptr(), x.data_ptr(), out.data_ptr(), _p(slab), numel, ksplit, B, g.OH, g.OW, Op, g.H,
                 g.W, Ip, g.KH, g.KW, g.sh, g.sw, g.dh, g.dw, g.pt, g.pl, n_lim, c_lim, sn, st, sc, _stream())
     if rc:

@@ -40,6 +40,16 @@ def main():
     rows = load(path)
     if not rows:
         sys.exit("no kernel records found")
+    steps = None
+    if "--steady" in sys.argv:
+        # keep the last 40 % of the trace (by time): warm-up, autotuning and graph capture are over;
+        # normalise per training step (the fused optimizer kernel runs twice per GAN step / once per
+        # classifier network step)
+        t0, t1 = rows[0][1], rows[-1][2]
+        cut = t0 + 0.6 * (t1 - t0)
+        rows = [r for r in rows if r[1] >= cut]
+        per = 2 if "--gan" in sys.argv else 5
+        steps = max(1, sum(1 for r in rows if "optim_kernel" in r[0]) // per)
     agg = defaultdict(lambda: [0, 0, 10**18, 0])
     for n, s, e in rows:
         a = agg[short(n)]
@@ -47,11 +57,16 @@ def main():
         a[0] += 1; a[1] += d; a[2] = min(a[2], d); a[3] = max(a[3], d)
     tot = sum(a[1] for a in agg.values())
     span = rows[-1][2] - rows[0][1]
-    print(f"kernels: {len(rows)} dispatches, {tot/1e6:.3f} ms busy, {span/1e6:.3f} ms first-to-last span\n")
+    print(f"kernels: {len(rows)} dispatches, {tot/1e6:.3f} ms busy, {span/1e6:.3f} ms first-to-last span")
+    if steps:
+        print(f"steady-state window: {steps} training steps -> {tot/1e6/steps:.3f} ms of kernel time per step, "
+              f"{len(rows)/steps:.0f} dispatches per step")
+    print()
     print("| kernel | calls | total us | avg us | min us | max us | % |")
     print("|---|---:|---:|---:|---:|---:|---:|")
     for n, a in sorted(agg.items(), key=lambda kv: -kv[1][1]):
-        print(f"| `{n}` | {a[0]} | {a[1]/1e3:.1f} | {a[1]/a[0]/1e3:.2f} | {a[2]/1e3:.2f} | {a[3]/1e3:.2f} | {100*a[1]/tot:.1f} |")
+        extra = f" {a[1]/1e3/steps:.1f} us/step" if steps else ""
+        print(f"| `{n}` | {a[0]} | {a[1]/1e3:.1f} | {a[1]/a[0]/1e3:.2f} | {a[2]/1e3:.2f} | {a[3]/1e3:.2f} | {100*a[1]/tot:.1f}{extra} |")
 
 
 if __name__ == "__main__":
