@@ -73,15 +73,27 @@ __global__ __launch_bounds__(256, (BN * FR >= 512 ? 1 : 2)) void pconv_kernel(co
         const int row0 = i0 * a.ssh + a.omin_h, col0 = a.omin_w;
         const int per_img = a.PH * a.PW * cs8;
         const int total = a.IMG * per_img;
-        for (int u = tid; u < total; u += 256) {
-            int img = fdiv(u, a.inv_per_img), r = u - img * per_img;
-            int pix = fdiv(r, a.inv_cs8), c8 = r - pix * cs8;
-            int pr = fdiv(pix, a.inv_PW), pc = pix - pr * a.PW;
-            int sr = row0 + pr, sc = col0 + pc, b = b0 + img;
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if (b < a.B && (unsigned)sr < (unsigned)a.Hs && (unsigned)sc < (unsigned)a.Ws)
-                v = *(const uint4*)(a.src + (((long)b * a.Hs + sr) * a.Ws + sc) * Cs + c8 * 8);
-            *(uint4*)(sP + img * a.img_bytes + pix * a.pitch + c8 * 16) = v;
+        // eight independent 16-byte loads in flight per thread before the first LDS store
+        for (int base = tid; base < total; base += 256 * 8) {
+            uint4 v[8];
+            int dst[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                int u = base + k * 256;
+                bool in = u < total;
+                int uu = in ? u : 0;
+                int img = fdiv(uu, a.inv_per_img), r = uu - img * per_img;
+                int pix = fdiv(r, a.inv_cs8), c8 = r - pix * cs8;
+                int pr = fdiv(pix, a.inv_PW), pc = pix - pr * a.PW;
+                int sr = row0 + pr, sc = col0 + pc, b = b0 + img;
+                v[k] = make_uint4(0, 0, 0, 0);
+                if (in && b < a.B && (unsigned)sr < (unsigned)a.Hs && (unsigned)sc < (unsigned)a.Ws)
+                    v[k] = *(const uint4*)(a.src + (((long)b * a.Hs + sr) * a.Ws + sc) * Cs + c8 * 8);
+                dst[k] = in ? img * a.img_bytes + pix * a.pitch + c8 * 16 : -1;
+            }
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+                if (dst[k] >= 0) *(uint4*)(sP + dst[k]) = v[k];
         }
         int2* sKw = (int2*)(smem + a.k_off);
         for (int t = tid; t < a.total_stages * 8; t += 256) sKw[t] = a.ktab[t];

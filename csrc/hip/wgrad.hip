@@ -155,6 +155,45 @@ __global__ void slab_reduce_kernel(const float* __restrict__ slab, float* __rest
     }
 }
 
+// Many-slab variant (persistent wgrad2 workers: up to 256 slabs).  A block owns 32 float4 columns and
+// splits the slabs over 8 lanes per column (independent, coalesced 512-byte rows), then combines the
+// 8 lane sums through LDS in a fixed order -> deterministic, and ~8x more loads in flight than the
+// one-thread-per-element walk above.
+__global__ __launch_bounds__(256) void slab_reduce_wide_kernel(const float4* __restrict__ slab, float4* __restrict__ out,
+                                                               long n4, long stride4, int ksplit) {
+    __shared__ float4 red[8][33];
+    const int col = threadIdx.x & 31, kl = threadIdx.x >> 5;
+    const long i = (long)blockIdx.x * 32 + col;
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (i < n4) {
+        for (int k = kl; k < ksplit; k += 8) {
+            float4 v = slab[k * stride4 + i];
+            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        }
+    }
+    red[kl][col] = s;
+    __syncthreads();
+    if (kl == 0 && i < n4) {
+#pragma unroll
+        for (int q = 1; q < 8; ++q) {
+            float4 v = red[q][col];
+            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        }
+        out[i] = s;
+    }
+}
+
+DDL_API void ddl_slab_reduce(const float* slab, float* out, long n, long stride, int k, hipStream_t s) {
+    if (k >= 16 && n % 4 == 0 && stride % 4 == 0) {
+        long n4 = n / 4;
+        slab_reduce_wide_kernel<<<(int)((n4 + 31) / 32), 256, 0, s>>>((const float4*)slab, (float4*)out, n4,
+                                                                     stride / 4, k);
+        return;
+    }
+    long g = (n + 255) / 256;
+    slab_reduce_kernel<<<(int)(g > 2048 ? 2048 : g), 256, 0, s>>>(slab, out, n, stride, k);
+}
+
 template <int TN, int TC>
 static void launch_wgrad(const WgradArgs& a, int ksplit, int taps, int tiles, hipStream_t s) {
     constexpr int STAGE = (TN / 16 + TC / 16) * 1024, RED = TN * TC * 4;
@@ -204,10 +243,7 @@ DDL_API int ddl_conv_wgrad(const void* dy, const void* x, float* out, float* sla
     WG_CASE(64, 64) WG_CASE(64, 32) WG_CASE(64, 16) WG_CASE(32, 64) WG_CASE(32, 32) WG_CASE(32, 16)
     WG_CASE(16, 64) WG_CASE(16, 32) WG_CASE(16, 16)
 #undef WG_CASE
-    if (ksplit > 1) {
-        long g = (numel + 255) / 256;
-        slab_reduce_kernel<<<(int)(g > 2048 ? 2048 : g), 256, 0, s>>>(slab, out, numel, numel, ksplit);
-    }
+    if (ksplit > 1) ddl_slab_reduce(slab, out, numel, numel, ksplit, s);
     return 0;
 }
 

@@ -1,0 +1,278 @@
+// Patch-resident, persistent weight-gradient kernel (gfx950, MFMA 16x16x32 bf16 + ds_read_b64_tr_b16).
+//
+//   dW[n][t][c] = sum_{b,oh,ow} dY[b,oh,ow,n] * X[b, oh*sh + kh*dh - pt, ow*sw + kw*dw - pl, c]
+//
+// wgrad.hip gives every tap its own blocks, each re-reading its dY and X pixels from global memory:
+// taps x M x (N + C) x 2 bytes of L2 traffic (0.9 GB for one DCGAN layer at B = 1000), which is what
+// bounds it.  Here a block is a persistent worker over a range of *units* (IMG images or a row band
+// of one image).  Per unit it stages the dY tile and the X patch (zero halo) into LDS once; then
+// EVERY tap is computed out of LDS: wave w owns taps {gw, gw + G, ...} (gw = global wave index among
+// the G = 4 x tap-groups waves that share this unit), keeps their [TN x TC] accumulators in registers
+// for its whole life, and walks all 32-pixel slices of the unit -- the dY fragments of a slice are
+// read once and reused for all of the wave's taps.  Both operands are pixel-major (k-strided for an
+// MFMA fragment); ds_read_b64_tr_b16 transposes them on the LDS read, each lane pointing at its own
+// pixel, so the patch needs no re-layout (per-pixel patch offsets come from a small LDS table).
+// At the end each wave writes its taps once to a per-worker slab; slab_reduce (wgrad.hip) sums the
+// workers in a fixed order (deterministic).
+#include "common.h"
+
+struct Wg2Args {
+    const bf16_t* dy; const bf16_t* x; float* slab;
+    int B, OH, OW, Ny;        // dY [B][OH][OW][Ny]
+    int H, W, Cx;             // X  [B][H][W][Cx]
+    int KH, KW, sh, sw, dh, dw, pt, pl;
+    int n_lim, c_lim;
+    long sn, st, sc;          // output strides (elements)
+    long slab_stride;
+    int IMG, BR, bands, n_units;
+    int PH, PW, xpitch, ximg_bytes;   // X patch: rows/cols (with halo), bytes per pixel / per image
+    int ypitch;                        // dY tile bytes per pixel
+    int y_off, t_off, k_off;           // LDS offsets: dY tile, pixel table, tap-offset table (X patch at 0)
+    int Mmax;                          // pixels per full unit (IMG * BR * OW)
+    int tiles_c, ngroups;
+    float inv_xper_img, inv_cx8, inv_PW, inv_yrow, inv_OW, inv_rows;
+};
+
+__device__ __forceinline__ int fdiv2(int x, float inv) { return __float2int_rz(((float)x + 0.5f) * inv); }
+
+__device__ __forceinline__ s16x4 tr_read2(const char* p) {
+    return __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(p));
+}
+
+template <int TN, int TC, int TPW>
+__global__ __launch_bounds__(256, (TPW * (TN / 16) * (TC / 16) * 4 > 160 ? 1 : 2)) void wgrad2_kernel(const Wg2Args a) {
+    constexpr int SN = TN / 16, SC = TC / 16;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* sX = smem;
+    char* sY = smem + a.y_off;
+    int* sTbl = (int*)(smem + a.t_off);          // per unit pixel: X patch byte offset
+    int* sTap = (int*)(smem + a.k_off);          // per tap: patch byte offset
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int g = lane >> 4, li = lane & 15, tq = li >> 2, tp = li & 3;
+    const int T = a.KH * a.KW;
+    const int group = blockIdx.y;
+    const int nt = blockIdx.z / a.tiles_c, ct = blockIdx.z - nt * a.tiles_c;
+    const int n0 = nt * TN, c0 = ct * TC;
+    const int G = 4 * a.ngroups;                  // waves sharing a unit's taps
+    const int gw = group * 4 + wave;
+    int ntaps_w = 0;                               // taps gw, gw + G, ... < T
+    for (int t = gw; t < T; t += G) ++ntaps_w;
+
+    // ---- once per block: pixel -> patch offset table, tap offsets (omin = -pt, -pl)
+    for (int m = tid; m < a.Mmax; m += 256) {
+        int img = fdiv2(m, a.inv_rows), rem = m - img * (a.BR * a.OW);
+        int il = fdiv2(rem, a.inv_OW), jl = rem - il * a.OW;
+        sTbl[m] = img * a.ximg_bytes + (il * a.sh * a.PW + jl * a.sw) * a.xpitch;
+    }
+    for (int t = tid; t < T; t += 256) {
+        int kh = t / a.KW, kw = t - kh * a.KW;
+        sTap[t] = (kh * a.dh * a.PW + kw * a.dw) * a.xpitch;
+    }
+
+    f32x4 acc[TPW][SN][SC];
+#pragma unroll
+    for (int q = 0; q < TPW; ++q)
+#pragma unroll
+        for (int i = 0; i < SN; ++i)
+#pragma unroll
+            for (int j = 0; j < SC; ++j) acc[q][i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int cx8 = a.Cx >> 3, ny8 = a.Ny >> 3;
+    // this wave's tap offsets into the patch (taps it does not own alias tap 0: read, never accumulated)
+    int toff[TPW];
+#pragma unroll
+    for (int q = 0; q < TPW; ++q) {
+        int t = gw + q * G;
+        int tt = t < T ? t : 0;
+        int kh = tt / a.KW, kw = tt - kh * a.KW;
+        toff[q] = (kh * a.dh * a.PW + kw * a.dw) * a.xpitch + (c0 + 4 * tp) * 2;
+    }
+    const int chan_y = (n0 + 4 * tp) * 2;
+
+    for (int unit = blockIdx.x; unit < a.n_units; unit += gridDim.x) {
+        const int grp = unit / a.bands, band = unit - grp * a.bands;
+        const int b0 = grp * a.IMG, i0 = band * a.BR;
+        const int nrow = min(a.BR, a.OH - i0);
+        __syncthreads();                          // previous unit fully consumed (also orders the tables)
+        // ---- stage X patch (zero halo / missing images) ...
+        {
+            const int row0 = i0 * a.sh - a.pt, col0 = -a.pl;
+            const int per_img = a.PH * a.PW * cx8;
+            // eight independent 16-byte loads in flight per thread before the first LDS store
+            for (int base = tid; base < a.IMG * per_img; base += 256 * 8) {
+                uint4 v[8];
+                int dst[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    int u = base + k * 256;
+                    bool in = u < a.IMG * per_img;
+                    int uu = in ? u : 0;
+                    int img = fdiv2(uu, a.inv_xper_img), r = uu - img * per_img;
+                    int pix = fdiv2(r, a.inv_cx8), c8 = r - pix * cx8;
+                    int pr = fdiv2(pix, a.inv_PW), pc = pix - pr * a.PW;
+                    int sr = row0 + pr, sc = col0 + pc, b = b0 + img;
+                    v[k] = make_uint4(0, 0, 0, 0);
+                    if (in && b < a.B && (unsigned)sr < (unsigned)a.H && (unsigned)sc < (unsigned)a.W)
+                        v[k] = *(const uint4*)(a.x + (((long)b * a.H + sr) * a.W + sc) * a.Cx + c8 * 8);
+                    dst[k] = in ? img * a.ximg_bytes + pix * a.xpitch + c8 * 16 : -1;
+                }
+#pragma unroll
+                for (int k = 0; k < 8; ++k)
+                    if (dst[k] >= 0) *(uint4*)(sX + dst[k]) = v[k];
+            }
+            // ... and the dY tile: pixel m = (img, il, jl) of the band; rows past the band / batch are zero
+            const int per_row = a.BR * a.OW * ny8;
+            const int mpad = (a.Mmax + 31) / 32 * 32;
+            for (int base = tid; base < mpad * ny8; base += 256 * 8) {
+                uint4 v[8];
+                int dst[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    int u = base + k * 256;
+                    bool in = u < mpad * ny8;
+                    int uu = in ? u : 0;
+                    int m = fdiv2(uu, a.inv_yrow), c8 = uu - m * ny8;
+                    int img = fdiv2(m, a.inv_rows), rem = m - img * (a.BR * a.OW);
+                    int il = fdiv2(rem, a.inv_OW), jl = rem - il * a.OW;
+                    int b = b0 + img;
+                    v[k] = make_uint4(0, 0, 0, 0);
+                    if (in && m < a.Mmax && b < a.B && il < nrow)
+                        v[k] = *(const uint4*)(a.dy + (((long)b * a.OH + i0 + il) * a.OW + jl) * a.Ny + c8 * 8);
+                    dst[k] = in ? m * a.ypitch + c8 * 16 : -1;
+                }
+#pragma unroll
+                for (int k = 0; k < 8; ++k)
+                    if (dst[k] >= 0) *(uint4*)(sY + dst[k]) = v[k];
+            }
+            (void)per_row;
+        }
+        __syncthreads();
+
+        // ---- every wave walks all 32-pixel slices; its taps' accumulators stay in registers.  All of a
+        // slice's fragments are fetched first (one burst of transposing LDS reads), then the MFMAs run.
+        for (int m0 = 0; m0 < a.Mmax; m0 += 32) {
+            const int plo = m0 + 4 * g + tq, phi = plo + 16;
+            const int xlo = sTbl[plo < a.Mmax ? plo : 0], xhi = sTbl[phi < a.Mmax ? phi : 0];
+            bf16x8_t fy[SN], fx[TPW][SC];
+#pragma unroll
+            for (int i = 0; i < SN; ++i) {
+                s16x4 lo = tr_read2(sY + plo * a.ypitch + chan_y + i * 32);
+                s16x4 hi = tr_read2(sY + phi * a.ypitch + chan_y + i * 32);
+                s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                fy[i] = __builtin_bit_cast(bf16x8_t, v);
+            }
+#pragma unroll
+            for (int q = 0; q < TPW; ++q)
+#pragma unroll
+                for (int j = 0; j < SC; ++j) {
+                    s16x4 lo = tr_read2(sX + xlo + toff[q] + j * 32);
+                    s16x4 hi = tr_read2(sX + xhi + toff[q] + j * 32);
+                    s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                    fx[q][j] = __builtin_bit_cast(bf16x8_t, v);
+                }
+#pragma unroll
+            for (int q = 0; q < TPW; ++q)
+                if (q < ntaps_w) {                 // wave-uniform
+#pragma unroll
+                    for (int i = 0; i < SN; ++i)
+#pragma unroll
+                        for (int j = 0; j < SC; ++j)
+                            acc[q][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fy[i], fx[q][j], acc[q][i][j], 0, 0, 0);
+                }
+        }
+    }
+
+    // ---- one slab write per wave tap: lane holds rows 16i + 4g + e, column 16j + li of the tile
+    float* out = a.slab + (long)blockIdx.x * a.slab_stride;
+#pragma unroll
+    for (int q = 0; q < TPW; ++q) {
+        if (q < ntaps_w) {
+            const int tap = gw + q * G;
+#pragma unroll
+            for (int i = 0; i < SN; ++i)
+#pragma unroll
+                for (int j = 0; j < SC; ++j) {
+                    const int nb = n0 + 16 * i + 4 * g, c = c0 + 16 * j + li;
+                    if (a.sn == 1 && nb + 3 < a.n_lim) {          // n-contiguous layout: one 16-byte store
+                        if (c < a.c_lim)
+                            *(float4*)(out + nb + tap * a.st + c * a.sc) =
+                                make_float4(acc[q][i][j][0], acc[q][i][j][1], acc[q][i][j][2], acc[q][i][j][3]);
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            if (nb + e < a.n_lim && c < a.c_lim)
+                                out[(nb + e) * a.sn + tap * a.st + c * a.sc] = acc[q][i][j][e];
+                    }
+                }
+        }
+    }
+}
+
+template <int TN, int TC, int TPW>
+static int launch_wg2(const Wg2Args& a, int nsplit, int tiles, size_t smem, hipStream_t s) {
+    if (smem > 64 * 1024) {
+        static bool done = false;
+        if (!done) {
+            hipFuncSetAttribute((const void*)wgrad2_kernel<TN, TC, TPW>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                160 * 1024);
+            done = true;
+        }
+    }
+    wgrad2_kernel<TN, TC, TPW><<<dim3(nsplit, a.ngroups, tiles), 256, smem, s>>>(a);
+    return 0;
+}
+
+DDL_API int ddl_wgrad2_lds(int IMG, int BR, int OW, int Ny, int PH, int PW, int xpitch, int ypitch, int taps) {
+    long x = (long)IMG * PH * PW * xpitch;
+    long mpad = ((long)IMG * BR * OW + 31) / 32 * 32;
+    long tot = (x + 15) / 16 * 16 + mpad * ypitch + (long)IMG * BR * OW * 4 + 16 + (long)taps * 4 + 16;
+    return tot > (1L << 30) ? -1 : (int)tot;
+}
+
+// The caller (ops/hip.py: _wgrad2_plan) chooses the unit decomposition, tile and split; slab holds
+// nsplit * numel floats.  The slab reduce into `out` is launched by the caller's existing path.
+DDL_API int ddl_conv_wgrad2(const void* dy, const void* x, float* slab, long numel, int nsplit, int B, int OH,
+                            int OW, int Ny, int H, int W, int Cx, int KH, int KW, int sh, int sw, int dh, int dw,
+                            int pt, int pl, int n_lim, int c_lim, long sn, long st, long sc, int IMG, int BR,
+                            int xpitch, int ypitch, int TN, int TC, int TPW, int ngroups, hipStream_t s) {
+    if (Ny % 8 || Cx % 8 || nsplit < 1 || IMG < 1 || BR < 1 || ngroups < 1) return -1;
+    if ((long)B * OH * OW * Ny >= (1L << 31) || (long)B * H * W * Cx >= (1L << 31)) return -3;
+    Wg2Args a;
+    a.dy = (const bf16_t*)dy; a.x = (const bf16_t*)x; a.slab = slab;
+    a.B = B; a.OH = OH; a.OW = OW; a.Ny = Ny; a.H = H; a.W = W; a.Cx = Cx;
+    a.KH = KH; a.KW = KW; a.sh = sh; a.sw = sw; a.dh = dh; a.dw = dw; a.pt = pt; a.pl = pl;
+    a.n_lim = n_lim; a.c_lim = c_lim; a.sn = sn; a.st = st; a.sc = sc; a.slab_stride = numel;
+    a.IMG = IMG; a.BR = BR; a.bands = (OH + BR - 1) / BR;
+    a.n_units = ((B + IMG - 1) / IMG) * a.bands;
+    a.PH = (BR - 1) * sh + (KH - 1) * dh + 1;
+    a.PW = (OW - 1) * sw + (KW - 1) * dw + 1;
+    a.xpitch = xpitch; a.ypitch = ypitch; a.ximg_bytes = a.PH * a.PW * xpitch;
+    a.Mmax = IMG * BR * OW;
+    if (xpitch % 16 || ypitch % 16 || xpitch < Cx * 2 || ypitch < Ny * 2) return -1;
+    if ((long)IMG * a.PH * a.PW * (Cx / 8) >= (1L << 22) || (long)(a.Mmax + 32) * (Ny / 8) >= (1L << 22)) return -2;
+    long xbytes = ((long)IMG * a.ximg_bytes + 15) / 16 * 16;
+    long mpad = (a.Mmax + 31) / 32 * 32;
+    a.y_off = (int)xbytes;
+    a.t_off = (int)(xbytes + mpad * ypitch);
+    a.k_off = a.t_off + ((a.Mmax * 4 + 15) / 16 * 16);
+    size_t smem = (size_t)a.k_off + (size_t)(KH * KW * 4 + 15) / 16 * 16;
+    if (smem > 160 * 1024) return -2;
+    int tiles_n = (n_lim + TN - 1) / TN;
+    a.tiles_c = (c_lim + TC - 1) / TC;
+    a.ngroups = ngroups;
+    if (4 * ngroups * TPW < KH * KW) return -4;           // not every tap would be owned by a wave
+    a.inv_xper_img = 1.0f / (float)(a.PH * a.PW * (Cx / 8));
+    a.inv_cx8 = 1.0f / (float)(Cx / 8);
+    a.inv_PW = 1.0f / (float)a.PW;
+    a.inv_yrow = 1.0f / (float)(Ny / 8);
+    a.inv_OW = 1.0f / (float)OW;
+    a.inv_rows = 1.0f / (float)(BR * OW);
+    int tiles = tiles_n * a.tiles_c;
+#define W2_CASE(TN_, TC_, TPW_) if (TN == TN_ && TC == TC_ && TPW == TPW_) return launch_wg2<TN_, TC_, TPW_>(a, nsplit, tiles, smem, s);
+    W2_CASE(64, 64, 3) W2_CASE(64, 64, 2) W2_CASE(64, 32, 7) W2_CASE(64, 32, 4) W2_CASE(32, 64, 7) W2_CASE(32, 64, 4)
+    W2_CASE(32, 32, 7) W2_CASE(32, 32, 4) W2_CASE(64, 16, 7) W2_CASE(16, 64, 7) W2_CASE(32, 16, 7) W2_CASE(16, 32, 7)
+    W2_CASE(16, 16, 7)
+#undef W2_CASE
+    return -4;
+}

@@ -77,6 +77,10 @@ _pconv_lds = _sig("ddl_pconv_lds_bytes", ci, ci, ci, cl)
 _wgrad_ksplit = _sig("ddl_wgrad_ksplit", ci, ci, ci, ci, ci)
 _wgrad = _sig("ddl_conv_wgrad", ci, vp, vp, vp, vp, cl, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci,
               ci, ci, ci, ci, cl, cl, cl, vp)
+_wgrad2 = _sig("ddl_conv_wgrad2", ci, vp, vp, vp, cl, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci,
+               cl, cl, cl, ci, ci, ci, ci, ci, ci, ci, ci, vp)
+_wgrad2_lds = _sig("ddl_wgrad2_lds", ci, ci, ci, ci, ci, ci, ci, ci, ci, ci)
+_slab_reduce = _sig("ddl_slab_reduce", None, vp, vp, cl, cl, ci, vp)
 _dw_blocks = _sig("ddl_dw_wgrad_blocks", ci, cl, ci)
 _depthwise = _sig("ddl_depthwise", ci, ci, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci,
                   ci, ci, ci, ci, cf, vp)
@@ -826,6 +830,58 @@ def conv_dgrad(dy, wB, g: ConvGeom, bias=None, act=None, alpha=0.3):
     return dx
 
 
+WGRAD_IMPL = os.environ.get("DDL_WGRAD", "wgrad2")          # wgrad2 (patch-resident, persistent) | wgrad
+_W2_COMBOS = {(64, 64): (2, 3), (64, 32): (4, 7), (32, 64): (4, 7), (32, 32): (4, 7), (64, 16): (7,), (16, 64): (7,),
+              (32, 16): (7,), (16, 32): (7,), (16, 16): (7,)}
+_W2_PLANS: Dict[Tuple, Optional[dict]] = {}
+
+
+def _tr_pitch(nbytes: int) -> int:
+    """Pixel pitch for ds_read_b64_tr_b16 operands: an odd multiple of 32 B >= nbytes, so the 8 pixel
+    rows a half-wave reads fall in 8 distinct 32-byte bank groups."""
+    p = (nbytes + 31) // 32
+    return (p if p % 2 else p + 1) * 32
+
+
+def _wgrad2_plan(g: ConvGeom, B: int, Cx: int, Ny: int, n_lim: int, c_lim: int):
+    key = (g, B, Cx, Ny, n_lim, c_lim)
+    if key in _W2_PLANS:
+        return _W2_PLANS[key]
+    plan = None
+    T = g.KH * g.KW
+    if T >= 4 and not g.depthwise:
+        tn = 64 if n_lim > 32 else (32 if n_lim > 16 else 16)
+        tc = 64 if c_lim > 32 else (32 if c_lim > 16 else 16)
+        opts = _W2_COMBOS[(tn, tc)]
+        ngroups = -(-T // (4 * max(opts)))
+        need = -(-T // (4 * ngroups))
+        TPW = min(o for o in opts if o >= need)
+        tiles = -(-n_lim // tn) * -(-c_lim // tc)
+        one_block = TPW * (tn // 16) * (tc // 16) * 4 > 160
+        budget = (150 if one_block else 76) * 1024
+        xp, yp = _tr_pitch(Cx * 2), _tr_pitch(Ny * 2)
+        PW = (g.OW - 1) * g.sw + (g.KW - 1) * g.dw + 1
+        lds = lambda img, br: _wgrad2_lds(img, br, g.OW, Ny, (br - 1) * g.sh + (g.KH - 1) * g.dh + 1, PW, xp, yp, T)
+        IMG, BR = 0, g.OH
+        if lds(1, g.OH) <= budget:
+            IMG = 1
+            while IMG < B and IMG * g.OH * g.OW < 512 and lds(IMG + 1, g.OH) <= budget:
+                IMG += 1
+        else:
+            br = g.OH
+            while br > 1 and lds(1, br) > budget:
+                br -= 1
+            if lds(1, br) <= budget:
+                IMG, BR = 1, br
+        if IMG:
+            n_units = -(-B // IMG) * -(-g.OH // BR)
+            target = 256 * (1 if one_block else 2)
+            nsplit = max(1, min(n_units, target // (ngroups * tiles)))
+            plan = dict(IMG=IMG, BR=BR, xp=xp, yp=yp, TN=tn, TC=tc, TPW=TPW, ngroups=ngroups, nsplit=nsplit)
+    _W2_PLANS[key] = plan
+    return plan
+
+
 def conv_wgrad(x, dy, g: ConvGeom, layout="A", out=None, box=None):
     """`box` = (n_lim, c_lim, sn, st, sc, numel): write dW[n][t][c] at out[n*sn + t*st + c*sc] instead of one of
     the two standard layouts (the caller guarantees `out` has `numel` elements and is zero elsewhere)."""
@@ -865,6 +921,45 @@ def conv_wgrad(x, dy, g: ConvGeom, layout="A", out=None, box=None):
     if out.numel() != numel:
         raise ValueError(f"conv_wgrad: out has {out.numel()} elements, expected {numel} for layout {layout}")
     _chk_f32(out, numel, "dW")
+    pl = _wgrad2_plan(g, B, Ip, Op, n_lim, c_lim) if WGRAD_IMPL == "wgrad2" else None
+
+    def run_w2():
+        ns = pl["nsplit"]
+        slab = (torch.zeros if box is not None else torch.empty)(ns * numel, dtype=torch.float32, device=dev)
+        rc = _wgrad2(dy.data_ptr(), x.data_ptr(), slab.data_ptr(), numel, ns, B, g.OH, g.OW, Op, g.H, g.W, Ip,
+                     g.KH, g.KW, g.sh, g.sw, g.dh, g.dw, g.pt, g.pl, n_lim, c_lim, sn, st, sc, pl["IMG"], pl["BR"],
+                     pl["xp"], pl["yp"], pl["TN"], pl["TC"], pl["TPW"], pl["ngroups"], _stream())
+        if rc:
+            raise ValueError(f"conv_wgrad2 rejected its plan (rc={rc}): {g} {pl}")
+        _slab_reduce(slab.data_ptr(), out.data_ptr(), numel, numel, ns, _stream())
+
+    def run_w1():
+        M = B * g.OH * g.OW
+        ksplit = _wgrad_ksplit(M, T, n_lim, c_lim)
+        slab = None
+        if ksplit > 1:
+            slab = (torch.zeros if box is not None else torch.empty)(ksplit * numel, dtype=torch.float32, device=dev)
+        rc = _wgrad(dy.data_ptr(), x.data_ptr(), out.data_ptr(), _p(slab), numel, ksplit, B, g.OH, g.OW, Op, g.H,
+                    g.W, Ip, g.KH, g.KW, g.sh, g.sw, g.dh, g.dw, g.pt, g.pl, n_lim, c_lim, sn, st, sc, _stream())
+        if rc:
+            raise ValueError(f"conv_wgrad rejected the problem (rc={rc}): {g}")
+
+    if pl is not None:
+        key = ("wgrad", g, B, Ip, Op, n_lim, c_lim, sn, st, sc)
+        choice = _CONV_CHOICE.get(key)
+        if choice is None:
+            if AUTOTUNE and not torch.cuda.is_current_stream_capturing():
+                t2, t1 = _time_us(run_w2), _time_us(run_w1)
+                choice = "w2" if t2 <= t1 else "w1"
+                if os.environ.get("DDL_AUTOTUNE_VERBOSE"):
+                    print(f"[autotune] wgrad B={B} {g.H}x{g.W}x{g.I}->{g.OH}x{g.OW}x{g.O}: wgrad2 {t2:.1f} us, "
+                          f"wgrad {t1:.1f} us", flush=True)
+            else:
+                choice = "w2"
+            _CONV_CHOICE[key] = choice
+        (run_w2 if choice == "w2" else run_w1)()
+        _done()
+        return out
     M = B * g.OH * g.OW
     ksplit = _wgrad_ksplit(M, T, n_lim, c_lim)
     # with a custom box the slab reduce also sweeps elements the kernel never writes: they must read as 0
