@@ -79,6 +79,7 @@ class ConvOp(Op):
         self.cpad = cpad
         self.kstruct = kstruct          # Dense fed by Flatten of (H, W, C): K is structured
         self.act_bwd_fused = False      # a following BN op applies act'(y) for us
+        self.next_bn = None             # BN op fed directly by this layer (if any)
         self.kernel = self.bias = None            # fp32 master views
         self.gkernel = self.gbias = None          # fp32 gradient views
         self.w_main = self.w_alt = None           # compute-dtype views
@@ -129,6 +130,15 @@ class ConvOp(Op):
         """Dense weights as a 1x1 conv kernel."""
         return w.reshape(w.shape[0], 1, 1, -1)
 
+    def _bias_grad(self, dy):
+        """Column sum of dY -- except straight in front of a batch-statistics BatchNorm, where the
+        bias gradient is identically zero (BN subtracts the batch mean): no reduction pass at all."""
+        bn = self.next_bn
+        if bn is not None and bn.used_batch_stats and self.act in (None, "linear"):
+            self.gbias.zero_()
+            return
+        F.bias_grad(dy, out=self.gbias)
+
     def _fwd_onech(self, x, training):
         g, g1, hip = self.g, self.g1, F.hip_backend()
         if self.onech == "in":          # im2col -> 1x1 conv with the layer's bias + activation
@@ -151,14 +161,14 @@ class ConvOp(Op):
             if need_dw:                 # dW[n][t] -> canonical [O][KH][KW][8] slot (n, t, channel 0)
                 hip.conv_wgrad(self.x, dy, g1, "A", out=self.gkernel,
                                box=(g.O, T, T * 8, 0, 8, self.gkernel.numel()))
-                F.bias_grad(dy, out=self.gbias)
+                self._bias_grad(dy)
             if need_dx:
                 dx = hip.col2im_1ch(hip.conv_dgrad(dy, self.w_tapT, g1), g)
         else:
             dyc = hip.im2col_1ch(dy, g)
             if need_dw:
                 hip.conv_wgrad(self.x, dyc, g1, "A", out=self.gkernel)
-                F.bias_grad(dy, out=self.gbias)
+                self._bias_grad(dy)
             if need_dx:
                 dx = hip.conv_dgrad(dyc, self.w_tapT, g1)
         return dx
@@ -192,20 +202,20 @@ class ConvOp(Op):
             dy4, x4 = dy.reshape(B, 1, 1, -1), x.reshape(B, 1, 1, -1)
             if need_dw:
                 F.conv_wgrad(x4, dy4, g, "A", out=self._w4(self.gkernel))
-                F.bias_grad(dy, out=self.gbias)
+                self._bias_grad(dy)
             if need_dx:
                 dx = F.conv_dgrad(dy4, self._w4(self.w_alt), g).reshape(x.shape)
         elif self.kind == "conv2d_transpose":
             # core X = our output (dy), core Y = our input (x)
             if need_dw:
                 F.conv_wgrad(dy, x, g, "B", out=self.gkernel)
-                F.bias_grad(dy, out=self.gbias)
+                self._bias_grad(dy)
             if need_dx:
                 dx = F.conv_fprop(dy, self.w_alt, None, g)
         else:
             if need_dw:
                 F.conv_wgrad(x, dy, g, "A", out=self.gkernel)
-                F.bias_grad(dy, out=self.gbias)
+                self._bias_grad(dy)
             if need_dx:
                 dx = F.conv_dgrad(dy, self.w_main if g.depthwise else self.w_alt, g)
         return dx
@@ -366,6 +376,8 @@ class Network:
                 op = BNOp(l, cur[-1], _round_up(cur[-1], self.cpad), len(cur) == 3)
                 op.mode = self.bn_mode
                 prev = self.ops[-1] if self.ops else None
+                if isinstance(prev, ConvOp):
+                    prev.next_bn = op
                 if isinstance(prev, ConvOp) and prev.act not in (None, "linear"):
                     op.prev_act, op.prev_alpha, prev.act_bwd_fused = prev.act, prev.alpha, True
                 if nxt is not None and nxt.kind == "leaky_relu":

@@ -684,11 +684,11 @@ def _run_pconv(pl, src, wgt, bias, dst, g, B, Hs, Ws, Cs, Hd, Wd, Nd, Nw, ss, sd
                          f"{ {k: v for k, v in pl.items() if k not in ('classes', 'ktab')} }")
 
 
-def _run_igemm(src, wgt, bias, dst, g, mode, B, Hs, Ws, Cs, Hd, Wd, Nd, Nw, ss, sd, act, alpha):
+def _run_igemm(src, wgt, bias, dst, g, mode, B, Hs, Ws, Cs, Hd, Wd, Nd, Nw, ss, sd, act, alpha, tile=None):
     ct, tt, ncls, maxM, maxT = _tables(g, mode, B, src.device)
     rc = _igemm(src.data_ptr(), wgt.data_ptr(), _p(bias), dst.data_ptr(), ct.data_ptr(), tt.data_ptr(), ncls,
                 maxM, maxT, B, Hs, Ws, Cs, Hd, Wd, Nd, Nw, ss[0], ss[1], sd[0], sd[1], g.KH * g.KW,
-                ACT_CODE[act], alpha, IGEMM_TILE, _stream())
+                ACT_CODE[act], alpha, IGEMM_TILE if tile is None else tile, _stream())
     if rc != 0:
         raise ValueError(f"igemm_conv rejected the problem (rc={rc}): {g} mode={mode} B={B}")
 
@@ -722,16 +722,18 @@ def _igemm_call(src, wgt, bias, dst, g, mode, B, Hs, Ws, Cs, Hd, Wd, Nd, Nw, ss,
     choice = _CONV_CHOICE.get(key)
     if choice is None:
         if AUTOTUNE and not torch.cuda.is_current_stream_capturing():
-            cands = [("igemm", None)] + [("pconv", pl) for pl in _pconv_candidates(g, mode, B, Cs, Nd, ss, src.device)]
+            tiles = [1] if Nd <= 16 else ([3] if Nd <= 32 else ([4, 5, 2] if Nd <= 64 else [6, 8]))
+            cands = [("igemm", t) for t in tiles] + \
+                    [("pconv", pl) for pl in _pconv_candidates(g, mode, B, Cs, Nd, ss, src.device)]
             timed = []
             for kind, pl in cands:
-                fn = (lambda: _run_igemm(src, wgt, bias, dst, g, mode, *tail)) if kind == "igemm" else \
+                fn = (lambda pl=pl: _run_igemm(src, wgt, bias, dst, g, mode, *tail, tile=pl)) if kind == "igemm" else \
                      (lambda pl=pl: _run_pconv(pl, src, wgt, bias, dst, g, *tail))
                 timed.append((_time_us(fn), kind, pl))
             timed.sort(key=lambda t: t[0])
             choice = (timed[0][1], timed[0][2])
             if os.environ.get("DDL_AUTOTUNE_VERBOSE"):
-                desc = [(round(t, 1), k, None if p is None else (p["IMG"], p["BR"], p["FR"], p["budget"] // 1024))
+                desc = [(round(t, 1), k, p if k == "igemm" else (p["IMG"], p["BR"], p["FR"], p["budget"] // 1024))
                         for t, k, p in timed]
                 print(f"[autotune] {mode} B={B} {g.H}x{g.W}x{g.I}->{g.OH}x{g.OW}x{g.O} k{g.KH} s{g.sh}: {desc}",
                       flush=True)
@@ -742,7 +744,7 @@ def _igemm_call(src, wgt, bias, dst, g, mode, B, Hs, Ws, Cs, Hd, Wd, Nd, Nw, ss,
     if choice[0] == "pconv":
         _run_pconv(choice[1], *args, *tail)
     else:
-        _run_igemm(src, wgt, bias, dst, g, mode, *tail)
+        _run_igemm(src, wgt, bias, dst, g, mode, *tail, tile=choice[1])
     _done()
 
 

@@ -43,7 +43,7 @@ def _directional_check(spec, x, loss_fn, bn_mode="batch", seed=0, eps=5e-3, tol=
         analytic = float((G0 * d).sum())
         fd = (L(P0 + eps * d) - L(P0 - eps * d)) / (2 * eps)
         scale = max(abs(fd), abs(analytic))
-        assert abs(fd - analytic) <= tol * scale + 2e-3 * float(G0.norm()), (p.layer, p.wname, fd, analytic)
+        assert abs(fd - analytic) <= tol * scale + 5e-3 * float(G0.norm()), (p.layer, p.wname, fd, analytic)
 
 
 def _ce(n_classes, B, seed=0):
