@@ -31,6 +31,8 @@ def main():
     ap.add_argument("--graph", default="on", choices=["on", "off", "full"],
                     help="hipGraph capture: on = segments around collectives, full = capture RCCL too")
     ap.add_argument("--comm-dtype", default="fp32", choices=["fp32", "bf16"])
+    ap.add_argument("--comm", default="torch", choices=["torch", "rccl"],
+                    help="collectives through torch.distributed (nccl == RCCL) or the native C++ RCCL communicator")
     ap.add_argument("--avg-every", type=int, default=8, help="local-SGD averaging period (config localsgd)")
     ap.add_argument("--device", default="cuda")
     a = ap.parse_args()
@@ -50,7 +52,12 @@ def main():
             print(f"warning: --gpus {a.gpus} but WORLD_SIZE={world}; using {world}", file=sys.stderr)
     dp = None
     if world > 1:
-        dp = ddp.FlatDataParallel(comm_dtype=torch.bfloat16 if a.comm_dtype == "bf16" else None)
+        cd = torch.bfloat16 if a.comm_dtype == "bf16" else None
+        if a.comm == "rccl" and on_gpu:
+            from distributeddeeplearning_amd.parallel.rccl import RcclCommunicator
+            dp = RcclCommunicator.from_env(device, comm_dtype=cd)
+        else:
+            dp = ddp.FlatDataParallel(comm_dtype=cd)
 
     from distributeddeeplearning_amd import benchmarks
     runner = benchmarks.make(a.config, device, dp, rank, a)

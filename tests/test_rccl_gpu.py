@@ -1,0 +1,56 @@
+"""Native RCCL communicator on the one GPU of the test box (world = 1: every collective is the
+identity, which still exercises bootstrap, dtype mapping, stream ordering and graph capture)."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def test_rccl_world1_collectives_and_graph_capture():
+    from distributeddeeplearning_amd.parallel.rccl import RcclCommunicator
+    comm = RcclCommunicator.from_env("cuda:0")
+    assert (comm.world, comm.rank) == (1, 0) and comm.healthy()
+    t = torch.arange(1024, dtype=torch.float32, device="cuda")
+    ref = t.clone()
+    comm.all_reduce_sum_(t)
+    comm.broadcast_(t)
+    assert torch.equal(t, ref)
+    b = torch.randn(64, device="cuda").bfloat16()
+    rb = b.clone()
+    comm.all_reduce_mean_(b)
+    assert torch.equal(b, rb)
+    assert torch.equal(comm.all_gather_scalars(t[:4]), ref[:4][None])
+    assert torch.equal(comm.reduce_scatter_sum(t), ref)
+    out = torch.empty_like(t)
+    comm.all_gather_flat(t, out)
+    assert torch.equal(out, ref)
+    comm.barrier()
+    # a collective between two kernels inside one hipGraph
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        t.mul_(1.0)
+        comm.all_reduce_sum_(t)
+    torch.cuda.current_stream().wait_stream(s)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        t.add_(1.0)
+        comm.all_reduce_sum_(t)
+        t.mul_(2.0)
+    g.replay()
+    g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(t, (ref + 1) * 2 * 2 + 2)          # ((x+1)*2 + 1)*2
+    comm.close()
+
+
+def test_rccl_bf16_wire_dtype():
+    from distributeddeeplearning_amd.parallel.rccl import RcclCommunicator
+    comm = RcclCommunicator.from_env("cuda:0", comm_dtype=torch.bfloat16)
+    t = torch.full((256,), 1.5, device="cuda")
+    comm.all_reduce_sum_(t)
+    assert torch.equal(t, torch.full((256,), 1.5, device="cuda"))
+    with pytest.raises(ValueError):
+        comm.all_reduce_sum_(torch.zeros(4))               # CPU tensors are rejected loudly
+    comm.close()
