@@ -139,14 +139,20 @@ class GANTrainer:
         self.d_loss = loss
         return loss
 
-    def g_backward(self, B):
+    def g_forward(self, B):
+        """Generator forward of the G phase (independent of D, so it can overlap D's all-reduce)."""
         z = self.rng.uniform((B, self.cfg.noise_dim), self.G.cdtype)
-        fake = self.G.forward(z, training=True)
+        self._fake = self.G.forward(z, training=True)
+        return self._fake
+
+    def g_backward(self, B, fake=None):
+        fake = self.g_forward(B) if fake is None else fake
         feat = self.D.forward(fake, training=True, stop=-1)
         loss, dfeat = self._d_head(feat, B, 1.0, 1.0, True, False)
         dfake = self.D.backward(dfeat, need_input_grad=True, need_dw=False, start=-1)
         self.G.backward(dfake, need_input_grad=False)
         self.g_loss = loss
+        self._fake = None
         return loss
 
     # ---- one reference iteration = train_discriminator() then train_generator() ------------
@@ -158,6 +164,14 @@ class GANTrainer:
         """D update, then G forward / D dgrad / G backward (local gradients in G.G)."""
         self.optD.step(self._gscale)
         return self.g_backward(B)
+
+    def phase_b1(self, B):
+        """The part of phase B that does not need the averaged D gradients: G's forward."""
+        return self.g_forward(B)
+
+    def phase_b2(self, B):
+        self.optD.step(self._gscale)
+        return self.g_backward(B, self._fake)
 
     def phase_c(self):
         self.optG.step(self._gscale)
@@ -230,7 +244,10 @@ class GraphedGANStep:
                 t.train_step(self.real, prepared=True)
             self.graphs = [g]
         else:
-            for fn in (lambda: t.phase_a(self.real), lambda: t.phase_b(self.B), t.phase_c):
+            # A | all-reduce(D grads) on the comm stream || B1 (G forward) | B2 | all-reduce(G grads) | C
+            self.comm_stream = torch.cuda.Stream()
+            for fn in (lambda: t.phase_a(self.real), lambda: t.phase_b1(self.B), lambda: t.phase_b2(self.B),
+                       t.phase_c):
                 g = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g, pool=pool):
                     fn()
@@ -241,9 +258,14 @@ class GraphedGANStep:
         if self.full:
             self.graphs[0].replay()
         else:
+            main = torch.cuda.current_stream()
             self.graphs[0].replay()
-            t.dp.all_reduce_sum_(t.D.G)
+            self.comm_stream.wait_stream(main)
+            with torch.cuda.stream(self.comm_stream):      # D's 1 MB all-reduce hides behind G's forward
+                t.dp.all_reduce_sum_(t.D.G)
             self.graphs[1].replay()
-            t.dp.all_reduce_sum_(t.G.G)
+            main.wait_stream(self.comm_stream)
             self.graphs[2].replay()
+            t.dp.all_reduce_sum_(t.G.G)
+            self.graphs[3].replay()
         return t.d_loss, t.g_loss

@@ -651,7 +651,7 @@ def _pconv_plan(g: ConvGeom, mode: str, B: int, Cs: int, Nd: int, ss, device, bu
 def _pconv_candidates(g, mode, B, Cs, Nd, ss, device):
     """Distinct plans worth timing: two LDS budgets (2 or 1 blocks per CU) x image counts x FR."""
     out, seen = [], set()
-    for budget in (80 * 1024, 160 * 1024):
+    for budget in (40 * 1024, 53 * 1024, 80 * 1024, 160 * 1024):      # 4 / 3 / 2 / 1 blocks per CU
         base = _pconv_plan(g, mode, B, Cs, Nd, ss, device, budget=budget, min_rows=64)
         if base is None:
             continue

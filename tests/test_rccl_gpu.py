@@ -54,3 +54,31 @@ def test_rccl_bf16_wire_dtype():
     with pytest.raises(ValueError):
         comm.all_reduce_sum_(torch.zeros(4))               # CPU tensors are rejected loudly
     comm.close()
+
+
+def test_graphed_dp_step_with_one_rank_group():
+    """The segmented-graph DP step (all-reduce of D grads overlapped with G's forward on a comm
+    stream) on a 1-rank RCCL group: same losses as the plain eager trainer."""
+    import os
+    import torch.distributed as dist
+    from distributeddeeplearning_amd.models.dcgan import GANConfig, GANTrainer, GraphedGANStep
+    from distributeddeeplearning_amd.parallel import ddp
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29677")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda:0"))
+    try:
+        dp = ddp.FlatDataParallel()
+        real = torch.rand(64, 28, 28, 1, generator=torch.Generator().manual_seed(0))
+        a = GANTrainer(GANConfig(batch=64, seed=5), "cuda:0", dp, 0)
+        b = GANTrainer(GANConfig(batch=64, seed=5), "cuda:0", None, 0)
+        rp = a.D.prepare_input(real)
+        step = GraphedGANStep(a, rp, warmup=2)
+        for _ in range(2):
+            b.train_step(rp, prepared=True)
+        for _ in range(3):
+            la = step.step()
+            lb = b.train_step(rp, prepared=True)
+        torch.cuda.synchronize()
+        assert abs(float(la[0]) - float(lb[0])) < 2e-2 * max(1.0, abs(float(lb[0])))
+        assert abs(float(la[1]) - float(lb[1])) < 2e-2 * max(1.0, abs(float(lb[1])))
+    finally:
+        dist.destroy_process_group()
