@@ -41,15 +41,19 @@ __device__ __forceinline__ uint4 pack8(const float* f) {
     return v;
 }
 
+// tanh(x) = 1 - 2 / (1 + e^{2x}); saturates cleanly for |x| large (e^{2x} -> 0 or inf)
+__device__ __forceinline__ float fast_tanh(float x) { return 1.f - 2.f * __frcp_rn(1.f + __expf(2.f * x)); }
+
 __device__ __forceinline__ float act_apply(float x, int kind, float alpha) {
     switch (kind) {
         case ACT_RELU: return fmaxf(x, 0.f);
-        case ACT_SIGMOID: return 1.f / (1.f + __expf(-x));
-        case ACT_SOFTPLUS: return x > 20.f ? x : log1pf(__expf(x));
-        case ACT_TANH: return tanhf(x);
-        case ACT_SOFTSIGN: return x / (1.f + fabsf(x));
+        // transcendental ones on the fast hardware exp/log/rcp (results are rounded to bf16 anyway)
+        case ACT_SIGMOID: return __frcp_rn(1.f + __expf(-x));
+        case ACT_SOFTPLUS: return x > 15.f ? x : __logf(1.f + __expf(x));
+        case ACT_TANH: return fast_tanh(x);
+        case ACT_SOFTSIGN: return x * __frcp_rn(1.f + fabsf(x));
         case ACT_LEAKY: return x > 0.f ? x : alpha * x;
-        case ACT_TANH01: return 0.5f * (tanhf(x) + 1.f);
+        case ACT_TANH01: return __frcp_rn(1.f + __expf(-2.f * x));        // (tanh(x) + 1) / 2 == sigmoid(2x)
         default: return x;
     }
 }

@@ -21,6 +21,8 @@ struct GemmSkArgs {
 template <int NT, int KS, bool SLOW>
 __global__ __launch_bounds__(256) void gemm_sk_kernel(const GemmSkArgs a) {
     constexpr int BN = NT * 16, KP = KS * 32;
+    constexpr int FRG = NT >= 8 ? 1 : (NT >= 4 ? 2 : 4);      // 16-row fragments per wave: keep acc <= 32-64 regs
+    constexpr int WROWS = FRG * 16;
     constexpr int WP = SK_WPITCH(KP);
     constexpr int EROW = BN * 2 + 16;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -48,11 +50,11 @@ __global__ __launch_bounds__(256) void gemm_sk_kernel(const GemmSkArgs a) {
             bv[t][e] = (a.bias && n < a.Nw) ? a.bias[n] : 0.f;
         }
 
-    for (long m0 = ((long)blockIdx.x * 4 + wave) * 64; m0 < a.M; m0 += (long)gridDim.x * 256) {
+    for (long m0 = ((long)blockIdx.x * 4 + wave) * WROWS; m0 < a.M; m0 += (long)gridDim.x * 4 * WROWS) {
         // ---- all X fragments of the wave's 64 rows: FR x KS independent 16-byte loads in flight
-        bf16x8_t xf[4][KS];
+        bf16x8_t xf[FRG][KS];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < FRG; ++j) {
             long m = m0 + 16 * j + fr;
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
@@ -62,11 +64,11 @@ __global__ __launch_bounds__(256) void gemm_sk_kernel(const GemmSkArgs a) {
                 xf[j][ks] = __builtin_bit_cast(bf16x8_t, v);
             }
         }
-        f32x4 acc[NT][4];
+        f32x4 acc[NT][FRG];
 #pragma unroll
         for (int t = 0; t < NT; ++t)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) acc[t][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            for (int j = 0; j < FRG; ++j) acc[t][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
             bf16x8_t wf[NT];
@@ -75,7 +77,7 @@ __global__ __launch_bounds__(256) void gemm_sk_kernel(const GemmSkArgs a) {
 #pragma unroll
             for (int t = 0; t < NT; ++t)
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
+                for (int j = 0; j < FRG; ++j)
                     acc[t][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[t], xf[j][ks], acc[t][j], 0, 0, 0);
         }
         // ---- bias + activation (switch hoisted), padding channels forced to zero
@@ -84,7 +86,7 @@ __global__ __launch_bounds__(256) void gemm_sk_kernel(const GemmSkArgs a) {
 #pragma unroll
         for (int t = 0; t < NT; ++t)
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
+            for (int j = 0; j < FRG; ++j)
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     float v = acc[t][j][e] + bv[t][e];
@@ -95,7 +97,7 @@ __global__ __launch_bounds__(256) void gemm_sk_kernel(const GemmSkArgs a) {
                 }
         // ---- transposed store: 16 rows at a time through the wave's LDS scratch
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < FRG; ++j) {
 #pragma unroll
             for (int t = 0; t < NT; ++t)
                 *(uint2*)(sE + fr * EROW + (16 * t + 4 * fq) * 2) =
@@ -121,8 +123,9 @@ template <int NT, int KS>
 static int launch_sk(const GemmSkArgs& a, hipStream_t s) {
     constexpr int BN = NT * 16, KP = KS * 32;
     size_t smem = (size_t)BN * SK_WPITCH(KP) + 4 * 16 * (BN * 2 + 16);
-    long blocks = (a.M + 255) / 256;
-    int grid = (int)(blocks > 4096 ? 4096 : blocks);
+    constexpr int FRG = NT >= 8 ? 1 : (NT >= 4 ? 2 : 4);
+    long blocks = (a.M + 64 * FRG - 1) / (64 * FRG);
+    int grid = (int)(blocks > 8192 ? 8192 : blocks);
     const bool fast = a.act == ACT_LINEAR || a.act == ACT_RELU || a.act == ACT_LEAKY;
     if (fast) gemm_sk_kernel<NT, KS, false><<<grid, 256, smem, s>>>(a);
     else gemm_sk_kernel<NT, KS, true><<<grid, 256, smem, s>>>(a);

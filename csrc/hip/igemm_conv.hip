@@ -34,6 +34,7 @@ struct ConvArgs {
     int Ttot;                 // taps per weight row
     int act; float alpha;
     int max_taps;
+    int ksplit; float* slab;   // split-K (single-class problems, Dense with huge K): fp32 partials [split][M][Nd]
 };
 
 #define PITCH 96              // bytes per LDS row (64 B of bf16 K-data + 32 B pad)
@@ -53,7 +54,8 @@ __global__ __launch_bounds__(256) void igemm_conv_kernel(const ConvArgs a) {
     char* sW = smem + 2 * BM * PITCH;                 // [2][BN][PITCH]
     int4* sT = (int4*)(smem + 2 * (BM + BN) * PITCH); // [max_taps]
 
-    const ClassDesc cd = a.classes[blockIdx.y];
+    const int split = a.ksplit > 1 ? blockIdx.y : 0;
+    const ClassDesc cd = a.classes[a.ksplit > 1 ? 0 : blockIdx.y];
     const int m0 = blockIdx.x * BM;
     if (m0 >= cd.M) return;
     const int n0 = blockIdx.z * BN;
@@ -80,8 +82,11 @@ __global__ __launch_bounds__(256) void igemm_conv_kernel(const ConvArgs a) {
         aiw[r] = j * a.ssw;
     }
     const int Cs = a.Cs;
-    int tap = (q * 8) / Cs, c = (q * 8) - tap * Cs;
-    const int nsteps = (cd.ntaps * Cs + 31) / 32;
+    const int nsteps_all = (cd.ntaps * Cs + 31) / 32;
+    const int per_split = (nsteps_all + a.ksplit - 1) / a.ksplit;
+    const int s_begin = split * per_split;
+    const int nsteps = max(0, min(nsteps_all, s_begin + per_split) - s_begin);
+    int tap = (s_begin * 32 + q * 8) / Cs, c = (s_begin * 32 + q * 8) - tap * Cs;
 
     uint4 regA[RA], regW[RW];
     auto gload = [&]() {
@@ -148,6 +153,20 @@ __global__ __launch_bounds__(256) void igemm_conv_kernel(const ConvArgs a) {
         __syncthreads();
     }
 
+    if (a.ksplit > 1) {      // raw fp32 partials; bias / activation / bf16 happen in splitk_finish_kernel
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            int m = m0 + wm * 64 + 16 * j + fr;
+            if (m >= cd.M) continue;
+            float* prow = a.slab + ((long)split * cd.M + m) * a.Nd;
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                int nb = n0 + wn * WN + 16 * t + 4 * fq;
+                if (nb + 3 < a.Nd) *(float4*)(prow + nb) = make_float4(acc[t][j][0], acc[t][j][1], acc[t][j][2], acc[t][j][3]);
+            }
+        }
+        return;
+    }
     // ---- epilogue: lane holds channels nb..nb+3 (nb = 4*fq) of pixel fr in each 16x16 tile
     const bool vec_ok = (a.Nd & 3) == 0;
 #pragma unroll
@@ -185,6 +204,19 @@ __global__ __launch_bounds__(256) void igemm_conv_kernel(const ConvArgs a) {
     }
 }
 
+// out[m][n] = act(bias[n] + sum_s slab[s][m][n]) for the split-K path (dst pixel index == m: single class, unit stride)
+__global__ void splitk_finish_kernel(const float* __restrict__ slab, const float* __restrict__ bias,
+                                     bf16_t* __restrict__ dst, long MN, int Nd, int Nw, int ksplit, int act, float alpha) {
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < MN; i += (long)gridDim.x * blockDim.x) {
+        int n = (int)(i % Nd);
+        float s = 0.f;
+        for (int k = 0; k < ksplit; ++k) s += slab[k * MN + i];
+        float v = 0.f;
+        if (n < Nw) v = act_apply(s + (bias ? bias[n] : 0.f), act, alpha);
+        dst[i] = f2bf(v);
+    }
+}
+
 template <int BM, int BN>
 static int launch_igemm(const ConvArgs& a, int n_classes, int max_M, hipStream_t s) {
     size_t smem = 2 * (BM + BN) * PITCH + (size_t)a.max_taps * sizeof(int4);
@@ -197,8 +229,14 @@ static int launch_igemm(const ConvArgs& a, int n_classes, int max_M, hipStream_t
             done = true;
         }
     }
-    dim3 grid((max_M + BM - 1) / BM, n_classes, (a.Nd + BN - 1) / BN);
+    dim3 grid((max_M + BM - 1) / BM, a.ksplit > 1 ? a.ksplit : n_classes, (a.Nd + BN - 1) / BN);
     igemm_conv_kernel<BM, BN><<<grid, 256, smem, s>>>(a);
+    if (a.ksplit > 1) {
+        long MN = (long)max_M * a.Nd;
+        long g = (MN + 255) / 256;
+        splitk_finish_kernel<<<(int)(g > 2048 ? 2048 : g), 256, 0, s>>>(a.slab, a.bias, a.dst, MN, a.Nd, a.Nw, a.ksplit,
+                                                                    a.act, a.alpha);
+    }
     return 0;
 }
 
@@ -207,7 +245,7 @@ static int launch_igemm(const ConvArgs& a, int n_classes, int max_M, hipStream_t
 DDL_API int ddl_igemm_conv(const void* src, const void* wgt, const float* bias, void* dst, const void* classes,
                            const void* taps, int n_classes, int max_M, int max_taps, int B, int Hs, int Ws,
                            int Cs, int Hd, int Wd, int Nd, int Nw, int ssh, int ssw, int sdh, int sdw, int Ttot,
-                           int act, float alpha, int tile, hipStream_t s) {
+                           int act, float alpha, int tile, int ksplit, float* slab, hipStream_t s) {
     if (Cs % 8 != 0 || Cs <= 0 || Nd <= 0 || n_classes <= 0 || max_M <= 0) return -1;
     if ((long)B * Hs * Ws * Cs >= (1L << 31) || (long)B * Hd * Wd * Nd >= (1L << 31)) return -3;
     ConvArgs a;
@@ -216,6 +254,13 @@ DDL_API int ddl_igemm_conv(const void* src, const void* wgt, const float* bias, 
     a.B = B; a.Hs = Hs; a.Ws = Ws; a.Cs = Cs; a.Hd = Hd; a.Wd = Wd; a.Nd = Nd; a.Nw = Nw;
     a.ssh = ssh; a.ssw = ssw; a.sdh = sdh; a.sdw = sdw; a.Ttot = Ttot; a.act = act; a.alpha = alpha;
     a.max_taps = max_taps;
+    a.ksplit = 1; a.slab = nullptr;
+    if (ksplit > 1) {
+        // split-K needs one class whose destination pixel index equals the row index (fprop, unit dst stride,
+        // whole output = [max_M][Nd]) -- Dense / 1x1 fprop
+        if (n_classes != 1 || sdh != 1 || sdw != 1 || !slab || (long)B * Hd * Wd != max_M || (Nd & 3)) return -5;
+        a.ksplit = ksplit; a.slab = slab;
+    }
     if (tile == 0) {
         // widest channel tile that is not mostly padding; shrink the pixel tile when the grid
         // would otherwise leave CUs idle (256 CUs, want >= ~2 blocks each)

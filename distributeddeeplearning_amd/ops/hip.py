@@ -70,7 +70,7 @@ _gather = _sig("ddl_relayout_gather", None, vp, vp, vp, ci, cl, vp)
 _gemm_sk = _sig("ddl_gemm_sk", ci, vp, vp, vp, vp, cl, ci, ci, ci, ci, cf, vp)
 _philox = _sig("ddl_philox_uniform", None, vp, cl, vp, cf, cf, vp)
 _igemm = _sig("ddl_igemm_conv", ci, vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci,
-              ci, ci, ci, ci, cf, ci, vp)
+              ci, ci, ci, ci, cf, ci, ci, vp, vp)
 _pconv = _sig("ddl_pconv", ci, vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, cf,
               ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, vp)
 _pconv_lds = _sig("ddl_pconv_lds_bytes", ci, ci, ci, cl)
@@ -686,9 +686,20 @@ def _run_pconv(pl, src, wgt, bias, dst, g, B, Hs, Ws, Cs, Hd, Wd, Nd, Nw, ss, sd
 
 def _run_igemm(src, wgt, bias, dst, g, mode, B, Hs, Ws, Cs, Hd, Wd, Nd, Nw, ss, sd, act, alpha, tile=None):
     ct, tt, ncls, maxM, maxT = _tables(g, mode, B, src.device)
+    # split-K: a Dense / 1x1 fprop with few output tiles and a very long reduction (model0's 86528 -> 10
+    # head at batch 512 is TWO 256-row blocks walking 2704 k-steps each) is spread over the K axis
+    ksplit, slab = 1, None
+    if mode == "fprop" and ncls == 1 and _is_1x1(g):
+        nsteps = (g.KH * g.KW * Cs + 31) // 32
+        blocks = -(-maxM // 256) * -(-Nd // 128)
+        if blocks < 128 and nsteps >= 64:
+            ksplit = max(1, min(nsteps // 16, 512 // blocks))
+            if ksplit > 1:
+                slab = torch.empty(ksplit * maxM * Nd, dtype=torch.float32, device=src.device)
     rc = _igemm(src.data_ptr(), wgt.data_ptr(), _p(bias), dst.data_ptr(), ct.data_ptr(), tt.data_ptr(), ncls,
                 maxM, maxT, B, Hs, Ws, Cs, Hd, Wd, Nd, Nw, ss[0], ss[1], sd[0], sd[1], g.KH * g.KW,
-                ACT_CODE[act], alpha, IGEMM_TILE if tile is None else tile, _stream())
+                ACT_CODE[act], alpha, IGEMM_TILE if tile is None else tile, ksplit if slab is not None else 1,
+                _p(slab), _stream())
     if rc != 0:
         raise ValueError(f"igemm_conv rejected the problem (rc={rc}): {g} mode={mode} B={B}")
 
