@@ -580,46 +580,51 @@ __global__ void im2col_1ch_kernel(const bf16_t* __restrict__ img, uint4* __restr
     }
 }
 
-// One block per image: the image's whole taps-as-channels tile is staged into LDS with coalesced
-// 16-byte loads (it is read 25x, two bytes at a time, by the fold), then every thread folds pixels.
-// LDS rows are padded by 4 B so the 2-byte gathers of neighbouring pixels spread over the banks.
+// One block per (image, band of output rows): the band's slice of the taps-as-channels tensor is
+// staged into LDS with coalesced 16-byte loads (it is read up to KH*KW times, two bytes at a time, by
+// the fold), then every thread folds pixels.  LDS rows are padded by 4 B so the 2-byte gathers of
+// neighbouring pixels spread over the banks.
 __global__ __launch_bounds__(256) void col2im_1ch_kernel(const bf16_t* __restrict__ col, uint4* __restrict__ img,
                                                          const OneChGeom g, const float* __restrict__ bias, int act,
-                                                         float alpha, int lds_tile) {
+                                                         float alpha, int band_rows) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int b = blockIdx.x;
-    const int npix_col = g.OH * g.OW, row_b = g.Tp * 2, pitch = row_b + 4;
-    const bf16_t* base = col + (long)b * npix_col * g.Tp;
-    if (lds_tile) {
+    const int h0 = blockIdx.y * band_rows, h1 = min(g.H, h0 + band_rows);
+    const int pitch = g.Tp * 2 + 4;
+    int lo = h0 + g.pt - (g.KH - 1) * g.dh;                  // smallest th of the band
+    const int oh_lo = lo <= 0 ? 0 : (lo + g.sh - 1) / g.sh;
+    const int oh_hi = min(g.OH - 1, (h1 - 1 + g.pt) / g.sh);
+    const int nrows = oh_hi - oh_lo + 1;
+    const bf16_t* base = col + ((long)b * g.OH + oh_lo) * g.OW * g.Tp;
+    if (nrows > 0) {
         const int u_per = g.Tp / 8;
-        for (int u = threadIdx.x; u < npix_col * u_per; u += 256) {
+        for (int u = threadIdx.x; u < nrows * g.OW * u_per; u += 256) {
             int p = u / u_per, c8 = u - p * u_per;
             uint4 v = *(const uint4*)(base + (long)p * g.Tp + c8 * 8);
             uint32_t* d = (uint32_t*)(smem + p * pitch + c8 * 16);
             d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
         }
-        __syncthreads();
     }
+    __syncthreads();
     const float b0 = bias ? bias[0] : 0.f;
-    for (int i = threadIdx.x; i < g.H * g.W; i += 256) {
-        int h = i / g.W, w = i - h * g.W;
+    for (int i = threadIdx.x; i < (h1 - h0) * g.W; i += 256) {
+        int hl = i / g.W, w = i - hl * g.W, h = h0 + hl;
         float acc = 0.f;
         for (int kh = 0; kh < g.KH; ++kh) {
             int th = h + g.pt - kh * g.dh;
             if (th < 0 || th % g.sh) continue;
             int oh = th / g.sh;
-            if (oh >= g.OH) continue;
+            if (oh > oh_hi) continue;
             for (int kw = 0; kw < g.KW; ++kw) {
                 int tw = w + g.pl - kw * g.dw;
                 if (tw < 0 || tw % g.sw) continue;
                 int ow = tw / g.sw;
                 if (ow >= g.OW) continue;
-                int p = oh * g.OW + ow, t = kh * g.KW + kw;
-                acc += lds_tile ? bf2f(*(const bf16_t*)(smem + p * pitch + t * 2)) : bf2f(base[(long)p * g.Tp + t]);
+                acc += bf2f(*(const bf16_t*)(smem + ((oh - oh_lo) * g.OW + ow) * pitch + (kh * g.KW + kw) * 2));
             }
         }
         float v = act_apply(acc + b0, act, alpha);
-        img[(long)b * g.H * g.W + i] = make_uint4((uint32_t)f2bf(v), 0, 0, 0);     // channel 0 real, 7 lanes zero
+        img[((long)b * g.H + h) * g.W + w] = make_uint4((uint32_t)f2bf(v), 0, 0, 0);   // channel 0 real, 7 lanes zero
     }
 }
 
@@ -638,16 +643,22 @@ DDL_API int ddl_col2im_1ch(const void* col, void* img, const float* bias, int B,
                            float alpha, hipStream_t s) {
     if (Tp % 8 || Tp < KH * KW) return -1;
     OneChGeom g{H, W, OH, OW, KH, KW, sh, sw, dh, dw, pt, pl, KH * KW, Tp, 8};
-    size_t smem = (size_t)OH * OW * (Tp * 2 + 4);
-    int tile = smem <= 150 * 1024;
-    if (tile && smem > 64 * 1024) {
+    // band height: the staged slice ((rows-1)/sh + halo rows of the col tensor) stays under ~40 KiB
+    const size_t row_bytes = (size_t)OW * (Tp * 2 + 4);
+    const int halo = ((KH - 1) * dh) / sh + 2;
+    int band = H;
+    while (band > 1 && ((size_t)((band - 1) / sh + halo)) * row_bytes > 40 * 1024) band = (band + 1) / 2;
+    size_t smem = ((size_t)((band - 1) / sh + halo)) * row_bytes;
+    if (smem > 160 * 1024) return -2;
+    if (smem > 64 * 1024) {
         static bool done = false;
         if (!done) {
             hipFuncSetAttribute((const void*)col2im_1ch_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             done = true;
         }
     }
-    col2im_1ch_kernel<<<B, 256, tile ? smem : 0, s>>>((const bf16_t*)col, (uint4*)img, g, bias, act, alpha, tile);
+    col2im_1ch_kernel<<<dim3(B, (H + band - 1) / band), 256, smem, s>>>((const bf16_t*)col, (uint4*)img, g, bias, act,
+                                                                        alpha, band);
     return 0;
 }
 
