@@ -34,6 +34,8 @@ def main():
     ap.add_argument("--comm", default="torch", choices=["torch", "rccl"],
                     help="collectives through torch.distributed (nccl == RCCL) or the native C++ RCCL communicator")
     ap.add_argument("--avg-every", type=int, default=8, help="local-SGD averaging period (config localsgd)")
+    ap.add_argument("--zero", action="store_true",
+                    help="dcgan configs, N>1: reduce-scatter + sharded update + all-gather instead of all-reduce")
     ap.add_argument("--device", default="cuda")
     a = ap.parse_args()
 

@@ -13,13 +13,14 @@
 // Out-of-range source pixels read as zero, so TF's asymmetric `same` padding, `valid` transpose
 // output padding and kernels larger than the image need no special cases.
 //
-// Tiling (wave64, 256 threads = 4 waves): block tile BM pixels x BN channels, K step 32.
+// Tiling (wave64, 256 threads = 4 waves): block tile BM pixels x BN channels, K step 64.
 // MFMA operands are swapped -- weights are the A operand (rows = channel n), pixels the B operand
 // (cols) -- so a lane's 4 accumulator registers are 4 consecutive channels of one pixel and the
-// epilogue stores 8-byte bf16x4 vectors.  LDS rows are 64 B of data on a 96 B pitch: with that
+// epilogue stores 8-byte bf16x4 vectors.  LDS rows are 128 B of data on a 160 B pitch: with that
 // pitch the four 16-lane groups of a ds_read_b128 fragment read hit 16 distinct 16-B slots
-// (conflict-free; a 64/80 B pitch is 2-4 way).  Global->LDS staging is register-staged and
-// software-pipelined one K step ahead (one barrier per step).
+// (conflict-free).  Global->LDS staging goes through a ring of three register stages: the gathers
+// of K-step s+3 are issued before the MFMAs of step s, so three steps of loads are in flight per
+// wave (the gather latency, not the math, bounds these small-N problems); one barrier per step.
 #include "common.h"
 
 struct ClassDesc { int ph, pw, Hc, Wc, ntaps, tap_off, M, pad; };
@@ -37,10 +38,220 @@ struct ConvArgs {
     int ksplit; float* slab;   // split-K (single-class problems, Dense with huge K): fp32 partials [split][M][Nd]
 };
 
-#define PITCH 96              // bytes per LDS row (64 B of bf16 K-data + 32 B pad)
+#define BK 64                 // K elements per LDS stage
+#define PITCH 160             // bytes per LDS row (128 B of bf16 K-data + 32 B pad; 160/16 = 10 == 2 mod 4)
+#define DEPTH 3               // global loads are issued DEPTH K-steps ahead of their use
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 template <int BM, int BN>
 __global__ __launch_bounds__(256) void igemm_conv_kernel(const ConvArgs a) {
+    constexpr int WAVES_M = BM / 64;
+    constexpr int WAVES_N = 4 / WAVES_M;
+    constexpr int WN = BN / WAVES_N;          // channels per wave
+    constexpr int NT = WN / 16;               // 16-channel MFMA tiles per wave
+    constexpr int RA = BM / 32;               // pixel rows staged per thread
+    constexpr int RW = (BN + 31) / 32;        // weight rows staged per thread
+    static_assert(WN >= 16 && WN % 16 == 0, "bad tile");
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* sA = smem;                                  // [2][BM][PITCH]
+    char* sW = smem + 2 * BM * PITCH;                 // [2][BN][PITCH]
+    int4* sT = (int4*)(smem + 2 * (BM + BN) * PITCH); // [max_taps]
+
+    const int split = a.ksplit > 1 ? blockIdx.y : 0;
+    const ClassDesc cd = a.classes[a.ksplit > 1 ? 0 : blockIdx.y];
+    const int m0 = blockIdx.x * BM;
+    if (m0 >= cd.M) return;
+    const int n0 = blockIdx.z * BN;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave % WAVES_M, wn = wave / WAVES_M;
+
+    for (int i = tid; i < cd.ntaps; i += 256) sT[i] = a.taps[cd.tap_off + i];
+
+    // ---- per-thread staging assignment: kgroup q (8 k-elements of the 64-wide stage), rows r0 + 32*r
+    const int q = tid & 7, r0 = tid >> 3;
+    const int HW = cd.Hc * cd.Wc;
+    const int Cs = a.Cs;
+    int abase[RA], aih[RA], aiw[RA];          // element offsets fit 31 bits (checked on the host)
+#pragma unroll
+    for (int r = 0; r < RA; ++r) {
+        int m = m0 + r0 + 32 * r;
+        bool v = m < cd.M;
+        int mm = v ? m : 0;
+        int b = mm / HW, rem = mm - b * HW;
+        int i = rem / cd.Wc, j = rem - i * cd.Wc;
+        abase[r] = b * a.Hs * a.Ws * Cs;
+        aih[r] = v ? i * a.ssh : -(1 << 24);  // invalid rows fail the bounds test below
+        aiw[r] = j * a.ssw;
+    }
+    int wbase[RW];
+#pragma unroll
+    for (int r = 0; r < RW; ++r) {
+        int nl = r0 + 32 * r, n = n0 + nl;
+        wbase[r] = (nl < BN && n < a.Nw) ? n * a.Ttot * Cs : -1;
+    }
+    const int nsteps_all = (cd.ntaps * Cs + BK - 1) / BK;
+    const int per_split = (nsteps_all + a.ksplit - 1) / a.ksplit;
+    const int s_begin = split * per_split;
+    const int nsteps = max(0, min(nsteps_all, s_begin + per_split) - s_begin);
+    int tap = (s_begin * BK + q * 8) / Cs, c = (s_begin * BK + q * 8) - tap * Cs;
+    int lstep = 0;                            // K-steps loaded so far
+
+    // bounds-checked buffer loads: an out-of-image / out-of-range element gets an offset beyond the
+    // descriptor's size and reads as zero, so the gathers are branch-free and the compiler can count
+    // them (a predicated global_load becomes an exec-masked branch and forces vmcnt(0) drains)
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)a.src, 0, (int)((unsigned)a.B * a.Hs * a.Ws * Cs * 2u), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)a.wgt, 0, (int)((unsigned)a.Nw * a.Ttot * Cs * 2u), 0x00020000);
+    const int dq = BK / Cs, dr = BK - dq * Cs;
+    const int last_tap = max(cd.ntaps - 1, 0);
+
+    u32x4 regA[DEPTH][RA], regW[DEPTH][RW];   // register ring of in-flight stages (statically indexed)
+    auto gload = [&](u32x4 (&rA)[RA], u32x4 (&rW)[RW]) {
+        const bool tv = (tap < cd.ntaps) & (lstep < nsteps);
+        const int4 te = sT[min(tap, last_tap)];
+#pragma unroll
+        for (int r = 0; r < RA; ++r) {
+            int ih = aih[r] + te.x, iw = aiw[r] + te.y;
+            bool ok = tv & ((unsigned)ih < (unsigned)a.Hs) & ((unsigned)iw < (unsigned)a.Ws);   // no short-circuit
+            unsigned off = ok ? (unsigned)(abase[r] + (ih * a.Ws + iw) * Cs + c) * 2u : 0xFFFFFFF0u;
+            rA[r] = __builtin_amdgcn_raw_buffer_load_b128(rsA, off, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < RW; ++r) {
+            bool ok = tv & (wbase[r] >= 0);
+            unsigned off = ok ? (unsigned)(wbase[r] + te.z * Cs + c) * 2u : 0xFFFFFFF0u;
+            rW[r] = __builtin_amdgcn_raw_buffer_load_b128(rsW, off, 0, 0);
+        }
+        ++lstep;
+        tap += dq;
+        c += dr;
+        if (c >= Cs) { c -= Cs; ++tap; }
+    };
+    auto lstore = [&](int buf, const u32x4 (&rA)[RA], const u32x4 (&rW)[RW]) {
+#pragma unroll
+        for (int r = 0; r < RA; ++r)
+            *(u32x4*)(sA + (buf * BM + r0 + 32 * r) * PITCH + q * 16) = rA[r];
+#pragma unroll
+        for (int r = 0; r < RW; ++r)
+            if (BN % 32 == 0 || r0 + 32 * r < BN) *(u32x4*)(sW + (buf * BN + r0 + 32 * r) * PITCH + q * 16) = rW[r];
+    };
+
+    f32x4 acc[NT][4];
+#pragma unroll
+    for (int i = 0; i < NT; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    __syncthreads();                 // tap table visible
+#pragma unroll
+    for (int u = 0; u < DEPTH; ++u) gload(regA[u], regW[u]);
+    lstore(0, regA[0], regW[0]);
+    __syncthreads();
+
+    const int fr = lane & 15, fq = lane >> 4;
+    auto mma = [&](int cur) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            bf16x8_t wf[NT], xf[4];
+#pragma unroll
+            for (int i = 0; i < NT; ++i)
+                wf[i] = *(const bf16x8_t*)(sW + (cur * BN + wn * WN + 16 * i + fr) * PITCH + h * 64 + fq * 16);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                xf[j] = *(const bf16x8_t*)(sA + (cur * BM + wm * 64 + 16 * j + fr) * PITCH + h * 64 + fq * 16);
+#pragma unroll
+            for (int i = 0; i < NT; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], xf[j], acc[i][j], 0, 0, 0);
+        }
+    };
+    // main loop: whole groups of DEPTH steps, no guards (a simple loop keeps the compiler's vmcnt
+    // counting exact: two stages of gathers stay in flight across every barrier)
+    int s = 0;
+    for (; s + DEPTH <= nsteps; s += DEPTH) {
+#pragma unroll
+        for (int u = 0; u < DEPTH; ++u) {
+            const int cur = (s + u) & 1;
+            gload(regA[u], regW[u]);                    // K-step s+u+DEPTH (slot u was stored one step ago)
+            mma(cur);
+            lstore(cur ^ 1, regA[(u + 1) % DEPTH], regW[(u + 1) % DEPTH]);     // K-step s+u+1
+            __syncthreads();
+        }
+    }
+    // tail: nsteps % DEPTH steps whose gathers are already in the ring
+#pragma unroll
+    for (int u = 0; u < DEPTH - 1; ++u) {
+        if (s + u < nsteps) {                           // block-uniform
+            const int cur = (s + u) & 1;
+            mma(cur);
+            if (s + u + 1 < nsteps) {
+                lstore(cur ^ 1, regA[(u + 1) % DEPTH], regW[(u + 1) % DEPTH]);
+                __syncthreads();
+            }
+        }
+    }
+
+    if (a.ksplit > 1) {      // raw fp32 partials; bias / activation / bf16 happen in splitk_finish_kernel
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            int m = m0 + wm * 64 + 16 * j + fr;
+            if (m >= cd.M) continue;
+            float* prow = a.slab + ((long)split * cd.M + m) * a.Nd;
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                int nb = n0 + wn * WN + 16 * t + 4 * fq;
+                if (nb + 3 < a.Nd) *(float4*)(prow + nb) = make_float4(acc[t][j][0], acc[t][j][1], acc[t][j][2], acc[t][j][3]);
+            }
+        }
+        return;
+    }
+    // ---- epilogue: lane holds channels nb..nb+3 (nb = 4*fq) of pixel fr in each 16x16 tile
+    const bool vec_ok = (a.Nd & 3) == 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        int m = m0 + wm * 64 + 16 * j + fr;
+        if (m >= cd.M) continue;
+        int b = m / HW, rem = m - b * HW;
+        int i = rem / cd.Wc, jj = rem - i * cd.Wc;
+        long pix = ((long)b * a.Hd + cd.ph + (long)a.sdh * i) * a.Wd + cd.pw + (long)a.sdw * jj;
+        bf16_t* drow = a.dst + pix * a.Nd;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            int nb = n0 + wn * WN + 16 * t + 4 * fq;
+            if (nb >= a.Nd) continue;
+            float v[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                int n = nb + e;
+                float x = acc[t][j][e];
+                if (n < a.Nw) {
+                    if (a.bias) x += a.bias[n];
+                    v[e] = act_apply(x, a.act, a.alpha);
+                } else {
+                    v[e] = 0.f;
+                }
+            }
+            if (vec_ok) {
+                *(uint2*)(drow + nb) = make_uint2(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]));
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (nb + e < a.Nd) drow[nb + e] = f2bf(v[e]);
+            }
+        }
+    }
+}
+
+// ---- the shallow variant: 32-wide K stages, loads one step ahead.  Less LDS and fewer registers per
+// block (more resident blocks), and no pipeline ramp: it wins on short reductions and on grids
+// that already fill the CUs several times over; the autotuner times both.
+#define PITCH1 96             // 32-wide K stage: 64 B of bf16 K-data + 32 B pad
+
+template <int BM, int BN>
+__global__ __launch_bounds__(256) void igemm_conv_kernel_k32(const ConvArgs a) {
     constexpr int WAVES_M = BM / 64;
     constexpr int WAVES_N = 4 / WAVES_M;
     constexpr int WN = BN / WAVES_N;          // channels per wave
@@ -50,9 +261,9 @@ __global__ __launch_bounds__(256) void igemm_conv_kernel(const ConvArgs a) {
     static_assert(WN >= 16 && WN % 16 == 0, "bad tile");
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* sA = smem;                                  // [2][BM][PITCH]
-    char* sW = smem + 2 * BM * PITCH;                 // [2][BN][PITCH]
-    int4* sT = (int4*)(smem + 2 * (BM + BN) * PITCH); // [max_taps]
+    char* sA = smem;                                  // [2][BM][PITCH1]
+    char* sW = smem + 2 * BM * PITCH1;                 // [2][BN][PITCH1]
+    int4* sT = (int4*)(smem + 2 * (BM + BN) * PITCH1); // [max_taps]
 
     const int split = a.ksplit > 1 ? blockIdx.y : 0;
     const ClassDesc cd = a.classes[a.ksplit > 1 ? 0 : blockIdx.y];
@@ -109,10 +320,10 @@ __global__ __launch_bounds__(256) void igemm_conv_kernel(const ConvArgs a) {
     auto lstore = [&](int buf) {
 #pragma unroll
         for (int r = 0; r < RA; ++r)
-            *(uint4*)(sA + (buf * BM + r0 + 64 * r) * PITCH + q * 16) = regA[r];
+            *(uint4*)(sA + (buf * BM + r0 + 64 * r) * PITCH1 + q * 16) = regA[r];
 #pragma unroll
         for (int r = 0; r < RW; ++r)
-            if (r0 + 64 * r < BN) *(uint4*)(sW + (buf * BN + r0 + 64 * r) * PITCH + q * 16) = regW[r];
+            if (r0 + 64 * r < BN) *(uint4*)(sW + (buf * BN + r0 + 64 * r) * PITCH1 + q * 16) = regW[r];
     };
     auto advance = [&]() {
         c += 32;
@@ -140,10 +351,10 @@ __global__ __launch_bounds__(256) void igemm_conv_kernel(const ConvArgs a) {
         bf16x8_t wf[NT], xf[4];
 #pragma unroll
         for (int i = 0; i < NT; ++i)
-            wf[i] = *(const bf16x8_t*)(sW + (cur * BN + wn * WN + 16 * i + fr) * PITCH + fq * 16);
+            wf[i] = *(const bf16x8_t*)(sW + (cur * BN + wn * WN + 16 * i + fr) * PITCH1 + fq * 16);
 #pragma unroll
         for (int j = 0; j < 4; ++j)
-            xf[j] = *(const bf16x8_t*)(sA + (cur * BM + wm * 64 + 16 * j + fr) * PITCH + fq * 16);
+            xf[j] = *(const bf16x8_t*)(sA + (cur * BM + wm * 64 + 16 * j + fr) * PITCH1 + fq * 16);
 #pragma unroll
         for (int i = 0; i < NT; ++i)
 #pragma unroll
@@ -217,20 +428,20 @@ __global__ void splitk_finish_kernel(const float* __restrict__ slab, const float
     }
 }
 
-template <int BM, int BN>
+template <int BM, int BN, bool DEEP = true>
 static int launch_igemm(const ConvArgs& a, int n_classes, int max_M, hipStream_t s) {
-    size_t smem = 2 * (BM + BN) * PITCH + (size_t)a.max_taps * sizeof(int4);
+    size_t smem = 2 * (BM + BN) * (DEEP ? PITCH : PITCH1) + (size_t)a.max_taps * sizeof(int4);
+    auto kern = DEEP ? igemm_conv_kernel<BM, BN> : igemm_conv_kernel_k32<BM, BN>;
     if (smem > 160 * 1024) return -2;
     if (smem > 64 * 1024) {
         static bool done = false;   // per-instantiation opt-in for > 64 KiB dynamic LDS
         if (!done) {
-            hipFuncSetAttribute((const void*)igemm_conv_kernel<BM, BN>,
-                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             done = true;
         }
     }
     dim3 grid((max_M + BM - 1) / BM, a.ksplit > 1 ? a.ksplit : n_classes, (a.Nd + BN - 1) / BN);
-    igemm_conv_kernel<BM, BN><<<grid, 256, smem, s>>>(a);
+    kern<<<grid, 256, smem, s>>>(a);
     if (a.ksplit > 1) {
         long MN = (long)max_M * a.Nd;
         long g = (MN + 255) / 256;
@@ -247,7 +458,8 @@ DDL_API int ddl_igemm_conv(const void* src, const void* wgt, const float* bias, 
                            int Cs, int Hd, int Wd, int Nd, int Nw, int ssh, int ssw, int sdh, int sdw, int Ttot,
                            int act, float alpha, int tile, int ksplit, float* slab, hipStream_t s) {
     if (Cs % 8 != 0 || Cs <= 0 || Nd <= 0 || n_classes <= 0 || max_M <= 0) return -1;
-    if ((long)B * Hs * Ws * Cs >= (1L << 31) || (long)B * Hd * Wd * Nd >= (1L << 31)) return -3;
+    if ((long)B * Hs * Ws * Cs >= (1L << 31) || (long)B * Hd * Wd * Nd >= (1L << 31) ||
+        (long)Nw * Ttot * Cs >= (1L << 31)) return -3;
     ConvArgs a;
     a.src = (const bf16_t*)src; a.wgt = (const bf16_t*)wgt; a.bias = bias; a.dst = (bf16_t*)dst;
     a.classes = (const ClassDesc*)classes; a.taps = (const int4*)taps;
@@ -278,6 +490,13 @@ DDL_API int ddl_igemm_conv(const void* src, const void* wgt, const float* bias, 
         case 5: return launch_igemm<256, 64>(a, n_classes, max_M, s);
         case 6: return launch_igemm<128, 128>(a, n_classes, max_M, s);   // WN = 64
         case 8: return launch_igemm<64, 128>(a, n_classes, max_M, s);    // WN = 32
+        case 17: return launch_igemm<256, 16, false>(a, n_classes, max_M, s);      // 16 + t: shallow variant
+        case 18: return launch_igemm<64, 64, false>(a, n_classes, max_M, s);
+        case 19: return launch_igemm<256, 32, false>(a, n_classes, max_M, s);
+        case 20: return launch_igemm<128, 64, false>(a, n_classes, max_M, s);
+        case 21: return launch_igemm<256, 64, false>(a, n_classes, max_M, s);
+        case 22: return launch_igemm<128, 128, false>(a, n_classes, max_M, s);
+        case 24: return launch_igemm<64, 128, false>(a, n_classes, max_M, s);
         default: return -4;
     }
 }

@@ -12,7 +12,7 @@ class _DCGAN:
     def setup(self):
         from .models.dcgan import GANConfig, GANTrainer, GraphedGANStep
         cfg = GANConfig(size=self.size, batch=self.batch, seed=0)
-        self.t = GANTrainer(cfg, self.device, self.dp, self.rank)
+        self.t = GANTrainer(cfg, self.device, self.dp, self.rank, shard_optimizer=getattr(self.args, 'zero', False))
         gen = torch.Generator().manual_seed(1234 + self.rank)
         real = torch.rand(self.batch, self.size, self.size, 1, generator=gen)    # synthetic [0,1] images
         self.real = self.t.D.prepare_input(real)

@@ -24,7 +24,7 @@ import torch
 from ..ops import functional as F
 from . import ir
 from .network import ConvOp, Network
-from .optim import FlatOptimizer, OptimConfig
+from .optim import FlatOptimizer, OptimConfig, ShardedFlatOptimizer
 
 NOISE_DIM = 128
 
@@ -101,14 +101,16 @@ class GANTrainer:
     """One rank's DCGAN trainer.  `dp` (parallel.ddp.FlatDataParallel or None) averages the flat
     gradient buffer of the network being updated across ranks -- one collective per phase."""
 
-    def __init__(self, cfg: GANConfig, device="cpu", dp=None, rank: int = 0):
+    def __init__(self, cfg: GANConfig, device="cpu", dp=None, rank: int = 0, shard_optimizer: bool = False):
         self.cfg, self.device, self.dp = cfg, torch.device(device), dp
+        self.sharded = bool(shard_optimizer and dp is not None)
         bn_mode = "inference" if cfg.reference_exact else "batch"
         # same seed on every rank -> identical initial replicas (dp.broadcast makes it certain)
         self.G = Network(generator_spec(cfg.size, cfg.base, cfg.noise_dim), device, cfg.seed + 1, bn_mode)
         self.D = Network(discriminator_spec(cfg.size, cfg.base), device, cfg.seed + 2, bn_mode)
         ocfg = OptimConfig.tf_adam(cfg.lr, fresh_double=cfg.reference_exact)
         self.optG, self.optD = FlatOptimizer(self.G, ocfg), FlatOptimizer(self.D, ocfg)
+        self._ocfg = ocfg
         self.rng = DeviceRNG(device, cfg.seed * 7919 + 17 + rank)
         self.head: ConvOp = self.D.ops[-1]
         assert self.head.kind == "dense" and self.head.g.O == 1
@@ -117,6 +119,9 @@ class GANTrainer:
             dp.broadcast_(self.G.P, self.G.S, self.D.P, self.D.S)
             self.G.refresh_working_copies()
             self.D.refresh_working_copies()
+        if self.sharded:        # reduce-scatter / shard update / all-gather instead of all-reduce (ZeRO-1)
+            self.optG = ShardedFlatOptimizer(self.G, ocfg, dp)
+            self.optD = ShardedFlatOptimizer(self.D, ocfg, dp)
 
     # ---- the two phases -------------------------------------------------------------------
     def _d_head(self, feat, n_first, label_first, label_second, want_dx, want_dw):
@@ -186,10 +191,10 @@ class GANTrainer:
         if not prepared:
             real = self.D.prepare_input(real)
         self.phase_a(real)
-        if self.dp is not None:
+        if self.dp is not None and not self.sharded:
             self.dp.all_reduce_sum_(self.D.G)
         self.phase_b(real.shape[0])
-        if self.dp is not None:
+        if self.dp is not None and not self.sharded:
             self.dp.all_reduce_sum_(self.G.G)
         self.phase_c()
         return self.d_loss, self.g_loss
@@ -227,7 +232,7 @@ class GraphedGANStep:
                  capture_collectives: bool = False):
         self.t, self.real = trainer, real_prepared
         self.B = real_prepared.shape[0]
-        self.full = trainer.dp is None or capture_collectives
+        self.full = trainer.dp is None or capture_collectives or trainer.sharded
         t = trainer
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())

@@ -84,3 +84,54 @@ class FlatOptimizer:
             self.v.copy_(sd["v"])
         if self.step_dev is not None:
             self.step_dev.fill_(self.t)
+
+
+class ShardedFlatOptimizer(FlatOptimizer):
+    """ZeRO-1 style data-parallel update [R-ns, SURVEY 2.3 "ZeRO/FSDP sharding"]: the flat gradient
+    is reduce-scattered, every rank keeps optimizer state for and updates only its 1/world slice
+    of the flat master parameters, and the slices are all-gathered back.  On a ring over xGMI this
+    moves the same bytes as the all-reduce it replaces, but the update reads 1/world of P/m/v.
+
+    `step()` contains the collectives: callers must not all-reduce the gradients themselves.
+    """
+
+    def __init__(self, net, cfg: OptimConfig, dp):
+        self.net, self.cfg, self.dp = net, cfg, dp
+        self.t = 0
+        dev, n, w = net.P.device, net.P.numel(), dp.world
+        self.chunk = ((-(-n // w)) + 7) // 8 * 8          # equal 32-byte aligned shards
+        self.lo = min(dp.rank * self.chunk, n)
+        self.hi = min(self.lo + self.chunk, n)
+        self._gbuf = torch.zeros(self.chunk * w, dtype=net.G.dtype, device=dev)
+        self._pbuf = torch.zeros(self.chunk * w, dtype=net.P.dtype, device=dev)
+        self.pshard = self._pbuf[dp.rank * self.chunk:(dp.rank + 1) * self.chunk]
+        self.pshard[:self.hi - self.lo].copy_(net.P[self.lo:self.hi])
+        self.m = torch.zeros(self.chunk, dtype=net.P.dtype, device=dev) if cfg.kind == "adam" else None
+        self.v = torch.zeros(self.chunk, dtype=net.P.dtype, device=dev) if cfg.kind in ("adam", "rmsprop") else None
+        self.step_dev = torch.zeros(1, dtype=torch.int32, device=dev) if net.on_gpu else None
+
+    def step(self, grad_scale: Optional[float] = None):
+        net, c, dp = self.net, self.cfg, self.dp
+        scale = dp.grad_scale if grad_scale is None else grad_scale
+        n = net.P.numel()
+        self.t += 1
+        self._gbuf[:n].copy_(net.G)
+        g = dp.reduce_scatter_sum(self._gbuf)
+        if net.on_gpu:
+            F.hip_backend().optimizer_step_flat(self.pshard, g, self.m, self.v, None, self.step_dev, c, scale)
+        else:
+            g = g * scale
+            if c.kind == "adam":
+                cpu_ref.adam_step(self.pshard, g, self.m, self.v, self.t, c.lr, c.beta1, c.beta2, c.eps)
+            elif c.kind == "sgd":
+                cpu_ref.sgd_step(self.pshard, g, c.lr)
+            elif c.kind == "rmsprop":
+                cpu_ref.rmsprop_step(self.pshard, g, self.v, c.lr, c.rho, c.eps)
+            elif c.kind == "adam_fresh_double":
+                cpu_ref.adam_fresh_double_step(self.pshard, g, c.lr, c.beta1, c.beta2, c.eps)
+            else:
+                raise ValueError(c.kind)
+        dp.all_gather_flat(self.pshard, self._pbuf)
+        net.P.copy_(self._pbuf[:n])
+        if net.on_gpu:
+            net.refresh_working_copies(cast=True)

@@ -477,6 +477,15 @@ def optimizer_step(opt, grad_scale=1.0, avg_with=None, avg_weight=0.0):
     _done()
 
 
+def optimizer_step_flat(P, G, m, v, Pc, step_dev, c, grad_scale=1.0):
+    """The fused update on explicit flat tensors (a shard of a network's buffers: ZeRO-1 mode)."""
+    n = P.numel()
+    _chk_f32(G, n, "grad shard")
+    _optim_step(P.data_ptr(), G.data_ptr(), _p(m), _p(v), _p(Pc), step_dev.data_ptr(), n, _OPT_KIND[c.kind],
+                c.lr, c.beta1, c.beta2, c.eps, c.rho, grad_scale, None, 0.0, _stream())
+    _done()
+
+
 def scale_emit(P, Pc, scale):
     _scale_emit(P.data_ptr(), _p(Pc), P.numel(), scale, _stream())
     _done()
@@ -690,10 +699,10 @@ def _run_igemm(src, wgt, bias, dst, g, mode, B, Hs, Ws, Cs, Hd, Wd, Nd, Nw, ss, 
     # head at batch 512 is TWO 256-row blocks walking 2704 k-steps each) is spread over the K axis
     ksplit, slab = 1, None
     if mode == "fprop" and ncls == 1 and _is_1x1(g):
-        nsteps = (g.KH * g.KW * Cs + 31) // 32
+        nsteps = (g.KH * g.KW * Cs + 63) // 64
         blocks = -(-maxM // 256) * -(-Nd // 128)
-        if blocks < 128 and nsteps >= 64:
-            ksplit = max(1, min(nsteps // 16, 512 // blocks))
+        if blocks < 128 and nsteps >= 32:
+            ksplit = max(1, min(nsteps // 8, 512 // blocks))
             if ksplit > 1:
                 slab = torch.empty(ksplit * maxM * Nd, dtype=torch.float32, device=src.device)
     rc = _igemm(src.data_ptr(), wgt.data_ptr(), _p(bias), dst.data_ptr(), ct.data_ptr(), tt.data_ptr(), ncls,
@@ -704,17 +713,20 @@ def _run_igemm(src, wgt, bias, dst, g, mode, B, Hs, Ws, Cs, Hd, Wd, Nd, Nw, ss, 
         raise ValueError(f"igemm_conv rejected the problem (rc={rc}): {g} mode={mode} B={B}")
 
 
-def _time_us(fn, reps=3):
+def _time_us(fn, reps=4, inner=4):
+    """Best-of-`reps` device time of one call; `inner` back-to-back launches per measurement keep the
+    launch latency of a ~20 us kernel out of the comparison."""
     fn()
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     best = float("inf")
     for _ in range(reps):
         e0.record()
-        fn()
+        for _ in range(inner):
+            fn()
         e1.record()
         e1.synchronize()
-        best = min(best, e0.elapsed_time(e1) * 1e3)
+        best = min(best, e0.elapsed_time(e1) * 1e3 / inner)
     return best
 
 
@@ -734,6 +746,7 @@ def _igemm_call(src, wgt, bias, dst, g, mode, B, Hs, Ws, Cs, Hd, Wd, Nd, Nw, ss,
     if choice is None:
         if AUTOTUNE and not torch.cuda.is_current_stream_capturing():
             tiles = [1] if Nd <= 16 else ([3] if Nd <= 32 else ([4, 5, 2] if Nd <= 64 else [6, 8]))
+            tiles = tiles + [t + 16 for t in tiles]          # deep (64-wide, 3 stages in flight) and shallow variants
             cands = [("igemm", t) for t in tiles] + \
                     [("pconv", pl) for pl in _pconv_candidates(g, mode, B, Cs, Nd, ss, src.device)]
             timed = []

@@ -130,12 +130,39 @@ def spmd_ensemble(rank, world, port, out):
     dist.destroy_process_group()
 
 
-def gan_dp(rank, world, port, out):
+def gan_dp(rank, world, port, out, sharded=False):
     dp = _init(rank, world, port)
     from distributeddeeplearning_amd.models.dcgan import GANConfig, GANTrainer
-    t = GANTrainer(GANConfig(batch=4, seed=3), "cpu", dp, rank)
+    t = GANTrainer(GANConfig(batch=4, seed=3), "cpu", dp, rank, shard_optimizer=sharded)
     real = torch.rand(4, 28, 28, 1, generator=torch.Generator().manual_seed(rank))
     for _ in range(2):
         dl, gl = t.train_step(real)
     np.save(f"{out}/gan{rank}.npy", np.concatenate([t.G.P.numpy(), t.D.P.numpy(), [float(dl), float(gl)]]))
+    dist.destroy_process_group()
+
+
+def sharded_adam(rank, world, port, out):
+    """ZeRO-1 Adam == replicated Adam on all-reduced gradients, step for step."""
+    dp = _init(rank, world, port)
+    from distributeddeeplearning_amd.models import ir
+    from distributeddeeplearning_amd.models.network import Network
+    from distributeddeeplearning_amd.models.optim import FlatOptimizer, OptimConfig, ShardedFlatOptimizer
+    spec = ir.ModelSpec("m", [ir.Input("in", (6, 6, 1))])
+    for l in (ir.Flatten("f"), ir.Dense("d1", 7, "relu"), ir.Dense("d2", 10, "softmax")):
+        spec.append(l)
+    res = []
+    for kind in ("adam", "rmsprop", "sgd"):
+        a, b = Network(spec, "cpu", 5), Network(spec, "cpu", 5)
+        oa = FlatOptimizer(a, OptimConfig.keras(kind, 1e-2))
+        ob = ShardedFlatOptimizer(b, OptimConfig.keras(kind, 1e-2), dp)
+        gen = torch.Generator().manual_seed(100 + rank)
+        for _ in range(3):
+            g = torch.randn(a.G.shape, generator=gen)
+            a.G.copy_(g)
+            b.G.copy_(g)
+            dp.all_reduce_sum_(a.G)
+            oa.step(dp.grad_scale)
+            ob.step()
+        res.append(float((a.P - b.P).abs().max()))
+    np.save(f"{out}/zero{rank}.npy", np.array(res))
     dist.destroy_process_group()

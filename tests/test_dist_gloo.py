@@ -63,8 +63,15 @@ def test_spmd_ensemble_two_ranks_agree(tmp_path):
     assert 0 <= a[10] <= 1
 
 
-def test_gan_data_parallel_replicas_stay_identical(tmp_path):
-    _spawn(W.gan_dp, tmp_path)
+def test_sharded_optimizer_matches_replicated(tmp_path):
+    _spawn(W.sharded_adam, tmp_path)
+    for r in range(2):
+        assert np.load(tmp_path / f"zero{r}.npy").max() < 1e-6
+
+
+@pytest.mark.parametrize("sharded", [False, True])
+def test_gan_data_parallel_replicas_stay_identical(tmp_path, sharded):
+    _spawn(W.gan_dp, tmp_path, sharded)
     a, b = np.load(tmp_path / "gan0.npy"), np.load(tmp_path / "gan1.npy")
     assert np.array_equal(a[:-2], b[:-2])                      # weights identical after 2 DP steps
     assert np.isfinite(a).all() and not np.array_equal(a[-2:], b[-2:])     # local losses differ (own shard)

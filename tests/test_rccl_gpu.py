@@ -56,7 +56,8 @@ def test_rccl_bf16_wire_dtype():
     comm.close()
 
 
-def test_graphed_dp_step_with_one_rank_group():
+@pytest.mark.parametrize("sharded", [False, True])
+def test_graphed_dp_step_with_one_rank_group(sharded):
     """The segmented-graph DP step (all-reduce of D grads overlapped with G's forward on a comm
     stream) on a 1-rank RCCL group: same losses as the plain eager trainer."""
     import os
@@ -68,7 +69,7 @@ def test_graphed_dp_step_with_one_rank_group():
     try:
         dp = ddp.FlatDataParallel()
         real = torch.rand(64, 28, 28, 1, generator=torch.Generator().manual_seed(0))
-        a = GANTrainer(GANConfig(batch=64, seed=5), "cuda:0", dp, 0)
+        a = GANTrainer(GANConfig(batch=64, seed=5), "cuda:0", dp, 0, shard_optimizer=sharded)
         b = GANTrainer(GANConfig(batch=64, seed=5), "cuda:0", None, 0)
         rp = a.D.prepare_input(real)
         step = GraphedGANStep(a, rp, warmup=2)

@@ -18,13 +18,14 @@ def load(path):
         db = sqlite3.connect(dbs[0])
         cols = [r[1] for r in db.execute("pragma table_info(kernels)")]
         name = "name" if "name" in cols else "kernel_name"
-        for n, s, e in db.execute(f"select {name}, start, end from kernels order by start"):
-            rows.append((n, s, e))
+        grid = "grid_x, grid_y, grid_z, workgroup_x" if "grid_x" in cols else "0, 0, 0, 0"
+        for n, s, e, gx, gy, gz, wx in db.execute(f"select {name}, start, end, {grid} from kernels order by start"):
+            rows.append((n, s, e, (gx, gy, gz, wx)))
         return rows
     for f in glob.glob(f"{path}/**/*_kernel_trace.csv", recursive=True):
         with open(f) as fh:
             for r in csv.DictReader(fh):
-                rows.append((r["Kernel_Name"], int(r["Start_Timestamp"]), int(r["End_Timestamp"])))
+                rows.append((r["Kernel_Name"], int(r["Start_Timestamp"]), int(r["End_Timestamp"]), None))
     rows.sort(key=lambda r: r[1])
     return rows
 
@@ -50,8 +51,23 @@ def main():
         rows = [r for r in rows if r[1] >= cut]
         per = 2 if "--gan" in sys.argv else 5
         steps = max(1, sum(1 for r in rows if "optim_kernel" in r[0]) // per)
+    if "--sequence" in sys.argv:
+        # the last complete training step in launch order (optimizer kernel to optimizer kernel)
+        per = 2 if "--gan" in sys.argv else 5
+        opt = [i for i, r in enumerate(rows) if "optim_kernel" in r[0]]
+        lo, hi = opt[-per - 1] + 1, opt[-1] + 1
+        print("| # | kernel | us | gap us | grid (threads) | block |")
+        print("|---:|---|---:|---:|---|---:|")
+        tot = 0
+        for i in range(lo, hi):
+            n, s_, e_, g = rows[i]
+            tot += e_ - s_
+            gs = "x".join(str(v) for v in g[:3]) if g else ""
+            print(f"| {i - lo} | `{short(n)}` | {(e_ - s_)/1e3:.1f} | {(s_ - rows[i-1][2])/1e3:.1f} | {gs} | {g[3] if g else ''} |")
+        print(f"\nkernel time {tot/1e3:.1f} us, span {(rows[hi-1][2] - rows[lo][1])/1e3:.1f} us")
+        return
     agg = defaultdict(lambda: [0, 0, 10**18, 0])
-    for n, s, e in rows:
+    for n, s, e, _ in rows:
         a = agg[short(n)]
         d = e - s
         a[0] += 1; a[1] += d; a[2] = min(a[2], d); a[3] = max(a[3], d)
