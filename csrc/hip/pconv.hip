@@ -45,6 +45,9 @@ struct PConvArgs {
 // floor(x / d) for 0 <= x < 2^22 via a float reciprocal (the +0.5 keeps x/d away from integers)
 __device__ __forceinline__ int fdiv(int x, float inv) { return __float2int_rz(((float)x + 0.5f) * inv); }
 
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+#define OOB 0xFFFFFFF0u            // a byte offset beyond any descriptor: the buffer load returns zeros
+
 #define WPITCH 160                 // weight stage row: 64 k-elements (128 B) + 32 B pad  (P = 10 == 2 mod 4)
 
 // SLOW = the activation is one of the transcendental ones (sigmoid / softplus / tanh / softsign /
@@ -67,6 +70,13 @@ __global__ __launch_bounds__(256, (BN * FR >= 512 ? 1 : 2)) void pconv_kernel(co
     const int i0 = band * a.BR;                        // first class-grid row of this band
     const int n0 = blockIdx.y * BN;
     const int Cs = a.Cs, cs8 = Cs >> 3;
+    // Bounds-checked buffer loads keep every gather branch-free (a predicated global_load compiles to an
+    // exec-masked branch, after which the compiler can no longer count outstanding loads and drains
+    // them all with vmcnt(0) -- that would serialise the weight pipeline below).
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)a.src, 0, (int)((unsigned)a.B * a.Hs * a.Ws * Cs * 2u), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)a.wgt, 0, (int)((unsigned)a.Nw * a.wrow * 2u), 0x00020000);
 
     // ---- stage the patch: every 16-B unit is either source data or zero (halo / missing image)
     {
@@ -75,7 +85,7 @@ __global__ __launch_bounds__(256, (BN * FR >= 512 ? 1 : 2)) void pconv_kernel(co
         const int total = a.IMG * per_img;
         // eight independent 16-byte loads in flight per thread before the first LDS store
         for (int base = tid; base < total; base += 256 * 8) {
-            uint4 v[8];
+            u32x4 v[8];
             int dst[8];
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
@@ -86,14 +96,14 @@ __global__ __launch_bounds__(256, (BN * FR >= 512 ? 1 : 2)) void pconv_kernel(co
                 int pix = fdiv(r, a.inv_cs8), c8 = r - pix * cs8;
                 int pr = fdiv(pix, a.inv_PW), pc = pix - pr * a.PW;
                 int sr = row0 + pr, sc = col0 + pc, b = b0 + img;
-                v[k] = make_uint4(0, 0, 0, 0);
-                if (in && b < a.B && (unsigned)sr < (unsigned)a.Hs && (unsigned)sc < (unsigned)a.Ws)
-                    v[k] = *(const uint4*)(a.src + (((long)b * a.Hs + sr) * a.Ws + sc) * Cs + c8 * 8);
+                bool ok = in & (b < a.B) & ((unsigned)sr < (unsigned)a.Hs) & ((unsigned)sc < (unsigned)a.Ws);
+                unsigned off = ok ? (unsigned)(((b * a.Hs + sr) * a.Ws + sc) * Cs + c8 * 8) * 2u : OOB;
+                v[k] = __builtin_amdgcn_raw_buffer_load_b128(rsA, off, 0, 0);
                 dst[k] = in ? img * a.img_bytes + pix * a.pitch + c8 * 16 : -1;
             }
 #pragma unroll
             for (int k = 0; k < 8; ++k)
-                if (dst[k] >= 0) *(uint4*)(sP + dst[k]) = v[k];
+                if (dst[k] >= 0) *(u32x4*)(sP + dst[k]) = v[k];
         }
         int2* sKw = (int2*)(smem + a.k_off);
         for (int t = tid; t < a.total_stages * 8; t += 256) sKw[t] = a.ktab[t];
@@ -102,14 +112,29 @@ __global__ __launch_bounds__(256, (BN * FR >= 512 ? 1 : 2)) void pconv_kernel(co
 
     // weight staging assignment: k-unit wq of rows wr0 + 32*r
     const int wq = tid & 7, wr0 = tid >> 3;
-    const bf16_t* wbase[RW];
-    bool wok[RW];
+    unsigned wbase[RW];                                // byte offset of the weight row, OOB if there is none
 #pragma unroll
     for (int r = 0; r < RW; ++r) {
         int nl = wr0 + 32 * r, n = n0 + nl;
-        wok[r] = nl < BN && n < a.Nw;
-        wbase[r] = a.wgt + (long)(wok[r] ? n : 0) * a.wrow;
+        wbase[r] = (nl < BN && n < a.Nw) ? (unsigned)(n * a.wrow) * 2u : OOB;
     }
+
+    // this lane's bias values (channels n0 + 16t + 4fq .. +3); channels >= Nw and a null bias read as zero.
+    // Small tiles keep them in registers for the whole kernel, the big ones reload them per epilogue.
+    constexpr bool HOIST_BIAS = BN * FR < 512;
+    const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)a.bias, 0, a.bias ? a.Nw * 4 : 0, 0x00020000);
+    f32x4 bv[NT];
+    auto load_bias = [&]() {
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const unsigned nb = (unsigned)(n0 + 16 * t + 4 * fq) * 4u;
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                bv[t][e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsB, nb + 4u * e, 0, 0));
+        }
+    };
+    if (HOIST_BIAS) load_bias();
 
     for (int ci = 0; ci < a.n_classes; ++ci) {
         const PClass cd = a.classes[ci];
@@ -133,20 +158,23 @@ __global__ __launch_bounds__(256, (BN * FR >= 512 ? 1 : 2)) void pconv_kernel(co
                 pixbase[j] = img * a.img_bytes + (il * a.ssh * a.PW + jl * a.ssw) * a.pitch;
             }
 
-            uint4 regA[RW], regB[RW];              // stage s lives in regA (s even) / regB (s odd)
+            u32x4 regA[RW], regB[RW];              // stage s lives in regA (s even) / regB (s odd)
             int wst = 0;                           // next stage to load
-            auto gload = [&](uint4* reg) {
-                const int kw = wst < nstages ? ck[wst * 8 + wq].y : -1;
+            auto gload = [&](u32x4 (&reg)[RW]) {
+                const int kv = ck[min(wst, nstages - 1) * 8 + wq].y;
+                const bool live = (wst < nstages) & (kv >= 0);
                 ++wst;
 #pragma unroll
-                for (int r = 0; r < RW; ++r)
-                    reg[r] = (kw >= 0 && wok[r]) ? *(const uint4*)(wbase[r] + kw) : make_uint4(0, 0, 0, 0);
+                for (int r = 0; r < RW; ++r) {
+                    unsigned off = (live & (wbase[r] != OOB)) ? wbase[r] + (unsigned)kv * 2u : OOB;
+                    reg[r] = __builtin_amdgcn_raw_buffer_load_b128(rsW, off, 0, 0);
+                }
             };
-            auto lstore = [&](int buf, const uint4* reg) {
+            auto lstore = [&](int buf, const u32x4 (&reg)[RW]) {
 #pragma unroll
                 for (int r = 0; r < RW; ++r) {
                     int nl = wr0 + 32 * r;
-                    if (nl < BN) *(uint4*)(sW + (buf * BN + nl) * WPITCH + wq * 16) = reg[r];
+                    if (BN % 32 == 0 || nl < BN) *(u32x4*)(sW + (buf * BN + nl) * WPITCH + wq * 16) = reg[r];
                 }
             };
 
@@ -200,14 +228,7 @@ __global__ __launch_bounds__(256, (BN * FR >= 512 ? 1 : 2)) void pconv_kernel(co
                 constexpr int EROW = BN * 2 + 16;
                 char* sE = smem + a.e_off + wave * (16 * EROW + 64);
                 int* sPix = (int*)(sE + 16 * EROW);
-                float bv[NT][4];
-#pragma unroll
-                for (int t = 0; t < NT; ++t)
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        int n = n0 + 16 * t + 4 * fq + e;
-                        bv[t][e] = (a.bias && n < a.Nw) ? a.bias[n] : 0.f;
-                    }
+                if (!HOIST_BIAS) load_bias();
                 const int act = a.act;
                 const float alpha = a.alpha;
                 if (SLOW) {

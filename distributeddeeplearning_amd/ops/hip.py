@@ -869,11 +869,46 @@ def _tr_pitch(nbytes: int) -> int:
     return (p if p % 2 else p + 1) * 32
 
 
-def _wgrad2_plan(g: ConvGeom, B: int, Cx: int, Ny: int, n_lim: int, c_lim: int):
+def _wgrad2_one_plan(g, B, Cx, Ny, n_lim, c_lim, tn, tc, TPW, budget_kb=None):
+    """One wgrad2 launch plan for an output tile (tn x tc), TPW taps per wave and an LDS budget (which
+    sets how many images / rows a unit holds and with it how many blocks share a CU)."""
+    T = g.KH * g.KW
+    ngroups = -(-T // (4 * TPW))
+    tiles = -(-n_lim // tn) * -(-c_lim // tc)
+    one_block = TPW * (tn // 16) * (tc // 16) * 4 > 160
+    if budget_kb is None:
+        budget_kb = 150 if one_block else 76
+    budget = budget_kb * 1024
+    xp, yp = _tr_pitch(Cx * 2), _tr_pitch(Ny * 2)
+    PW = (g.OW - 1) * g.sw + (g.KW - 1) * g.dw + 1
+    lds = lambda img, br: _wgrad2_lds(img, br, g.OW, Ny, (br - 1) * g.sh + (g.KH - 1) * g.dh + 1, PW, xp, yp, T)
+    IMG, BR = 0, g.OH
+    if lds(1, g.OH) <= budget:
+        IMG = 1
+        while IMG < B and IMG * g.OH * g.OW < 512 and lds(IMG + 1, g.OH) <= budget:
+            IMG += 1
+    else:
+        br = g.OH
+        while br > 1 and lds(1, br) > budget:
+            br -= 1
+        if lds(1, br) <= budget:
+            IMG, BR = 1, br
+    if not IMG:
+        return None
+    n_units = -(-B // IMG) * -(-g.OH // BR)
+    per_cu = 1 if one_block else max(1, min(2, (160 * 1024) // max(lds(IMG, BR), 1)))
+    target = 256 * per_cu
+    nsplit = max(1, min(n_units, target // (ngroups * tiles)))
+    return dict(IMG=IMG, BR=BR, xp=xp, yp=yp, TN=tn, TC=tc, TPW=TPW, ngroups=ngroups, nsplit=nsplit,
+                budget=budget_kb)
+
+
+def _wgrad2_plans(g: ConvGeom, B: int, Cx: int, Ny: int, n_lim: int, c_lim: int):
+    """Candidate plans, the heuristic default first (the autotuner times them all against wgrad.hip)."""
     key = (g, B, Cx, Ny, n_lim, c_lim)
     if key in _W2_PLANS:
         return _W2_PLANS[key]
-    plan = None
+    plans = []
     T = g.KH * g.KW
     if T >= 4 and not g.depthwise:
         tn = 64 if n_lim > 32 else (32 if n_lim > 16 else 16)
@@ -881,31 +916,30 @@ def _wgrad2_plan(g: ConvGeom, B: int, Cx: int, Ny: int, n_lim: int, c_lim: int):
         opts = _W2_COMBOS[(tn, tc)]
         ngroups = -(-T // (4 * max(opts)))
         need = -(-T // (4 * ngroups))
-        TPW = min(o for o in opts if o >= need)
-        tiles = -(-n_lim // tn) * -(-c_lim // tc)
-        one_block = TPW * (tn // 16) * (tc // 16) * 4 > 160
-        budget = (150 if one_block else 76) * 1024
-        xp, yp = _tr_pitch(Cx * 2), _tr_pitch(Ny * 2)
-        PW = (g.OW - 1) * g.sw + (g.KW - 1) * g.dw + 1
-        lds = lambda img, br: _wgrad2_lds(img, br, g.OW, Ny, (br - 1) * g.sh + (g.KH - 1) * g.dh + 1, PW, xp, yp, T)
-        IMG, BR = 0, g.OH
-        if lds(1, g.OH) <= budget:
-            IMG = 1
-            while IMG < B and IMG * g.OH * g.OW < 512 and lds(IMG + 1, g.OH) <= budget:
-                IMG += 1
-        else:
-            br = g.OH
-            while br > 1 and lds(1, br) > budget:
-                br -= 1
-            if lds(1, br) <= budget:
-                IMG, BR = 1, br
-        if IMG:
-            n_units = -(-B // IMG) * -(-g.OH // BR)
-            target = 256 * (1 if one_block else 2)
-            nsplit = max(1, min(n_units, target // (ngroups * tiles)))
-            plan = dict(IMG=IMG, BR=BR, xp=xp, yp=yp, TN=tn, TC=tc, TPW=TPW, ngroups=ngroups, nsplit=nsplit)
-    _W2_PLANS[key] = plan
-    return plan
+        first = _wgrad2_one_plan(g, B, Cx, Ny, n_lim, c_lim, tn, tc, min(o for o in opts if o >= need))
+        if first is not None:
+            plans.append(first)
+        tiles = {(tn, tc)}
+        if tn == 64 and tc == 64:
+            tiles |= {(64, 32), (32, 64)}
+        elif tn == 64 and tc == 32:
+            tiles.add((32, 32))
+        elif tn == 32 and tc == 64:
+            tiles.add((32, 32))
+        seen = {tuple(sorted(first.items()))} if first else set()
+        for (a_, b_) in sorted(tiles):
+            for tpw in _W2_COMBOS[(a_, b_)]:
+                for kb in (150, 76, 50, 36):
+                    pl = _wgrad2_one_plan(g, B, Cx, Ny, n_lim, c_lim, a_, b_, tpw, kb)
+                    if pl is None:
+                        continue
+                    sig = tuple(sorted((k, v) for k, v in pl.items() if k != "budget"))
+                    if sig in seen:
+                        continue
+                    seen.add(sig)
+                    plans.append(pl)
+    _W2_PLANS[key] = plans
+    return plans
 
 
 def conv_wgrad(x, dy, g: ConvGeom, layout="A", out=None, box=None):
@@ -947,9 +981,9 @@ def conv_wgrad(x, dy, g: ConvGeom, layout="A", out=None, box=None):
     if out.numel() != numel:
         raise ValueError(f"conv_wgrad: out has {out.numel()} elements, expected {numel} for layout {layout}")
     _chk_f32(out, numel, "dW")
-    pl = _wgrad2_plan(g, B, Ip, Op, n_lim, c_lim) if WGRAD_IMPL == "wgrad2" else None
+    plans = _wgrad2_plans(g, B, Ip, Op, n_lim, c_lim) if WGRAD_IMPL == "wgrad2" else []
 
-    def run_w2():
+    def run_w2(pl):
         ns = pl["nsplit"]
         slab = (torch.zeros if box is not None else torch.empty)(ns * numel, dtype=torch.float32, device=dev)
         rc = _wgrad2(dy.data_ptr(), x.data_ptr(), slab.data_ptr(), numel, ns, B, g.OH, g.OW, Op, g.H, g.W, Ip,
@@ -970,20 +1004,27 @@ def conv_wgrad(x, dy, g: ConvGeom, layout="A", out=None, box=None):
         if rc:
             raise ValueError(f"conv_wgrad rejected the problem (rc={rc}): {g}")
 
-    if pl is not None:
+    if plans:
         key = ("wgrad", g, B, Ip, Op, n_lim, c_lim, sn, st, sc)
         choice = _CONV_CHOICE.get(key)
         if choice is None:
             if AUTOTUNE and not torch.cuda.is_current_stream_capturing():
-                t2, t1 = _time_us(run_w2), _time_us(run_w1)
-                choice = "w2" if t2 <= t1 else "w1"
+                timed = [(_time_us(lambda pl=pl: run_w2(pl)), i) for i, pl in enumerate(plans)]
+                timed.append((_time_us(run_w1), -1))
+                timed.sort()
+                choice = timed[0][1]
                 if os.environ.get("DDL_AUTOTUNE_VERBOSE"):
-                    print(f"[autotune] wgrad B={B} {g.H}x{g.W}x{g.I}->{g.OH}x{g.OW}x{g.O}: wgrad2 {t2:.1f} us, "
-                          f"wgrad {t1:.1f} us", flush=True)
+                    desc = [(round(t, 1), "wgrad" if i < 0 else
+                             tuple(plans[i][k] for k in ("TN", "TC", "TPW", "IMG", "BR", "ngroups", "nsplit")))
+                            for t, i in timed[:6]]
+                    print(f"[autotune] wgrad B={B} {g.H}x{g.W}x{g.I}->{g.OH}x{g.OW}x{g.O}: {desc}", flush=True)
             else:
-                choice = "w2"
+                choice = 0
             _CONV_CHOICE[key] = choice
-        (run_w2 if choice == "w2" else run_w1)()
+        if choice >= 0:
+            run_w2(plans[choice])
+        else:
+            run_w1()
         _done()
         return out
     M = B * g.OH * g.OW
