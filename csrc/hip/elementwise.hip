@@ -5,6 +5,9 @@
 
 #define EW_BLOCK 256
 #define EW_MAX_GRID 2048
+#ifndef COLREDUCE_MAX_BLOCKS
+#define COLREDUCE_MAX_BLOCKS 1024      // 4 blocks per CU: enough loads in flight to stream from HBM / Infinity Cache
+#endif
 
 static inline int ew_grid(long n_groups) {
     long g = (n_groups + EW_BLOCK - 1) / EW_BLOCK;
@@ -150,9 +153,13 @@ static inline void colreduce_grid(long rows, int C, dim3* grid) {
     int cg = C / 8;
     int cgl = cg < EW_BLOCK ? cg : EW_BLOCK;
     int rpi = EW_BLOCK / cgl;
-    long nb = (rows + (long)rpi * 8 - 1) / ((long)rpi * 8);      // >= 8 rows per thread
+    // cache-resident tensors (< 64 MB): one block per CU and a short finalize; larger ones stream from HBM and
+    // need four blocks per CU to keep enough loads in flight (measured: classifier step -6 %, dcgan64 -7 %)
+    const bool big = rows * (long)C * 2 >= (64L << 20);
+    const long per_thread = big ? 4 : 8, cap = big ? COLREDUCE_MAX_BLOCKS : 256;
+    long nb = (rows + (long)rpi * per_thread - 1) / ((long)rpi * per_thread);
     if (nb < 1) nb = 1;
-    if (nb > 256) nb = 256;
+    if (nb > cap) nb = cap;
     *grid = dim3((unsigned)nb, (unsigned)((cg + EW_BLOCK - 1) / EW_BLOCK), 1);
 }
 

@@ -43,14 +43,14 @@ def main():
         sys.exit("no kernel records found")
     steps = None
     if "--steady" in sys.argv:
-        # keep the last 40 % of the trace (by time): warm-up, autotuning and graph capture are over;
-        # normalise per training step (the fused optimizer kernel runs twice per GAN step / once per
-        # classifier network step)
-        t0, t1 = rows[0][1], rows[-1][2]
-        cut = t0 + 0.6 * (t1 - t0)
-        rows = [r for r in rows if r[1] >= cut]
+        # keep the last few training steps (optimizer kernel to optimizer kernel): warm-up, autotuning
+        # and graph capture are over by then.  The fused optimizer kernel runs twice per GAN step and
+        # once per network of the 5-replica classifier step.
         per = 2 if "--gan" in sys.argv else 5
-        steps = max(1, sum(1 for r in rows if "optim_kernel" in r[0]) // per)
+        opt = [i for i, r in enumerate(rows) if "optim_kernel" in r[0]]
+        total_steps = len(opt) // per
+        steps = max(1, min(8, total_steps // 2))
+        rows = rows[opt[-steps * per - 1] + 1: opt[-1] + 1]
     if "--sequence" in sys.argv:
         # the last complete training step in launch order (optimizer kernel to optimizer kernel)
         per = 2 if "--gan" in sys.argv else 5
