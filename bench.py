@@ -62,8 +62,33 @@ def main():
             dp = ddp.FlatDataParallel(comm_dtype=cd)
 
     from distributeddeeplearning_amd import benchmarks
-    runner = benchmarks.make(a.config, device, dp, rank, a)
-    runner.setup()
+
+    def build_runner():
+        r = benchmarks.make(a.config, device, dp, rank, a)
+        r.setup()
+        return r
+
+    # hipGraph capture next to a live RCCL group is the one step of setup that can fail for reasons
+    # outside the model code; if it does on ANY rank, every rank falls back to eager launches together
+    # (the measurement stays valid, only slower) instead of the job dying or ranks diverging.
+    runner, err = None, None
+    try:
+        runner = build_runner()
+    except Exception as e:          # noqa: BLE001 - re-raised below unless the eager fallback applies
+        err = e
+    failed = err is not None
+    if world > 1:
+        f = torch.tensor([1.0 if failed else 0.0], device=device)
+        torch.distributed.all_reduce(f, op=torch.distributed.ReduceOp.MAX)
+        failed = bool(f.item() > 0)
+    if failed:
+        if a.graph == "off" or not on_gpu:
+            raise err if err is not None else RuntimeError("setup failed on another rank")
+        print(f"[rank {rank}] graph setup failed ({err!r}); falling back to --graph off", file=sys.stderr, flush=True)
+        a.graph = "off"
+        runner = None
+        torch.cuda.synchronize()
+        runner = build_runner()
 
     def sync():
         if world > 1:

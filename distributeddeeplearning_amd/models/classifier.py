@@ -24,6 +24,7 @@ import torch
 
 from ..config import SearchSpace
 from ..ops import functional as F
+from ..utils import hipgraph
 from ..utils.data import Data, Sample
 from .network import Network
 from .optim import FlatOptimizer
@@ -100,19 +101,14 @@ class RandomModel:
             with torch.cuda.stream(side):        # warm-up really trains (first step of the epoch)
                 first = self._step_body(self._idx)
             torch.cuda.current_stream().wait_stream(side)
-            torch.cuda.synchronize()
+            hipgraph.quiesce()
             pool = torch.cuda.graph_pool_handle()
             if self._sync_dp:
-                ga, gb = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-                with torch.cuda.graph(ga, pool=pool):
-                    self._static_loss = self._fwd_bwd(self._idx)
-                with torch.cuda.graph(gb, pool=pool):
-                    self._update()
+                ga, self._static_loss = hipgraph.capture(lambda: self._fwd_bwd(self._idx), pool)
+                gb, _ = hipgraph.capture(self._update, pool)
                 self._graph = (ga, gb)
             else:
-                g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g, pool=pool):
-                    self._static_loss = self._step_body(self._idx)
+                g, self._static_loss = hipgraph.capture(lambda: self._step_body(self._idx), pool)
                 self._graph = (g,)
             self._gB = B
             return first                         # capture records, it does not execute

@@ -22,6 +22,7 @@ from typing import Optional
 import torch
 
 from ..ops import functional as F
+from ..utils import hipgraph
 from . import ir
 from .network import ConvOp, Network
 from .optim import FlatOptimizer, OptimConfig, ShardedFlatOptimizer
@@ -240,23 +241,18 @@ class GraphedGANStep:
             for _ in range(warmup):          # populates table caches / allocator before capture
                 t.train_step(self.real, prepared=True)
         torch.cuda.current_stream().wait_stream(side)
-        torch.cuda.synchronize()
+        hipgraph.quiesce()
         pool = torch.cuda.graph_pool_handle()
         self.graphs = []
         if self.full:
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, pool=pool):
-                t.train_step(self.real, prepared=True)
+            g, _ = hipgraph.capture(lambda: t.train_step(self.real, prepared=True), pool)
             self.graphs = [g]
         else:
             # A | all-reduce(D grads) on the comm stream || B1 (G forward) | B2 | all-reduce(G grads) | C
             self.comm_stream = torch.cuda.Stream()
             for fn in (lambda: t.phase_a(self.real), lambda: t.phase_b1(self.B), lambda: t.phase_b2(self.B),
                        t.phase_c):
-                g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g, pool=pool):
-                    fn()
-                self.graphs.append(g)
+                self.graphs.append(hipgraph.capture(fn, pool)[0])
 
     def step(self):
         t = self.t
