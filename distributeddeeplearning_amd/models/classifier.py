@@ -42,6 +42,7 @@ class RandomModel:
         self.verbose = verbose
         self.dp, self.averager = dp, averager
         self.net = Network(compiled.spec, device, seed)
+        self.net.branch_wgrad = True     # measured +2 % on the 5-replica step (network.SideBranch)
         if parent_state is not None:
             # clone_model + set_weights(get_weights()): inherited layers start from the parent's
             # weights (BN moving statistics included); the new head keeps its fresh init.

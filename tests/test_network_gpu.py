@@ -86,3 +86,26 @@ def test_gan_trainer_runs_and_learns():
     assert losses[-1][0] < losses[0][0]          # D learns to separate real from fake
     img = t.generate(4)
     assert img.shape == (4, 28, 28, 1) and float(img.min()) >= 0 and float(img.max()) <= 1
+
+
+def test_captured_step_with_wgrad_branch_matches_eager_bitwise():
+    """The hipGraph step forks every layer's weight-gradient chain onto a side stream
+    (network.SideBranch); the eager step runs the same kernels on one stream.  All reductions have a
+    fixed order, so after the same number of steps both trainers must hold identical bits."""
+    from distributeddeeplearning_amd.models import network
+    from distributeddeeplearning_amd.models.dcgan import GraphedGANStep
+    assert network.BRANCH and network._BR is not None
+    real = torch.rand(96, 28, 28, 1, generator=torch.Generator().manual_seed(3))
+    a = GANTrainer(GANConfig(batch=96, seed=9), "cuda")
+    b = GANTrainer(GANConfig(batch=96, seed=9), "cuda")
+    a.D.branch_wgrad = a.G.branch_wgrad = True
+    rp = a.D.prepare_input(real)
+    step = GraphedGANStep(a, rp, warmup=2)
+    assert network._BR.stream is not None
+    for _ in range(4):
+        step.step()
+    for _ in range(6):
+        b.train_step(rp, prepared=True)
+    torch.cuda.synchronize()
+    assert torch.equal(a.D.P, b.D.P) and torch.equal(a.G.P, b.G.P)
+    assert torch.equal(a.D.S, b.D.S) and torch.equal(a.G.S, b.G.S)
