@@ -2,6 +2,7 @@
 // weight relayout, channel padding, dataset gather.  All tensors are [rows][C] with C a
 // multiple of 8 so every access is a 16-byte vector (8 x bf16) per lane.
 #include "common.h"
+#include <cstdlib>
 
 #define EW_BLOCK 256
 #define EW_MAX_GRID 2048
@@ -52,56 +53,104 @@ DDL_API void ddl_act_bwd(const void* dy, const void* y, void* dx, long n, int ki
 }
 
 // ------------------------------------------------------------------------------ column reductions
-// One kernel shape for the three per-channel reductions over rows:
+// One kernel shape for the per-channel reductions over rows:
 //   MODE 0 (stats):   s0 = sum x          s1 = sum x^2
 //   MODE 1 (bn bwd):  s0 = sum g          s1 = sum g * xhat      g = dy * act'(y)
 //   MODE 2 (colsum):  s0 = sum dy
-// Block partials go to part[block][2][C]; a finalize kernel combines them in fp64 (deterministic).
+//   MODE 3 (bn bwd + bias grad of the conv in front of the BN): MODE 1 plus, with a = prev_act'(x),
+//                     s2 = sum a * g     s3 = sum a * x          s4 = sum a
+//       bn_bwd_apply writes dx = a * (k0*g + k1*x + k2), so the conv's bias gradient sum_r dx is
+//       k0*s2 + k1*s3 + k2*s4: the finalize kernel emits it and no separate pass over dx is needed.
+// Block partials go to part[block][NS][C]; a finalize kernel combines them in fp64 (deterministic).
+// The row loop issues four rows' loads before it consumes any of them (8-12 independent 16-byte
+// loads in flight per lane), which is what a streaming reduction needs at 1-4 blocks per CU.
+template <int MODE> struct CrSums { static constexpr int N = MODE == 3 ? 5 : 2; };
+
 template <int MODE>
 __global__ __launch_bounds__(EW_BLOCK) void colreduce_kernel(
     const uint4* __restrict__ a, const uint4* __restrict__ b, const uint4* __restrict__ yv,
     const float* __restrict__ mean, const float* __restrict__ invstd, float* __restrict__ part,
-    long rows, int C, int act, float alpha) {
-    __shared__ float red[EW_BLOCK][17];
+    long rows, int C, int act, float alpha, int prev_act, float prev_alpha) {
+    constexpr int NS = CrSums<MODE>::N;
+    __shared__ float red[EW_BLOCK][NS * 8 + 1];
     const int cg = C / 8;
     const int cgl = cg < EW_BLOCK ? cg : EW_BLOCK;           // channel groups handled by this block column
     const int rpi = EW_BLOCK / cgl;                            // rows per block iteration
     const int g = blockIdx.y * EW_BLOCK + (threadIdx.x % cgl);
     const int rl = threadIdx.x / cgl;
-    float s0[8], s1[8];
+    float s[NS][8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) s0[j] = s1[j] = 0.f;
+    for (int k = 0; k < NS; ++k)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) s[k][j] = 0.f;
     const bool active = rl < rpi && g < cg;
     if (active) {
         float mu[8], is[8];
-        if (MODE == 1) {
+        if (MODE == 1 || MODE == 3) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) { mu[j] = mean[g * 8 + j]; is[j] = invstd[g * 8 + j]; }
         }
-        for (long r = blockIdx.x * (long)rpi + rl; r < rows; r += (long)gridDim.x * rpi) {
+        const bool has_y = (MODE == 1 || MODE == 3) && act != ACT_LINEAR;
+        auto accum = [&](const uint4& ua, const uint4& ub, const uint4& uy) {
             float v[8];
-            unpack8(a[r * cg + g], v);
+            unpack8(ua, v);
             if (MODE == 0) {
 #pragma unroll
-                for (int j = 0; j < 8; ++j) { s0[j] += v[j]; s1[j] += v[j] * v[j]; }
-            } else if (MODE == 1) {
+                for (int j = 0; j < 8; ++j) { s[0][j] += v[j]; s[1][j] += v[j] * v[j]; }
+            } else if (MODE == 1 || MODE == 3) {
                 float x[8], yy[8];
-                unpack8(b[r * cg + g], x);
-                if (act != ACT_LINEAR) {
-                    unpack8(yv[r * cg + g], yy);
+                unpack8(ub, x);
+                if (has_y) {
+                    unpack8(uy, yy);
 #pragma unroll
                     for (int j = 0; j < 8; ++j) v[j] *= act_grad_y(yy[j], act, alpha);
                 }
 #pragma unroll
-                for (int j = 0; j < 8; ++j) { s0[j] += v[j]; s1[j] += v[j] * (x[j] - mu[j]) * is[j]; }
+                for (int j = 0; j < 8; ++j) { s[0][j] += v[j]; s[1][j] += v[j] * (x[j] - mu[j]) * is[j]; }
+                if (MODE == 3) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const float ad = act_grad_y(x[j], prev_act, prev_alpha);
+                        s[NS - 3][j] += ad * v[j];
+                        s[NS - 2][j] += ad * x[j];
+                        s[NS - 1][j] += ad;
+                    }
+                }
             } else {
 #pragma unroll
-                for (int j = 0; j < 8; ++j) s0[j] += v[j];
+                for (int j = 0; j < 8; ++j) s[0][j] += v[j];
             }
+        };
+        const long stride = (long)gridDim.x * rpi;
+        long r = blockIdx.x * (long)rpi + rl;
+        for (; r + 3 * stride < rows; r += 4 * stride) {
+            uint4 ua[4], ub[4], uy[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const long i = (r + u * stride) * cg + g;
+                ua[u] = a[i];
+                if (MODE == 1 || MODE == 3) {
+                    ub[u] = b[i];
+                    if (has_y) uy[u] = yv[i];
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) accum(ua[u], ub[u], uy[u]);
+        }
+        for (; r < rows; r += stride) {
+            const long i = r * cg + g;
+            uint4 ua = a[i], ub = ua, uy = ua;
+            if (MODE == 1 || MODE == 3) {
+                ub = b[i];
+                if (has_y) uy = yv[i];
+            }
+            accum(ua, ub, uy);
         }
     }
 #pragma unroll
-    for (int j = 0; j < 8; ++j) { red[threadIdx.x][j] = s0[j]; red[threadIdx.x][8 + j] = s1[j]; }
+    for (int k = 0; k < NS; ++k)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) red[threadIdx.x][k * 8 + j] = s[k][j];
     __syncthreads();
     // tree reduction over the row-lane dimension (rpi lanes share one channel group)
     int half = 1;
@@ -109,14 +158,16 @@ __global__ __launch_bounds__(EW_BLOCK) void colreduce_kernel(
     for (half >>= 1; half > 0; half >>= 1) {
         if (rl < half && rl + half < rpi) {
 #pragma unroll
-            for (int j = 0; j < 16; ++j) red[threadIdx.x][j] += red[threadIdx.x + half * cgl][j];
+            for (int j = 0; j < NS * 8; ++j) red[threadIdx.x][j] += red[threadIdx.x + half * cgl][j];
         }
         __syncthreads();
     }
     if (rl == 0 && g < cg) {
-        float* p = part + (size_t)blockIdx.x * 2 * C;
+        float* p = part + (size_t)blockIdx.x * NS * C;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) { p[g * 8 + j] = red[threadIdx.x][j]; p[C + g * 8 + j] = red[threadIdx.x][8 + j]; }
+        for (int k = 0; k < NS; ++k)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) p[k * C + g * 8 + j] = red[threadIdx.x][k * 8 + j];
     }
 }
 
@@ -127,23 +178,38 @@ __global__ __launch_bounds__(EW_BLOCK) void colreduce_kernel(
 // latency-bound serial walk.  Result valid where pl == 0.
 #define FIN_BLOCK 256
 #define FIN_CH 8
-__device__ __forceinline__ void reduce_partials(const float* __restrict__ part, int nblocks, int C, int c,
-                                                bool two, double& s0, double& s1) {
+template <int NS, int NUSE>
+__device__ __forceinline__ void reduce_partials_n(const float* __restrict__ part, int nblocks, int C, int c,
+                                                  double (&out)[NUSE]) {
     const int pl = threadIdx.x & 31;
-    double a0 = 0, a1 = 0;
+    double acc[NUSE];
+#pragma unroll
+    for (int k = 0; k < NUSE; ++k) acc[k] = 0;
     if (c < C) {
         for (int b = pl; b < nblocks; b += 32) {
-            a0 += part[(size_t)b * 2 * C + c];
-            if (two) a1 += part[(size_t)b * 2 * C + C + c];
+#pragma unroll
+            for (int k = 0; k < NUSE; ++k) acc[k] += part[((size_t)b * NS + k) * C + c];
         }
     }
 #pragma unroll
     for (int o = 16; o > 0; o >>= 1) {
-        a0 += __shfl_down(a0, o, 32);
-        a1 += __shfl_down(a1, o, 32);
+#pragma unroll
+        for (int k = 0; k < NUSE; ++k) acc[k] += __shfl_down(acc[k], o, 32);
     }
-    s0 = a0;
-    s1 = a1;
+#pragma unroll
+    for (int k = 0; k < NUSE; ++k) out[k] = acc[k];
+}
+__device__ __forceinline__ void reduce_partials(const float* __restrict__ part, int nblocks, int C, int c,
+                                                bool two, double& s0, double& s1) {
+    if (two) {
+        double o[2];
+        reduce_partials_n<2, 2>(part, nblocks, C, c, o);
+        s0 = o[0]; s1 = o[1];
+    } else {
+        double o[1];
+        reduce_partials_n<2, 1>(part, nblocks, C, c, o);
+        s0 = o[0]; s1 = 0;
+    }
 }
 #define FIN_CHANNEL() (blockIdx.x * FIN_CH + (threadIdx.x >> 5))
 #define FIN_LEADER() ((threadIdx.x & 31) == 0)
@@ -155,8 +221,10 @@ static inline void colreduce_grid(long rows, int C, dim3* grid) {
     int rpi = EW_BLOCK / cgl;
     // cache-resident tensors (< 64 MB): one block per CU and a short finalize; larger ones stream from HBM and
     // need four blocks per CU to keep enough loads in flight (measured: classifier step -6 %, dcgan64 -7 %)
+    static const long small_cap = getenv("DDL_CR_SMALL_CAP") ? atol(getenv("DDL_CR_SMALL_CAP")) : 256;
+    static const long small_rows = getenv("DDL_CR_SMALL_ROWS") ? atol(getenv("DDL_CR_SMALL_ROWS")) : 8;
     const bool big = rows * (long)C * 2 >= (64L << 20);
-    const long per_thread = big ? 4 : 8, cap = big ? COLREDUCE_MAX_BLOCKS : 256;
+    const long per_thread = big ? 4 : small_rows, cap = big ? COLREDUCE_MAX_BLOCKS : small_cap;
     long nb = (rows + (long)rpi * per_thread - 1) / ((long)rpi * per_thread);
     if (nb < 1) nb = 1;
     if (nb > cap) nb = cap;
@@ -203,7 +271,7 @@ DDL_API void ddl_bn_batch_stats(const void* x, long rows, int C, float* part, co
     dim3 grid;
     colreduce_grid(rows, C, &grid);
     colreduce_kernel<0><<<grid, EW_BLOCK, 0, s>>>((const uint4*)x, nullptr, nullptr, nullptr, nullptr, part,
-                                                  rows, C, 0, 0.f);
+                                                  rows, C, 0, 0.f, 0, 0.f);
     bn_stats_finalize_kernel<<<FIN_GRID(C), FIN_BLOCK, 0, s>>>(part, grid.x, C, rows, gamma, beta, mm, mv,
                                                              momentum, eps, bessel, update_moving, scale,
                                                              shift, mean, invstd);
@@ -286,17 +354,28 @@ DDL_API void ddl_bn_apply(const void* x, void* y, const float* scale, const floa
 }
 
 // BN backward: reduce -> finalize (dgamma, dbeta, c1 = dbeta/M, c2 = dgamma/M) -> apply.
+template <int NS>
 __global__ void bn_bwd_finalize_kernel(const float* __restrict__ part, int nblocks, int C, long rows,
                                        int train_stats, float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                       float* __restrict__ c1, float* __restrict__ c2) {
+                                       float* __restrict__ c1, float* __restrict__ c2,
+                                       const float* __restrict__ mean, const float* __restrict__ invstd,
+                                       const float* __restrict__ gamma, float* __restrict__ dbias, int c_bias) {
     int c = FIN_CHANNEL();
-    double s0, s1;
-    reduce_partials(part, nblocks, C, c, true, s0, s1);
+    double o[NS];
+    reduce_partials_n<NS, NS>(part, nblocks, C, c, o);
     if (c >= C || !FIN_LEADER()) return;
-    if (dbeta) dbeta[c] = (float)s0;
-    if (dgamma) dgamma[c] = (float)s1;
-    c1[c] = train_stats ? (float)(s0 / (double)rows) : 0.f;
-    c2[c] = train_stats ? (float)(s1 / (double)rows) : 0.f;
+    if (dbeta) dbeta[c] = (float)o[0];
+    if (dgamma) dgamma[c] = (float)o[1];
+    const float f1 = train_stats ? (float)(o[0] / (double)rows) : 0.f;
+    const float f2 = train_stats ? (float)(o[1] / (double)rows) : 0.f;
+    c1[c] = f1;
+    c2[c] = f2;
+    if (NS == 5 && c < c_bias) {
+        // same k0/k1/k2 as bn_bwd_apply (fp32 there); combined in fp64 here
+        const double is = invstd[c], gi = (double)gamma[c] * is;
+        const double k0 = gi, k1 = -gi * is * (double)f2, k2 = -gi * ((double)f1 - (double)mean[c] * is * (double)f2);
+        dbias[c] = (float)(k0 * o[NS - 3] + k1 * o[NS - 2] + k2 * o[NS - 1]);
+    }
 }
 
 __global__ void bn_bwd_apply_kernel(const uint4* __restrict__ dy, const uint4* __restrict__ x,
@@ -367,13 +446,24 @@ __global__ __launch_bounds__(EW_BLOCK) void bn_bwd_apply_cs_kernel(
 DDL_API void ddl_bn_bwd(const void* dy, const void* x, const void* y, void* dx, long rows, int C,
                         const float* mean, const float* invstd, const float* gamma, int act, float alpha,
                         int train_stats, int prev_act, float prev_alpha, float* part, float* dgamma,
-                        float* dbeta, float* c1, float* c2, hipStream_t s) {
+                        float* dbeta, float* c1, float* c2, float* dbias, int c_bias, hipStream_t s) {
+    // `dbias` (optional, c_bias entries): bias gradient of the conv feeding this BN, = column sums of dx;
+    // `part` then holds 5 (instead of 2) partial rows per block.
     dim3 grid;
     colreduce_grid(rows, C, &grid);
-    colreduce_kernel<1><<<grid, EW_BLOCK, 0, s>>>((const uint4*)dy, (const uint4*)x, (const uint4*)y, mean,
-                                                  invstd, part, rows, C, act, alpha);
-    bn_bwd_finalize_kernel<<<FIN_GRID(C), FIN_BLOCK, 0, s>>>(part, grid.x, C, rows, train_stats, dgamma, dbeta,
-                                                           c1, c2);
+    if (dbias) {
+        colreduce_kernel<3><<<grid, EW_BLOCK, 0, s>>>((const uint4*)dy, (const uint4*)x, (const uint4*)y, mean,
+                                                      invstd, part, rows, C, act, alpha, prev_act, prev_alpha);
+        bn_bwd_finalize_kernel<5><<<FIN_GRID(C), FIN_BLOCK, 0, s>>>(part, grid.x, C, rows, train_stats, dgamma,
+                                                                  dbeta, c1, c2, mean, invstd, gamma, dbias,
+                                                                  c_bias);
+    } else {
+        colreduce_kernel<1><<<grid, EW_BLOCK, 0, s>>>((const uint4*)dy, (const uint4*)x, (const uint4*)y, mean,
+                                                      invstd, part, rows, C, act, alpha, 0, 0.f);
+        bn_bwd_finalize_kernel<2><<<FIN_GRID(C), FIN_BLOCK, 0, s>>>(part, grid.x, C, rows, train_stats, dgamma,
+                                                                  dbeta, c1, c2, mean, invstd, gamma, nullptr,
+                                                                  0);
+    }
     long n8 = rows * (C / 8);
     if (cs_ok(C / 8)) {
         bn_bwd_apply_cs_kernel<<<cs_grid(rows, C / 8), EW_BLOCK, 0, s>>>(
@@ -401,7 +491,7 @@ DDL_API void ddl_bias_grad(const void* dy, long rows, int C, int c_out, float* p
     dim3 grid;
     colreduce_grid(rows, C, &grid);
     colreduce_kernel<2><<<grid, EW_BLOCK, 0, s>>>((const uint4*)dy, nullptr, nullptr, nullptr, nullptr, part,
-                                                  rows, C, 0, 0.f);
+                                                  rows, C, 0, 0.f, 0, 0.f);
     colsum_finalize_kernel<<<FIN_GRID(c_out), FIN_BLOCK, 0, s>>>(part, grid.x, C, c_out, out);
 }
 

@@ -195,6 +195,8 @@ class ConvOp(Op):
         if bn is not None and bn.used_batch_stats and self.act in (None, "linear"):
             self.gbias.zero_()
             return
+        if bn is not None and bn.bias_grad_for is self:
+            return                      # already written by the BN's backward reduction (F.bn_bwd out_dbias)
         F.bias_grad(dy, out=self.gbias)
 
     def _fwd_onech(self, x, training):
@@ -306,6 +308,7 @@ class BNOp(Op):
         self.moving_mean = self.moving_var = None
         self.x = self.y = self.mean = self.invstd = None
         self.used_batch_stats = False
+        self.bias_grad_for = None      # ConvOp (with a fused activation) whose bias gradient our backward emits
 
     def fwd(self, x, training):
         use_batch = training and self.mode == "batch"
@@ -324,9 +327,11 @@ class BNOp(Op):
         return y
 
     def bwd(self, dy, need_dx=True, need_dw=True):
+        conv = self.bias_grad_for
         dx, _, _ = F.bn_bwd(dy, self.x, self.y, self.mean, self.invstd, self.gamma, self.post_act,
                             self.post_alpha, self.used_batch_stats, self.prev_act, self.prev_alpha,
-                            self.ggamma if need_dw else None, self.gbeta if need_dw else None)
+                            self.ggamma if need_dw else None, self.gbeta if need_dw else None,
+                            conv.gbias if (need_dw and conv is not None) else None)
         return dx
 
     def release(self):
@@ -451,6 +456,7 @@ class Network:
                     prev.next_bn = op
                 if isinstance(prev, ConvOp) and prev.act not in (None, "linear"):
                     op.prev_act, op.prev_alpha, prev.act_bwd_fused = prev.act, prev.alpha, True
+                    op.bias_grad_for = prev        # dx of this BN is the conv's dY: its column sums come for free
                 if nxt is not None and nxt.kind == "leaky_relu":
                     op.post_act, op.post_alpha, consumed = "leaky", nxt.cfg["alpha"], 2
                 elif nxt is not None and nxt.kind == "activation" and nxt.cfg["activation"] != "softmax":

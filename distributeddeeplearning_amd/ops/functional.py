@@ -125,15 +125,19 @@ def bn_apply(x, scale, shift, act=None, alpha=0.3, c_true=None):
 
 
 def bn_bwd(dy, x, y, mean, invstd, gamma, act, alpha, train_stats, prev_act=None, prev_alpha=0.3,
-           out_dgamma=None, out_dbeta=None):
+           out_dgamma=None, out_dbeta=None, out_dbias=None):
+    """`out_dbias`: also write the bias gradient of the conv/dense layer feeding this BN (the column
+    sums of dx) -- on device it comes out of the same reduction pass as dgamma/dbeta."""
     if dy.is_cuda:
         return hip_backend().bn_bwd(dy, x, y, mean, invstd, gamma, act, alpha, train_stats, prev_act,
-                                    prev_alpha, out_dgamma, out_dbeta)
+                                    prev_alpha, out_dgamma, out_dbeta, out_dbias)
     dx, dgamma, dbeta = cpu_ref.bn_bwd(dy, x, y, mean, invstd, gamma, act, alpha, train_stats, prev_act,
                                        prev_alpha)
     if out_dgamma is not None:
         out_dgamma.copy_(dgamma)
         out_dbeta.copy_(dbeta)
+    if out_dbias is not None:
+        out_dbias.copy_(cpu_ref.bias_grad(dx)[:out_dbias.numel()])
     return dx, dgamma, dbeta
 
 

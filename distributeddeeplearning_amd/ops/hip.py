@@ -48,7 +48,8 @@ _colreduce_blocks = _sig("ddl_colreduce_blocks", ci, cl, ci)
 _bn_batch_stats = _sig("ddl_bn_batch_stats", None, vp, cl, ci, vp, vp, vp, vp, vp, cf, cf, ci, ci, vp, vp, vp, vp, vp)
 _bn_infer_affine = _sig("ddl_bn_infer_affine", None, vp, vp, vp, vp, cf, ci, vp, vp, vp, vp)
 _bn_apply = _sig("ddl_bn_apply", None, vp, vp, vp, vp, cl, ci, ci, ci, cf, vp)
-_bn_bwd = _sig("ddl_bn_bwd", None, vp, vp, vp, vp, cl, ci, vp, vp, vp, ci, cf, ci, ci, cf, vp, vp, vp, vp, vp, vp)
+_bn_bwd = _sig("ddl_bn_bwd", None, vp, vp, vp, vp, cl, ci, vp, vp, vp, ci, cf, ci, ci, cf, vp, vp, vp, vp, vp, vp, ci,
+              vp)
 _bias_grad = _sig("ddl_bias_grad", None, vp, cl, ci, ci, vp, vp, vp)
 _cast = _sig("ddl_cast_f32_bf16", None, vp, vp, cl, vp)
 _relayout = _sig("ddl_relayout_alt", None, vp, vp, vp, ci, cl, vp)
@@ -178,9 +179,9 @@ def spatial_pad(x, pt, pb, pl, pr):
 
 
 # ------------------------------------------------------------------------------ batch norm
-def _part(rows, Cp, device):
+def _part(rows, Cp, device, ns=2):
     nb = _colreduce_blocks(rows, Cp)
-    return torch.empty(nb * 2 * Cp, dtype=torch.float32, device=device)
+    return torch.empty(nb * ns * Cp, dtype=torch.float32, device=device)
 
 
 def bn_train_affine(x, gamma, beta, mm, mv, momentum, eps, bessel, update_moving=True):
@@ -219,7 +220,9 @@ def bn_apply(x, scale, shift, act=None, alpha=0.3, c_true=None):
 
 
 def bn_bwd(dy, x, y, mean, invstd, gamma, act, alpha, train_stats, prev_act=None, prev_alpha=0.3,
-           out_dgamma=None, out_dbeta=None):
+           out_dgamma=None, out_dbeta=None, out_dbias=None):
+    """`out_dbias` (fp32, <= C entries): also emit the bias gradient of the conv layer feeding this BN
+    (= column sums of dx) from the same reduction pass (colreduce MODE 3)."""
     _chk_act(dy, "dy")
     _chk_act(x, "x")
     if dy.shape != x.shape:
@@ -231,7 +234,11 @@ def bn_bwd(dy, x, y, mean, invstd, gamma, act, alpha, train_stats, prev_act=None
         _chk_f32(t, Cp, n)
     dev = x.device
     dx = torch.empty_like(x)
-    part = _part(rows, Cp, dev)
+    if out_dbias is not None:
+        _chk_f32(out_dbias, None, "dbias")
+        if out_dbias.numel() > Cp:
+            raise ValueError("bn_bwd: bias gradient longer than the channel dim")
+    part = _part(rows, Cp, dev, 5 if out_dbias is not None else 2)
     coef = torch.empty(2, Cp, dtype=torch.float32, device=dev)
     if out_dgamma is None:
         out_dgamma = torch.empty(Cp, dtype=torch.float32, device=dev)
@@ -242,7 +249,7 @@ def bn_bwd(dy, x, y, mean, invstd, gamma, act, alpha, train_stats, prev_act=None
     _bn_bwd(dy.data_ptr(), x.data_ptr(), _p(y), dx.data_ptr(), rows, Cp, mean.data_ptr(), invstd.data_ptr(),
             gamma.data_ptr(), ACT_CODE[act], alpha, int(bool(train_stats)), ACT_CODE[prev_act], prev_alpha,
             part.data_ptr(), out_dgamma.data_ptr(), out_dbeta.data_ptr(), coef[0].data_ptr(),
-            coef[1].data_ptr(), _stream())
+            coef[1].data_ptr(), _p(out_dbias), 0 if out_dbias is None else out_dbias.numel(), _stream())
     _done()
     return dx, out_dgamma, out_dbeta
 

@@ -164,7 +164,7 @@ def test_dense_large_k(hip):
     close(dw, cpu_ref.conv_wgrad(x, dy, g), rtol=1e-2)
 
 
-@pytest.mark.parametrize("shape", [(2000, 7, 7, 64), (64, 13), (33, 5, 5, 19)])
+@pytest.mark.parametrize("shape", [(2000, 7, 7, 64), (64, 13), (33, 5, 5, 19), (300, 28, 28, 32)])
 @pytest.mark.parametrize("post,prev", [(None, "relu"), ("leaky", None), (None, "softsign")])
 @pytest.mark.parametrize("train", [True, False])
 def test_batchnorm(hip, shape, post, prev, train):
@@ -209,6 +209,14 @@ def test_batchnorm(hip, shape, post, prev, train):
     close(host(hip, dx, Cc), dx_ref, rtol=3e-2)
     close(dg[:Cc].cpu(), dg_ref, rtol=2e-2)
     close(db[:Cc].cpu(), db_ref, rtol=2e-2)
+    if prev:
+        # bias gradient of the conv in front (column sums of dx) out of the same reduction pass
+        dbias = torch.full((Cc,), 7.0, device="cuda")
+        dx2, dg2, db2 = hip.bn_bwd(dev(hip, dy), xd, y, mean_d, invstd_d, gd, post, 0.3, train, prev,
+                                   out_dbias=dbias)
+        assert torch.equal(dx2, dx) and torch.equal(dg2, dg) and torch.equal(db2, db)
+        ref = cpu_ref.bias_grad(dx_ref)
+        close(dbias.cpu(), ref, rtol=2e-2, atol=2e-3 * float(dx_ref.abs().sum(tuple(range(dx_ref.dim() - 1))).max()))
 
 
 @pytest.mark.parametrize("kind", ["relu", "sigmoid", "softplus", "tanh", "softsign", "leaky", "tanh01"])
