@@ -137,8 +137,15 @@ class GANTrainer:
         """Forward/backward of the discriminator phase; leaves averaged grads in D.G."""
         B = real.shape[0]
         z = self.rng.uniform((B, self.cfg.noise_dim), self.G.cdtype)
-        fake = self.G.forward(z, training=False)               # generator.predict(noise)
-        xs = torch.cat([real, fake], 0)
+        if self.G.can_forward_into() and real.is_contiguous():
+            # [real ; fake] assembled in place: the generator's last kernel writes straight into the
+            # second half of the discriminator batch (no 2B-image concat copy)
+            xs = torch.empty((2 * B,) + tuple(real.shape[1:]), dtype=real.dtype, device=real.device)
+            xs[:B].copy_(real)
+            self.G.forward(z, training=False, out=xs[B:])      # generator.predict(noise)
+        else:
+            fake = self.G.forward(z, training=False)
+            xs = torch.cat([real, fake], 0)
         feat = self.D.forward(xs, training=True, stop=-1)
         loss, dfeat = self._d_head(feat, B, 1.0, 0.0, True, True)
         self.D.backward(dfeat, need_input_grad=False, start=-1)

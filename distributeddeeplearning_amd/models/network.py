@@ -146,6 +146,7 @@ class ConvOp(Op):
         self.onech = None               # None | "in" (Conv2D 1->N) | "out" (Conv2DTranspose C->1)
         self.g1 = None                  # the equivalent 1x1 geometry on the taps-as-channels tensor
         self.w_tap = self.w_tapT = None
+        self.out_buffer = None          # optional destination of the next forward's output ("out" path only)
 
     def _p(self, c):
         return _round_up(c, self.cpad)
@@ -208,7 +209,7 @@ class ConvOp(Op):
                 self.x, self.y = xc, y
         else:                           # 1x1 conv to taps -> col2im fold with bias + activation
             z = hip.conv_fprop(x, self.w_main.reshape(g1.O, 1, 1, -1), None, g1)
-            y = hip.col2im_1ch(z, g, self.bias, self.act, self.alpha)
+            y = hip.col2im_1ch(z, g, self.bias, self.act, self.alpha, out=self.out_buffer)
             if training:
                 self.x, self.y = x, y
         return y
@@ -673,11 +674,26 @@ class Network:
             return F.hip_backend().strip_channels(y, c_true)
         return y.float()
 
-    def forward(self, x, training: bool = False, start: int = 0, stop: Optional[int] = None):
+    def forward(self, x, training: bool = False, start: int = 0, stop: Optional[int] = None, out=None):
+        """`out`: destination for the network's output when its last op can write in place of
+        allocating (`can_forward_into()`); lets a caller assemble a batch without a concat copy."""
         stop = len(self.ops) if stop is None else (stop if stop >= 0 else len(self.ops) + stop)
-        for op in self.ops[start:stop]:
-            x = op.fwd(x, training)
+        last = self.ops[-1] if self.ops else None
+        if out is not None:
+            if not (stop == len(self.ops) and self.can_forward_into()):
+                raise ValueError("forward(out=...) needs a final single-channel transposed conv on device")
+            last.out_buffer = out
+        try:
+            for op in self.ops[start:stop]:
+                x = op.fwd(x, training)
+        finally:
+            if out is not None:
+                last.out_buffer = None
         return x
+
+    def can_forward_into(self) -> bool:
+        last = self.ops[-1] if self.ops else None
+        return isinstance(last, ConvOp) and last.onech == "out"
 
     def backward(self, dy, need_input_grad: bool = False, need_dw: bool = True,
                  start: Optional[int] = None):

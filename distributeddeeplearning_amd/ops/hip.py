@@ -329,8 +329,9 @@ def im2col_1ch(img, g: ConvGeom):
     return col
 
 
-def col2im_1ch(col, g: ConvGeom, bias=None, act=None, alpha=0.3):
-    """taps-as-channels [B][g.OH][g.OW][pad8(T)] -> single-channel image [B][g.H][g.W][8] = act(bias + fold)."""
+def col2im_1ch(col, g: ConvGeom, bias=None, act=None, alpha=0.3, out=None):
+    """taps-as-channels [B][g.OH][g.OW][pad8(T)] -> single-channel image [B][g.H][g.W][8] = act(bias + fold).
+    `out`: write into this (contiguous, same shape) tensor instead of a fresh one."""
     _chk_act(col, "col")
     B = col.shape[0]
     Tp = pad8(g.KH * g.KW)
@@ -338,7 +339,13 @@ def col2im_1ch(col, g: ConvGeom, bias=None, act=None, alpha=0.3):
         raise ValueError(f"col2im_1ch: col {tuple(col.shape)} vs geometry {g}")
     if bias is not None:
         _chk_f32(bias, 1, "bias")
-    img = torch.empty(B, g.H, g.W, 8, dtype=torch.bfloat16, device=col.device)
+    if out is not None:
+        _chk_act(out, "out")
+        if tuple(out.shape) != (B, g.H, g.W, 8):
+            raise ValueError(f"col2im_1ch: out {tuple(out.shape)} != {(B, g.H, g.W, 8)}")
+        img = out
+    else:
+        img = torch.empty(B, g.H, g.W, 8, dtype=torch.bfloat16, device=col.device)
     rc = _col2im(col.data_ptr(), img.data_ptr(), _p(bias), B, g.H, g.W, g.OH, g.OW, g.KH, g.KW, g.sh, g.sw, g.dh,
                  g.dw, g.pt, g.pl, Tp, ACT_CODE[act], alpha, _stream())
     if rc:
