@@ -650,8 +650,9 @@ DDL_API void ddl_affine(const void* x, void* y, long rows, int C, int c_true, fl
 //   col2im : img[b][h][w][0]   = act(bias + sum_t col[b][(h + pt - kh*dh)/sh][(w + pl - kw*dw)/sw][t])
 struct OneChGeom { int H, W, OH, OW, KH, KW, sh, sw, dh, dw, pt, pl, T, Tp, Ci; };
 
-__global__ void im2col_1ch_kernel(const bf16_t* __restrict__ img, uint4* __restrict__ col, long n_units,
-                                  const OneChGeom g) {
+// Generic fallback (planes too large for LDS): one thread per 8 taps, gathers straight from global memory.
+__global__ void im2col_1ch_generic_kernel(const bf16_t* __restrict__ img, uint4* __restrict__ col, long n_units,
+                                          const OneChGeom g) {
     const int tg = g.Tp / 8;
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n_units; i += (long)gridDim.x * blockDim.x) {
         int t8 = (int)(i % tg);
@@ -677,26 +678,81 @@ __global__ void im2col_1ch_kernel(const bf16_t* __restrict__ img, uint4* __restr
     }
 }
 
+// floor(x / d) for 0 <= x < 2^22 through the reciprocal (exact in that range)
+__device__ __forceinline__ int fdiv_small(int x, float inv) { return __float2int_rz(((float)x + 0.5f) * inv); }
+
+// LDS-staged im2col: a block owns `ipb` images.  Their real channel is staged once as zero-haloed planes
+// [PH][PW] (halo = every out-of-image tap position, so the gather needs no bounds test), a small table
+// maps tap -> plane offset, and then consecutive lanes emit consecutive 16-byte groups of 8 taps: eight
+// 2-byte LDS reads and one coalesced global store each, no integer division anywhere in the loop.
+__global__ __launch_bounds__(256) void im2col_1ch_kernel(const bf16_t* __restrict__ img, uint4* __restrict__ col,
+                                                         int B, const OneChGeom g, int ipb, int PH, int PW) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    int* tap = (int*)smem;                                   // [Tp] plane offset of tap t (-1: padding tap)
+    bf16_t* plane = (bf16_t*)(smem + g.Tp * 4);             // [ipb][PH*PW]
+    const int b0 = blockIdx.x * ipb;
+    const int nimg = min(ipb, B - b0);
+    const int psz = PH * PW;
+    const float invPW = 1.0f / (float)PW;
+    for (int t = threadIdx.x; t < g.Tp; t += 256) {
+        int kh = t / g.KW, kw = t - kh * g.KW;
+        tap[t] = t < g.T ? kh * g.dh * PW + kw * g.dw : -1;
+    }
+    for (int i = threadIdx.x; i < nimg * psz; i += 256) {
+        const int im = fdiv_small(i, 1.0f / (float)psz), e = i - im * psz;
+        const int r = fdiv_small(e, invPW), c = e - r * PW;
+        const int ih = r - g.pt, iw = c - g.pl;
+        bf16_t v = 0;
+        if ((unsigned)ih < (unsigned)g.H && (unsigned)iw < (unsigned)g.W)
+            v = img[(((long)(b0 + im) * g.H + ih) * g.W + iw) * g.Ci];
+        plane[i] = v;
+    }
+    __syncthreads();
+    const int tg = g.Tp / 8, npix = g.OH * g.OW, per_img = npix * tg;
+    const float inv_tg = 1.0f / (float)tg, invOW = 1.0f / (float)g.OW, inv_per = 1.0f / (float)per_img;
+    uint4* out = col + (long)b0 * per_img;
+    for (int u = threadIdx.x; u < nimg * per_img; u += 256) {
+        const int im = fdiv_small(u, inv_per), e = u - im * per_img;
+        const int p = fdiv_small(e, inv_tg), t8 = e - p * tg;
+        const int oh = fdiv_small(p, invOW), ow = p - oh * g.OW;
+        const bf16_t* src = plane + im * psz + oh * g.sh * PW + ow * g.sw;
+        uint32_t w[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int off = tap[t8 * 8 + j];
+            uint32_t v = src[off < 0 ? 0 : off];
+            v = off < 0 ? 0u : v;
+            w[j >> 1] |= v << ((j & 1) * 16);
+        }
+        out[u] = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+}
+
 // One block per (image, band of output rows): the band's slice of the taps-as-channels tensor is
 // staged into LDS with coalesced 16-byte loads (it is read up to KH*KW times, two bytes at a time, by
 // the fold), then every thread folds pixels.  LDS rows are padded by 4 B so the 2-byte gathers of
-// neighbouring pixels spread over the banks.
+// neighbouring pixels spread over the banks.  SH / SW: compile-time strides (1 | 2; 0 = runtime): the
+// fold's divisibility tests and divisions cost more than its loads when they are runtime integers
+// (measured 34 us for a 50 MB tensor: ALU-bound at 1.5 TB/s).
+template <int SH, int SW>
 __global__ __launch_bounds__(256) void col2im_1ch_kernel(const bf16_t* __restrict__ col, uint4* __restrict__ img,
                                                          const OneChGeom g, const float* __restrict__ bias, int act,
                                                          float alpha, int band_rows) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int sh = SH ? SH : g.sh, sw = SW ? SW : g.sw;
     const int b = blockIdx.x;
     const int h0 = blockIdx.y * band_rows, h1 = min(g.H, h0 + band_rows);
     const int pitch = g.Tp * 2 + 4;
     int lo = h0 + g.pt - (g.KH - 1) * g.dh;                  // smallest th of the band
-    const int oh_lo = lo <= 0 ? 0 : (lo + g.sh - 1) / g.sh;
-    const int oh_hi = min(g.OH - 1, (h1 - 1 + g.pt) / g.sh);
+    const int oh_lo = lo <= 0 ? 0 : (lo + sh - 1) / sh;
+    const int oh_hi = min(g.OH - 1, (h1 - 1 + g.pt) / sh);
     const int nrows = oh_hi - oh_lo + 1;
     const bf16_t* base = col + ((long)b * g.OH + oh_lo) * g.OW * g.Tp;
     if (nrows > 0) {
         const int u_per = g.Tp / 8;
+        const float inv_u = 1.0f / (float)u_per;
         for (int u = threadIdx.x; u < nrows * g.OW * u_per; u += 256) {
-            int p = u / u_per, c8 = u - p * u_per;
+            int p = fdiv_small(u, inv_u), c8 = u - p * u_per;
             uint4 v = *(const uint4*)(base + (long)p * g.Tp + c8 * 8);
             uint32_t* d = (uint32_t*)(smem + p * pitch + c8 * 16);
             d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
@@ -704,20 +760,22 @@ __global__ __launch_bounds__(256) void col2im_1ch_kernel(const bf16_t* __restric
     }
     __syncthreads();
     const float b0 = bias ? bias[0] : 0.f;
+    const float invW = 1.0f / (float)g.W;
     for (int i = threadIdx.x; i < (h1 - h0) * g.W; i += 256) {
-        int hl = i / g.W, w = i - hl * g.W, h = h0 + hl;
+        int hl = fdiv_small(i, invW), w = i - hl * g.W, h = h0 + hl;
         float acc = 0.f;
         for (int kh = 0; kh < g.KH; ++kh) {
             int th = h + g.pt - kh * g.dh;
-            if (th < 0 || th % g.sh) continue;
-            int oh = th / g.sh;
+            if (th < 0 || th % sh) continue;
+            int oh = th / sh;
             if (oh > oh_hi) continue;
+            const char* row = smem + (oh - oh_lo) * g.OW * pitch + kh * g.KW * 2;
             for (int kw = 0; kw < g.KW; ++kw) {
                 int tw = w + g.pl - kw * g.dw;
-                if (tw < 0 || tw % g.sw) continue;
-                int ow = tw / g.sw;
+                if (tw < 0 || tw % sw) continue;
+                int ow = tw / sw;
                 if (ow >= g.OW) continue;
-                acc += bf2f(*(const bf16_t*)(smem + ((oh - oh_lo) * g.OW + ow) * pitch + (kh * g.KW + kw) * 2));
+                acc += bf2f(*(const bf16_t*)(row + ow * pitch + kw * 2));
             }
         }
         float v = act_apply(acc + b0, act, alpha);
@@ -729,8 +787,22 @@ DDL_API int ddl_im2col_1ch(const void* img, void* col, int B, int H, int W, int 
                            int sh, int sw, int dh, int dw, int pt, int pl, int Tp, hipStream_t s) {
     if (Tp % 8 || Tp < KH * KW || Ci <= 0) return -1;
     OneChGeom g{H, W, OH, OW, KH, KW, sh, sw, dh, dw, pt, pl, KH * KW, Tp, Ci};
-    long n = (long)B * OH * OW * (Tp / 8);
-    im2col_1ch_kernel<<<ew_grid(n), EW_BLOCK, 0, s>>>((const bf16_t*)img, (uint4*)col, n, g);
+    // zero-haloed plane covering every tap position: rows -pt .. (OH-1)*sh + (KH-1)*dh - pt
+    const long PH = (long)(OH - 1) * sh + (long)(KH - 1) * dh + 1, PW = (long)(OW - 1) * sw + (long)(KW - 1) * dw + 1;
+    const long psz = PH * PW, per_img = (long)OH * OW * (Tp / 8);
+    if (B > 0 && psz * 2 + Tp * 4 <= 48 * 1024 && per_img < (1L << 20)) {
+        long ipb = 4096 / per_img;                               // >= ~16 stores per thread and block
+        if (ipb < 1) ipb = 1;
+        while (ipb > 1 && (ipb * psz * 2 + Tp * 4 > 48 * 1024 || ipb * per_img >= (1L << 21) || ipb * psz >= (1L << 21)))
+            --ipb;
+        while (ipb > 1 && (B + ipb - 1) / ipb < 1024) --ipb;     // keep >= 4 blocks per CU when the batch allows
+        const int blocks = (int)((B + ipb - 1) / ipb);
+        const size_t smem = (size_t)(ipb * psz * 2 + Tp * 4);
+        im2col_1ch_kernel<<<blocks, 256, smem, s>>>((const bf16_t*)img, (uint4*)col, B, g, (int)ipb, (int)PH, (int)PW);
+        return 0;
+    }
+    long n = (long)B * per_img;
+    im2col_1ch_generic_kernel<<<ew_grid(n), EW_BLOCK, 0, s>>>((const bf16_t*)img, (uint4*)col, n, g);
     return 0;
 }
 
@@ -747,15 +819,18 @@ DDL_API int ddl_col2im_1ch(const void* col, void* img, const float* bias, int B,
     while (band > 1 && ((size_t)((band - 1) / sh + halo)) * row_bytes > 40 * 1024) band = (band + 1) / 2;
     size_t smem = ((size_t)((band - 1) / sh + halo)) * row_bytes;
     if (smem > 160 * 1024) return -2;
+    if ((long)((band - 1) / sh + halo) * OW * (Tp / 8) >= (1L << 21) || (long)band * W >= (1L << 21)) return -2;
+    auto kern = (sh == 1 && sw == 1) ? col2im_1ch_kernel<1, 1>
+              : (sh == 2 && sw == 2) ? col2im_1ch_kernel<2, 2> : col2im_1ch_kernel<0, 0>;
     if (smem > 64 * 1024) {
-        static bool done = false;
-        if (!done) {
-            hipFuncSetAttribute((const void*)col2im_1ch_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            done = true;
+        static bool done[3] = {false, false, false};
+        const int v = (sh == 1 && sw == 1) ? 0 : ((sh == 2 && sw == 2) ? 1 : 2);
+        if (!done[v]) {
+            hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            done[v] = true;
         }
     }
-    col2im_1ch_kernel<<<dim3(B, (H + band - 1) / band), 256, smem, s>>>((const bf16_t*)col, (uint4*)img, g, bias, act,
-                                                                        alpha, band);
+    kern<<<dim3(B, (H + band - 1) / band), 256, smem, s>>>((const bf16_t*)col, (uint4*)img, g, bias, act, alpha, band);
     return 0;
 }
 

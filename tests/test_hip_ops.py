@@ -328,3 +328,59 @@ def test_philox(hip):
     assert int(st[1]) == 2
     assert a.min() >= -1 and a.max() <= 1 and not torch.equal(a, b)
     assert abs(float(a.mean())) < 0.01 and abs(float(a.var()) - 1 / 3) < 0.01
+
+
+ONECH_CASES = [
+    # H, W, k, s, d, padding   (forward geometry of a Conv2D 1->N; its adjoint is the Conv2DTranspose N->1 fold)
+    (28, 28, (5, 5), (2, 2), (1, 1), "same"),        # D1 / its dgrad
+    (28, 28, (5, 5), (1, 1), (1, 1), "same"),        # G6
+    (28, 28, (3, 2), (1, 2), (2, 1), "valid"),
+    (64, 64, (5, 5), (2, 2), (1, 1), "same"),        # dcgan64
+    (9, 11, (1, 1), (3, 3), (1, 1), "valid"),
+]
+
+
+@pytest.mark.parametrize("case", ONECH_CASES)
+@pytest.mark.parametrize("B", [1, 37])
+def test_onech_im2col_col2im(hip, case, B):
+    """Single-channel path: im2col is pure data movement (bit-exact vs an index gather), col2im is its
+    adjoint with fused bias + activation."""
+    H, W, k, s, d, pad = case
+    g = G.conv2d_geom(H, W, 1, 8, k, s, d, pad)
+    T, Tp = g.KH * g.KW, hip.pad8(g.KH * g.KW)
+    torch.manual_seed(11)
+    img = r16(torch.randn(B, H, W, 1))
+    ref = torch.zeros(B, g.OH, g.OW, Tp)
+    for kh in range(g.KH):
+        for kw in range(g.KW):
+            for oh in range(g.OH):
+                ih = oh * g.sh + kh * g.dh - g.pt
+                if not 0 <= ih < H:
+                    continue
+                for ow in range(g.OW):
+                    iw = ow * g.sw + kw * g.dw - g.pl
+                    if 0 <= iw < W:
+                        ref[:, oh, ow, kh * g.KW + kw] = img[:, ih, iw, 0]
+    col = hip.im2col_1ch(dev(hip, img), g)
+    assert col.shape == (B, g.OH, g.OW, Tp)
+    assert torch.equal(col.float().cpu(), ref)
+    # fold: <col2im(c), img> == <c, im2col(img)> for every c  =>  check against the explicit scatter-add
+    c = r16(torch.randn(B, g.OH, g.OW, Tp) * 0.5)
+    c[..., T:] = 0
+    fold = torch.zeros(B, H, W)
+    for kh in range(g.KH):
+        for kw in range(g.KW):
+            for oh in range(g.OH):
+                ih = oh * g.sh + kh * g.dh - g.pt
+                if not 0 <= ih < H:
+                    continue
+                for ow in range(g.OW):
+                    iw = ow * g.sw + kw * g.dw - g.pl
+                    if 0 <= iw < W:
+                        fold[:, ih, iw] += c[:, oh, ow, kh * g.KW + kw]
+    bias = torch.tensor([0.25], device="cuda")
+    out = hip.col2im_1ch(c.bfloat16().cuda().contiguous(), g, bias, "tanh")
+    close(out[..., 0].float().cpu(), torch.tanh(fold + 0.25), atol=2e-2)
+    assert float(out[..., 1:].float().abs().max()) == 0.0
+    plain = hip.col2im_1ch(c.bfloat16().cuda().contiguous(), g)
+    close(plain[..., 0].float().cpu(), fold, rtol=2e-2)
