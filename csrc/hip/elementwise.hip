@@ -308,17 +308,37 @@ DDL_API void ddl_bn_infer_affine(const float* gamma, const float* beta, const fl
     bn_infer_affine_kernel<<<(C + 127) / 128, 128, 0, s>>>(gamma, beta, mm, mv, eps, C, scale, shift, invstd);
 }
 
+// (scale, shift) of 8 channels.  With moving statistics given (inference-phase BN), `scale` / `shift`
+// are gamma / beta and the affine is derived here: no separate bn_infer_affine launch.
+__device__ __forceinline__ void bn_affine8(const float* __restrict__ scale, const float* __restrict__ shift,
+                                           const float* __restrict__ mm, const float* __restrict__ mv, float eps,
+                                           int c0, float* sc, float* sh) {
+    const float4 sa = *(const float4*)(scale + c0), sb = *(const float4*)(scale + c0 + 4);
+    const float4 ha = *(const float4*)(shift + c0), hb = *(const float4*)(shift + c0 + 4);
+    const float s_[8] = {sa.x, sa.y, sa.z, sa.w, sb.x, sb.y, sb.z, sb.w};
+    const float h_[8] = {ha.x, ha.y, ha.z, ha.w, hb.x, hb.y, hb.z, hb.w};
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { sc[j] = s_[j]; sh[j] = h_[j]; }
+    if (mm) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float k = sc[j] * rsqrtf(mv[c0 + j] + eps);
+            sh[j] = sh[j] - mm[c0 + j] * k;
+            sc[j] = k;
+        }
+    }
+}
+
 __global__ void bn_apply_kernel(const uint4* __restrict__ x, uint4* __restrict__ y,
                                 const float* __restrict__ scale, const float* __restrict__ shift, long n8,
-                                int cg, int c_true, int act, float alpha) {
+                                int cg, int c_true, int act, float alpha, const float* __restrict__ mm,
+                                const float* __restrict__ mv, float eps) {
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n8; i += (long)gridDim.x * blockDim.x) {
         int c0 = (int)(i % cg) * 8;
         float f[8];
         unpack8(x[i], f);
-        const float4 sa = *(const float4*)(scale + c0), sb = *(const float4*)(scale + c0 + 4);
-        const float4 ha = *(const float4*)(shift + c0), hb = *(const float4*)(shift + c0 + 4);
-        const float sc[8] = {sa.x, sa.y, sa.z, sa.w, sb.x, sb.y, sb.z, sb.w};
-        const float sh[8] = {ha.x, ha.y, ha.z, ha.w, hb.x, hb.y, hb.z, hb.w};
+        float sc[8], sh[8];
+        bn_affine8(scale, shift, mm, mv, eps, c0, sc, sh);
 #pragma unroll
         for (int j = 0; j < 8; ++j)
             f[j] = (c0 + j < c_true) ? act_apply(fmaf(f[j], sc[j], sh[j]), act, alpha) : 0.f;
@@ -331,13 +351,13 @@ __global__ void bn_apply_kernel(const uint4* __restrict__ x, uint4* __restrict__
 __global__ __launch_bounds__(EW_BLOCK) void bn_apply_cs_kernel(const uint4* __restrict__ x, uint4* __restrict__ y,
                                                                const float* __restrict__ scale,
                                                                const float* __restrict__ shift, long rows, int cg,
-                                                               int c_true, int act, float alpha) {
+                                                               int c_true, int act, float alpha,
+                                                               const float* __restrict__ mm,
+                                                               const float* __restrict__ mv, float eps) {
     const int g = threadIdx.x % cg, rl = threadIdx.x / cg, rpi = EW_BLOCK / cg;
     const int c0 = g * 8;
-    const float4 sa = *(const float4*)(scale + c0), sb = *(const float4*)(scale + c0 + 4);
-    const float4 ha = *(const float4*)(shift + c0), hb = *(const float4*)(shift + c0 + 4);
-    const float sc[8] = {sa.x, sa.y, sa.z, sa.w, sb.x, sb.y, sb.z, sb.w};
-    const float sh[8] = {ha.x, ha.y, ha.z, ha.w, hb.x, hb.y, hb.z, hb.w};
+    float sc[8], sh[8];
+    bn_affine8(scale, shift, mm, mv, eps, c0, sc, sh);
     for (long r = blockIdx.x * (long)rpi + rl; r < rows; r += (long)gridDim.x * rpi) {
         float f[8];
         unpack8(x[r * cg + g], f);
@@ -355,16 +375,29 @@ static inline int cs_grid(long rows, int cg) {
     return (int)(g < 1 ? 1 : (g > EW_MAX_GRID ? EW_MAX_GRID : g));
 }
 
-DDL_API void ddl_bn_apply(const void* x, void* y, const float* scale, const float* shift, long rows, int C,
-                          int c_true, int act, float alpha, hipStream_t s) {
+static void bn_apply_launch(const void* x, void* y, const float* scale, const float* shift, long rows, int C,
+                            int c_true, int act, float alpha, const float* mm, const float* mv, float eps,
+                            hipStream_t s) {
     long n8 = rows * (C / 8);
     if (cs_ok(C / 8)) {
         bn_apply_cs_kernel<<<cs_grid(rows, C / 8), EW_BLOCK, 0, s>>>((const uint4*)x, (uint4*)y, scale, shift, rows,
-                                                                   C / 8, c_true, act, alpha);
+                                                                   C / 8, c_true, act, alpha, mm, mv, eps);
         return;
     }
     bn_apply_kernel<<<ew_grid(n8), EW_BLOCK, 0, s>>>((const uint4*)x, (uint4*)y, scale, shift, n8, C / 8,
-                                                     c_true, act, alpha);
+                                                     c_true, act, alpha, mm, mv, eps);
+}
+
+DDL_API void ddl_bn_apply(const void* x, void* y, const float* scale, const float* shift, long rows, int C,
+                          int c_true, int act, float alpha, hipStream_t s) {
+    bn_apply_launch(x, y, scale, shift, rows, C, c_true, act, alpha, nullptr, nullptr, 0.f, s);
+}
+
+// Inference-phase BN in one launch: y = act(gamma * (x - moving_mean) * rsqrt(moving_var + eps) + beta).
+DDL_API void ddl_bn_apply_infer(const void* x, void* y, const float* gamma, const float* beta, const float* mm,
+                                const float* mv, float eps, long rows, int C, int c_true, int act, float alpha,
+                                hipStream_t s) {
+    bn_apply_launch(x, y, gamma, beta, rows, C, c_true, act, alpha, mm, mv, eps, s);
 }
 
 // BN backward: reduce -> finalize (dgamma, dbeta, c1 = dbeta/M, c2 = dgamma/M) -> apply.

@@ -188,7 +188,17 @@ __global__ __launch_bounds__(256) void head_finalize_kernel(const float* __restr
     const int cl = threadIdx.x & 31, lb = threadIdx.x >> 5;
     const int k = blockIdx.x * 32 + cl;
     double s = 0;
-    if (k < K) for (int b = lb; b < nblocks; b += 8) s += dw_part[(size_t)b * K + k];
+    if (k < K) {
+        int b = lb;
+        for (; b + 56 < nblocks; b += 64) {      // eight independent loads per trip, summed in a fixed order
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = dw_part[(size_t)(b + 8 * u) * K + k];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s += v[u];
+        }
+        for (; b < nblocks; b += 8) s += dw_part[(size_t)b * K + k];
+    }
     fin[lb][cl] = s;
     __syncthreads();
     if (lb == 0 && k < K) {

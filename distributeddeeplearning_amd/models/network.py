@@ -313,6 +313,9 @@ class BNOp(Op):
 
     def fwd(self, x, training):
         use_batch = training and self.mode == "batch"
+        if not training:            # pure inference: one fused launch, nothing kept
+            return F.bn_apply_infer(x, self.gamma, self.beta, self.moving_mean, self.moving_var, self.eps,
+                                    self.post_act, self.post_alpha, self.C)
         if use_batch:
             scale, shift, mean, invstd = F.bn_train_affine(x, self.gamma, self.beta, self.moving_mean,
                                                            self.moving_var, self.momentum, self.eps,

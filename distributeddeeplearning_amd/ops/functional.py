@@ -118,6 +118,14 @@ def bn_infer_affine(gamma, beta, mm, mv, eps):
     return scale, beta - mm * scale, invstd
 
 
+def bn_apply_infer(x, gamma, beta, mm, mv, eps, act=None, alpha=0.3, c_true=None):
+    """y = act(BN(x)) with the moving statistics, nothing saved for a backward pass."""
+    if x.is_cuda:
+        return hip_backend().bn_apply_infer(x, gamma, beta, mm, mv, eps, act, alpha, c_true)
+    scale, shift, _ = bn_infer_affine(gamma, beta, mm, mv, eps)
+    return cpu_ref.bn_apply(x, scale, shift, act, alpha)
+
+
 def bn_apply(x, scale, shift, act=None, alpha=0.3, c_true=None):
     if x.is_cuda:
         return hip_backend().bn_apply(x, scale, shift, act, alpha, c_true)

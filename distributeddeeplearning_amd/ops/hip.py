@@ -48,6 +48,7 @@ _colreduce_blocks = _sig("ddl_colreduce_blocks", ci, cl, ci)
 _bn_batch_stats = _sig("ddl_bn_batch_stats", None, vp, cl, ci, vp, vp, vp, vp, vp, cf, cf, ci, ci, vp, vp, vp, vp, vp)
 _bn_infer_affine = _sig("ddl_bn_infer_affine", None, vp, vp, vp, vp, cf, ci, vp, vp, vp, vp)
 _bn_apply = _sig("ddl_bn_apply", None, vp, vp, vp, vp, cl, ci, ci, ci, cf, vp)
+_bn_apply_infer = _sig("ddl_bn_apply_infer", None, vp, vp, vp, vp, vp, vp, cf, cl, ci, ci, ci, cf, vp)
 _bn_bwd = _sig("ddl_bn_bwd", None, vp, vp, vp, vp, cl, ci, vp, vp, vp, ci, cf, ci, ci, cf, vp, vp, vp, vp, vp, vp, ci,
               vp)
 _bias_grad = _sig("ddl_bias_grad", None, vp, cl, ci, ci, vp, vp, vp)
@@ -215,6 +216,19 @@ def bn_apply(x, scale, shift, act=None, alpha=0.3, c_true=None):
     y = torch.empty_like(x)
     _bn_apply(x.data_ptr(), y.data_ptr(), scale.data_ptr(), shift.data_ptr(), rows, Cp,
               Cp if c_true is None else c_true, ACT_CODE[act], alpha, _stream())
+    _done()
+    return y
+
+
+def bn_apply_infer(x, gamma, beta, mm, mv, eps, act=None, alpha=0.3, c_true=None):
+    """Inference-phase BN (moving statistics) + activation in ONE launch."""
+    _chk_act(x, "x")
+    rows, Cp = _rows_c(x)
+    for t, n in ((gamma, "gamma"), (beta, "beta"), (mm, "moving_mean"), (mv, "moving_var")):
+        _chk_f32(t, Cp, n)
+    y = torch.empty_like(x)
+    _bn_apply_infer(x.data_ptr(), y.data_ptr(), gamma.data_ptr(), beta.data_ptr(), mm.data_ptr(), mv.data_ptr(), eps,
+                    rows, Cp, Cp if c_true is None else c_true, ACT_CODE[act], alpha, _stream())
     _done()
     return y
 

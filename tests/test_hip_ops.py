@@ -203,6 +203,10 @@ def test_batchnorm(hip, shape, post, prev, train):
     y_ref = cpu_ref.bn_apply(x, sc, beta - mean * sc, post)
     y = hip.bn_apply(xd, scale, shift, post, 0.3, Cc)
     close(host(hip, y, Cc), y_ref)
+    if not train:       # the single-launch inference form computes the same affine inside the kernel
+        y1 = hip.bn_apply_infer(xd, gd, bd, mmd, mvd, 1e-3, post, 0.3, Cc)
+        close(host(hip, y1, Cc), y_ref)
+        assert float(y1[..., Cc:].float().abs().max()) == 0.0 if Cp > Cc else True
     dy = r16(torch.randn(*shape))
     dx_ref, dg_ref, db_ref = cpu_ref.bn_bwd(dy, x, r16(y_ref), mean, invstd, gamma, post, 0.3, train, prev)
     dx, dg, db = hip.bn_bwd(dev(hip, dy), xd, y, mean_d, invstd_d, gd, post, 0.3, train, prev)
