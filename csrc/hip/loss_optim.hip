@@ -182,7 +182,9 @@ __global__ __launch_bounds__(HEAD_ROWS * 64) void dense1_bce_kernel(
 // dw[k] = sum_b dw_part[b][k]: 256 threads = 32 k-columns x 8 partial lanes; block 0 also sums db.
 __global__ __launch_bounds__(256) void head_finalize_kernel(const float* __restrict__ dw_part, int nblocks, int K,
                                                             const float* __restrict__ dlogit, int M,
-                                                            float* __restrict__ dw, float* __restrict__ db) {
+                                                            float* __restrict__ dw, float* __restrict__ db,
+                                                            const float* __restrict__ rowloss,
+                                                            float* __restrict__ loss_out) {
     __shared__ double fin[8][33];
     __shared__ float wsum[4];
     const int cl = threadIdx.x & 31, lb = threadIdx.x >> 5;
@@ -215,6 +217,16 @@ __global__ __launch_bounds__(256) void head_finalize_kernel(const float* __restr
         __syncthreads();
         if (threadIdx.x == 0) db[0] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
     }
+    if (blockIdx.x == gridDim.x - 1 && loss_out) {     // mean loss (saves the separate mean_kernel launch)
+        __shared__ double lsum[4];
+        double t = 0;
+        for (int i = threadIdx.x; i < M; i += 256) t += rowloss[i];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) t += __shfl_xor(t, o, 64);
+        if ((threadIdx.x & 63) == 0) lsum[threadIdx.x >> 6] = t;
+        __syncthreads();
+        if (threadIdx.x == 0) loss_out[0] = (float)((lsum[0] + lsum[1] + lsum[2] + lsum[3]) / (double)M);
+    }
 }
 
 DDL_API int ddl_dense1_bce_blocks(int M) {
@@ -231,8 +243,13 @@ DDL_API int ddl_dense1_bce(const void* x, const void* w, const float* bias, floa
     dense1_bce_kernel<<<nb, HEAD_ROWS * 64, 0, s>>>((const uint4*)x, (const bf16_t*)w, bias, label_first,
                                                     label_second, n_first, M, K, (uint4*)dx, dw_part, logits,
                                                     rowloss, dlogit, want_dx, want_dw);
+    if (want_dw) {
+        const int fb = (K + 31) / 32;
+        head_finalize_kernel<<<fb, 256, 0, s>>>(dw_part, nb, K, dlogit, M, dw, db, rowloss,
+                                                fb > 1 ? loss_out : nullptr);
+        if (fb > 1) return 0;
+    }
     mean_kernel<<<1, LB, 0, s>>>(rowloss, M, 1.0 / (double)M, loss_out);
-    if (want_dw) head_finalize_kernel<<<(K + 31) / 32, 256, 0, s>>>(dw_part, nb, K, dlogit, M, dw, db);
     return 0;
 }
 

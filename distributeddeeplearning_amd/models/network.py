@@ -146,6 +146,7 @@ class ConvOp(Op):
         self.onech = None               # None | "in" (Conv2D 1->N) | "out" (Conv2DTranspose C->1)
         self.g1 = None                  # the equivalent 1x1 geometry on the taps-as-channels tensor
         self.w_tap = self.w_tapT = None
+        self._gbias_is_zero = False     # gbias currently holds the exact-zero gradient written by _bias_grad
         self.out_buffer = None          # optional destination of the next forward's output ("out" path only)
 
     def _p(self, c):
@@ -194,10 +195,13 @@ class ConvOp(Op):
         bias gradient is identically zero (BN subtracts the batch mean): no reduction pass at all."""
         bn = self.next_bn
         if bn is not None and bn.used_batch_stats and self.act in (None, "linear"):
-            self.gbias.zero_()
+            if not self._gbias_is_zero:         # only this method ever writes the slot: zero it once, not per step
+                self.gbias.zero_()
+                self._gbias_is_zero = True
             return
         if bn is not None and bn.bias_grad_for is self:
             return                      # already written by the BN's backward reduction (F.bn_bwd out_dbias)
+        self._gbias_is_zero = False
         F.bias_grad(dy, out=self.gbias)
 
     def _fwd_onech(self, x, training):
