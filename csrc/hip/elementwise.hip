@@ -236,9 +236,10 @@ static inline void colreduce_grid(long rows, int C, dim3* grid) {
     int cg = C / 8;
     int cgl = cg < EW_BLOCK ? cg : EW_BLOCK;
     int rpi = EW_BLOCK / cgl;
-    // cache-resident tensors (< 64 MB): one block per CU and a short finalize; larger ones stream from HBM and
-    // need four blocks per CU to keep enough loads in flight (measured: classifier step -6 %, dcgan64 -7 %)
-    static const long small_cap = getenv("DDL_CR_SMALL_CAP") ? atol(getenv("DDL_CR_SMALL_CAP")) : 256;
+    // cache-resident tensors (< 64 MB): two blocks per CU (measured on the DCGAN28 step: 256 -> 512 blocks +1 %,
+    // 1024 -2.5 %); larger ones stream from HBM and need four blocks per CU to keep enough loads in flight
+    // (measured: classifier step -6 %, dcgan64 -7 %)
+    static const long small_cap = getenv("DDL_CR_SMALL_CAP") ? atol(getenv("DDL_CR_SMALL_CAP")) : 512;
     static const long small_rows = getenv("DDL_CR_SMALL_ROWS") ? atol(getenv("DDL_CR_SMALL_ROWS")) : 8;
     const bool big = rows * (long)C * 2 >= (64L << 20);
     const long per_thread = big ? 4 : small_rows, cap = big ? COLREDUCE_MAX_BLOCKS : small_cap;
