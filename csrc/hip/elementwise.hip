@@ -866,8 +866,9 @@ DDL_API int ddl_col2im_1ch(const void* col, void* img, const float* bias, int B,
     // band height: the staged slice ((rows-1)/sh + halo rows of the col tensor) stays under ~40 KiB
     const size_t row_bytes = (size_t)OW * (Tp * 2 + 4);
     const int halo = ((KH - 1) * dh) / sh + 2;
+    static const size_t band_cap = getenv("DDL_COL2IM_LDS_KB") ? (size_t)atol(getenv("DDL_COL2IM_LDS_KB")) * 1024 : 40 * 1024;
     int band = H;
-    while (band > 1 && ((size_t)((band - 1) / sh + halo)) * row_bytes > 40 * 1024) band = (band + 1) / 2;
+    while (band > 1 && ((size_t)((band - 1) / sh + halo)) * row_bytes > band_cap) band = (band + 1) / 2;
     size_t smem = ((size_t)((band - 1) / sh + halo)) * row_bytes;
     if (smem > 160 * 1024) return -2;
     if ((long)((band - 1) / sh + halo) * OW * (Tp / 8) >= (1L << 21) || (long)band * W >= (1L << 21)) return -2;
