@@ -36,6 +36,9 @@ def main():
     ap.add_argument("--avg-every", type=int, default=8, help="local-SGD averaging period (config localsgd)")
     ap.add_argument("--zero", action="store_true",
                     help="dcgan configs, N>1: reduce-scatter + sharded update + all-gather instead of all-reduce")
+    ap.add_argument("--force-dp", action="store_true",
+                    help="diagnostics: run the data-parallel code path (segmented graphs + collectives) on a "
+                         "1-rank process group, to price its overhead without a second GPU")
     ap.add_argument("--device", default="cuda")
     a = ap.parse_args()
 
@@ -48,12 +51,17 @@ def main():
     device = torch.device(f"cuda:{local}") if on_gpu else torch.device("cpu")
     if on_gpu:
         torch.cuda.set_device(device)
+    if a.force_dp and int(os.environ.get("WORLD_SIZE", "1")) == 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
+        kw = {"device_id": device} if on_gpu else {}
+        torch.distributed.init_process_group("nccl" if on_gpu else "gloo", rank=0, world_size=1, **kw)
     rank, world, _ = ddp.init_process_group(device=device)
     if world != a.gpus:
         if rank == 0:
             print(f"warning: --gpus {a.gpus} but WORLD_SIZE={world}; using {world}", file=sys.stderr)
     dp = None
-    if world > 1:
+    if world > 1 or a.force_dp:
         cd = torch.bfloat16 if a.comm_dtype == "bf16" else None
         if a.comm == "rccl" and on_gpu:
             from distributeddeeplearning_amd.parallel.rccl import RcclCommunicator
@@ -119,7 +127,7 @@ def main():
         out["config"]["global_batch"] = info["images_per_step_per_rank"] * world
         out.update(info.get("extra", {}))
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if torch.distributed.is_initialized():
         torch.distributed.destroy_process_group()
 
 

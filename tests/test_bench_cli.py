@@ -28,6 +28,15 @@ def test_bench_contract_cpu(cfg):
     assert d["config"]["parallelism"] == "dp1" and d["data"] == "synthetic"
 
 
+def test_bench_force_dp_one_rank_cpu():
+    """--force-dp runs the data-parallel code path (collectives on a 1-rank gloo group) in one process."""
+    env = dict(os.environ, MASTER_PORT="29641")
+    r = _run(["bench.py", "--device", "cpu", "--steps", "2", "--warmup", "1", "--batch", "8", "--force-dp"], env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["n_gpus"] == 1 and d["value"] > 0
+
+
 def test_bench_two_ranks_gloo():
     env = dict(os.environ, OMP_NUM_THREADS="2")
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
