@@ -133,11 +133,12 @@ def test_conv_transpose(hip, case):
 
 
 @pytest.mark.parametrize("case", [(57, 57, 128, (3, 3), (2, 2)), (28, 28, 12, (3, 3), (1, 1)),
-                                  (10, 10, 128, (2, 2), (3, 3)), (18, 18, 16, (3, 2), (1, 2))])
+                                  (10, 10, 128, (2, 2), (3, 3)), (18, 18, 16, (3, 2), (1, 2)),
+                                  (9, 11, 8, (1, 1), (2, 2)), (16, 16, 24, (3, 3), (3, 3))])
 def test_depthwise(hip, case):
     H, W, Cc, k, s = case
     g = G.depthwise_geom(H, W, Cc, k, s, (2, 2), "valid", keras224_compat=True)
-    B = 3
+    B = 3 if H > 30 else 41
     torch.manual_seed(3)
     x = r16(torch.randn(B, H, W, Cc))
     w = r16(torch.randn(k[0], k[1], Cc))
