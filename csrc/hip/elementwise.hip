@@ -788,7 +788,8 @@ __global__ __launch_bounds__(256) void im2col_1ch_kernel(const bf16_t* __restric
 template <int SH, int SW>
 __global__ __launch_bounds__(256) void col2im_1ch_kernel(const bf16_t* __restrict__ col, uint4* __restrict__ img,
                                                          const OneChGeom g, const float* __restrict__ bias, int act,
-                                                         float alpha, int band_rows) {
+                                                         float alpha, int band_rows, const bf16_t* __restrict__ mul_y,
+                                                         int mul_act, float mul_alpha) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int sh = SH ? SH : g.sh, sw = SW ? SW : g.sw;
     const int b = blockIdx.x;
@@ -830,7 +831,10 @@ __global__ __launch_bounds__(256) void col2im_1ch_kernel(const bf16_t* __restric
             }
         }
         float v = act_apply(acc + b0, act, alpha);
-        img[((long)b * g.H + h) * g.W + w] = make_uint4((uint32_t)f2bf(v), 0, 0, 0);   // channel 0 real, 7 lanes zero
+        const long pix = ((long)b * g.H + h) * g.W + w;
+        // fused activation backward of the layer below: (bf16 result) * act'(its saved output), rounded once more
+        if (mul_y) v = bf2f(f2bf(v)) * act_grad_y(bf2f(mul_y[pix * 8]), mul_act, mul_alpha);
+        img[pix] = make_uint4((uint32_t)f2bf(v), 0, 0, 0);   // channel 0 real, 7 lanes zero
     }
 }
 
@@ -860,7 +864,7 @@ DDL_API int ddl_im2col_1ch(const void* img, void* col, int B, int H, int W, int 
 // img is written as [B][H][W][8] (one real channel).
 DDL_API int ddl_col2im_1ch(const void* col, void* img, const float* bias, int B, int H, int W, int OH, int OW,
                            int KH, int KW, int sh, int sw, int dh, int dw, int pt, int pl, int Tp, int act,
-                           float alpha, hipStream_t s) {
+                           float alpha, const void* mul_y, int mul_act, float mul_alpha, hipStream_t s) {
     if (Tp % 8 || Tp < KH * KW) return -1;
     OneChGeom g{H, W, OH, OW, KH, KW, sh, sw, dh, dw, pt, pl, KH * KW, Tp, 8};
     // band height: the staged slice ((rows-1)/sh + halo rows of the col tensor) stays under ~40 KiB
@@ -882,7 +886,8 @@ DDL_API int ddl_col2im_1ch(const void* col, void* img, const float* bias, int B,
             done[v] = true;
         }
     }
-    kern<<<dim3(B, (H + band - 1) / band), 256, smem, s>>>((const bf16_t*)col, (uint4*)img, g, bias, act, alpha, band);
+    kern<<<dim3(B, (H + band - 1) / band), 256, smem, s>>>((const bf16_t*)col, (uint4*)img, g, bias, act, alpha, band,
+                                                           (const bf16_t*)mul_y, mul_act, mul_alpha);
     return 0;
 }
 

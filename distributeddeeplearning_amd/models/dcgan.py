@@ -162,8 +162,11 @@ class GANTrainer:
         fake = self.g_forward(B) if fake is None else fake
         feat = self.D.forward(fake, training=True, stop=-1)
         loss, dfeat = self._d_head(feat, B, 1.0, 1.0, True, False)
-        dfake = self.D.backward(dfeat, need_input_grad=True, need_dw=False, start=-1)
-        self.G.backward(dfake, need_input_grad=False)
+        # the generator's output activation backward rides in the epilogue of D's input-gradient kernel
+        from .network import FUSE_ACT_BWD
+        mul = Network.act_owner(self.G.ops[-1]) if (FUSE_ACT_BWD and isinstance(self.D.ops[0], ConvOp)) else None
+        dfake = self.D.backward(dfeat, need_input_grad=True, need_dw=False, start=-1, input_mul=mul)
+        self.G.backward(dfake, need_input_grad=False, dy_premultiplied=mul is not None)
         self.g_loss = loss
         self._fake = None
         return loss

@@ -31,6 +31,7 @@ from ..ops.geometry import ConvGeom, dense_geom
 from .ir import LayerSpec, ModelSpec
 
 ONECH = os.environ.get("DDL_ONECH", "1") == "1"      # single-channel conv fast path (device)
+FUSE_ACT_BWD = os.environ.get("DDL_FUSE_ACT_BWD", "1") == "1"   # act'(y) of the layer below in the dgrad epilogue
 BRANCH = os.environ.get("DDL_BRANCH", "1") == "1"    # weight-gradient branch on a side stream (captured steps)
 ALIGN = 8      # every tensor starts at a multiple of 8 elements (16 B in bf16, 32 B in fp32)
 
@@ -146,6 +147,7 @@ class ConvOp(Op):
         self.onech = None               # None | "in" (Conv2D 1->N) | "out" (Conv2DTranspose C->1)
         self.g1 = None                  # the equivalent 1x1 geometry on the taps-as-channels tensor
         self.w_tap = self.w_tapT = None
+        self.dy_premul = False          # the incoming dY already carries act'(y) (fused by the layer above)
         self._gbias_is_zero = False     # gbias currently holds the exact-zero gradient written by _bias_grad
         self.out_buffer = None          # optional destination of the next forward's output ("out" path only)
 
@@ -218,7 +220,7 @@ class ConvOp(Op):
                 self.x, self.y = x, y
         return y
 
-    def _bwd_onech(self, dy, need_dx, need_dw):
+    def _bwd_onech(self, dy, need_dx, need_dw, mul=None):
         g, g1, hip = self.g, self.g1, F.hip_backend()
         T = g.KH * g.KW
         dx = None
@@ -230,7 +232,7 @@ class ConvOp(Op):
                     self._bias_grad(dy)
                 _BR.run(wg, dy)
             if need_dx:
-                dx = hip.col2im_1ch(hip.conv_dgrad(dy, self.w_tapT, g1), g)
+                dx = hip.col2im_1ch(hip.conv_dgrad(dy, self.w_tapT, g1), g, mul=mul)
         else:
             dyc = hip.im2col_1ch(dy, g)
             if need_dw:
@@ -239,7 +241,7 @@ class ConvOp(Op):
                     self._bias_grad(dy)
                 _BR.run(wg, dy, dyc)
             if need_dx:
-                dx = hip.conv_dgrad(dyc, self.w_tapT, g1)
+                dx = hip.conv_dgrad(dyc, self.w_tapT, g1, mul=mul)
         return dx
 
     def fwd(self, x, training):
@@ -258,14 +260,19 @@ class ConvOp(Op):
             self.x, self.y = x, y
         return y
 
-    def bwd(self, dy, need_dx=True, need_dw=True):
+    def bwd(self, dy, need_dx=True, need_dw=True, mul=None):
+        """`mul` = (y, act, alpha) of the activation-carrying layer below: dx leaves already multiplied by
+        act'(y) (epilogue of the input-gradient kernel), and that layer skips its own act_bwd pass."""
         g = self.g
         if self.act not in (None, "linear") and not self.act_bwd_fused:
-            dy = F.act_bwd(dy, self.y, self.act, self.alpha)
+            if self.dy_premul:
+                self.dy_premul = False
+            else:
+                dy = F.act_bwd(dy, self.y, self.act, self.alpha)
         x = self.x
         dx = None
         if self.onech:
-            return self._bwd_onech(dy, need_dx, need_dw)
+            return self._bwd_onech(dy, need_dx, need_dw, mul)
         if self.kind == "dense":
             B = x.shape[0]
             dy4, x4 = dy.reshape(B, 1, 1, -1), x.reshape(B, 1, 1, -1)
@@ -275,7 +282,7 @@ class ConvOp(Op):
                     self._bias_grad(dy)
                 _BR.run(wg, dy)
             if need_dx:
-                dx = F.conv_dgrad(dy4, self._w4(self.w_alt), g).reshape(x.shape)
+                dx = F.conv_dgrad(dy4, self._w4(self.w_alt), g, mul=mul).reshape(x.shape)
         elif self.kind == "conv2d_transpose":
             # core X = our output (dy), core Y = our input (x)
             if need_dw:
@@ -284,7 +291,7 @@ class ConvOp(Op):
                     self._bias_grad(dy)
                 _BR.run(wg, dy)
             if need_dx:
-                dx = F.conv_fprop(dy, self.w_alt, None, g)
+                dx = F.conv_fprop(dy, self.w_alt, None, g, mul=mul)
         else:
             if need_dw:
                 def wg():
@@ -292,7 +299,7 @@ class ConvOp(Op):
                     self._bias_grad(dy)
                 _BR.run(wg, dy)
             if need_dx:
-                dx = F.conv_dgrad(dy, self.w_main if g.depthwise else self.w_alt, g)
+                dx = F.conv_dgrad(dy, self.w_main if g.depthwise else self.w_alt, g, mul=mul)
         return dx
 
     def release(self):
@@ -702,18 +709,51 @@ class Network:
         last = self.ops[-1] if self.ops else None
         return isinstance(last, ConvOp) and last.onech == "out"
 
+    @staticmethod
+    def act_owner(op):
+        """(y, act, alpha) if `op` is a conv/dense layer whose activation backward is still a separate
+        pass over dY (not already folded into a following BN), else None."""
+        if isinstance(op, ConvOp) and op.act not in (None, "linear") and not op.act_bwd_fused and op.y is not None:
+            return (op.y, op.act, op.alpha)
+        return None
+
     def backward(self, dy, need_input_grad: bool = False, need_dw: bool = True,
-                 start: Optional[int] = None):
-        """Back-propagate from op index `start` (exclusive upper bound, default: all ops)."""
+                 start: Optional[int] = None, input_mul=None, dy_premultiplied: bool = False):
+        """Back-propagate from op index `start` (exclusive upper bound, default: all ops).
+
+        Activation backward fusion: when the op below a conv/dense layer (through reshapes) carries an
+        unfused activation, its act'(y) is applied in the epilogue of this layer's input-gradient kernel
+        instead of a separate elementwise pass.  `input_mul` does the same for the network INPUT gradient
+        (y of the producer network's last layer: G -> D chains), `dy_premultiplied` tells this network that
+        its incoming dY already carries the last layer's act'(y)."""
         start = len(self.ops) if start is None else (start if start >= 0 else len(self.ops) + start)
         first_param = next((i for i, op in enumerate(self.ops) if op.has_params), len(self.ops))
         _BR.enabled = self.branch_wgrad
+        for op in self.ops:
+            if isinstance(op, ConvOp):
+                op.dy_premul = False
+        if dy_premultiplied and start > 0 and isinstance(self.ops[start - 1], ConvOp):
+            self.ops[start - 1].dy_premul = True
         for i in range(start - 1, -1, -1):
             op = self.ops[i]
             need_dx = need_input_grad or i > first_param
             if not need_dx and not (need_dw and op.has_params):
                 break
-            dy = op.bwd(dy, need_dx=need_dx, need_dw=need_dw)
+            if isinstance(op, ConvOp):
+                mul = None
+                if need_dx and FUSE_ACT_BWD:
+                    j = i - 1
+                    while j >= 0 and isinstance(self.ops[j], ViewOp):
+                        j -= 1
+                    if j >= 0:
+                        mul = self.act_owner(self.ops[j])
+                        if mul is not None:
+                            self.ops[j].dy_premul = True
+                    elif input_mul is not None:
+                        mul = input_mul
+                dy = op.bwd(dy, need_dx=need_dx, need_dw=need_dw, mul=mul)
+            else:
+                dy = op.bwd(dy, need_dx=need_dx, need_dw=need_dw)
         _BR.join()
         return dy
 

@@ -31,17 +31,28 @@ def _b(t: torch.Tensor):
 
 
 # conv family -------------------------------------------------------------------------------
-def conv_fprop(x, wA, bias, g, act=None, alpha=0.3):
-    return _b(x).conv_fprop(x, wA, bias, g, act, alpha)
+def _cpu_mul(t, mul):
+    if mul is None:
+        return t
+    y, act, alpha = mul
+    return cpu_ref.act_bwd(t, y.reshape(t.shape), act, alpha)
 
 
-def conv_dgrad(dy, wB, g, bias=None, act=None, alpha=0.3):
+def conv_fprop(x, wA, bias, g, act=None, alpha=0.3, mul=None):
+    """`mul` = (y, act, alpha): result *= act'(y), the activation backward of the layer below (fused
+    into the kernel epilogue on device)."""
+    if x.is_cuda:
+        return hip_backend().conv_fprop(x, wA, bias, g, act, alpha, mul)
+    return _cpu_mul(cpu_ref.conv_fprop(x, wA, bias, g, act, alpha), mul)
+
+
+def conv_dgrad(dy, wB, g, bias=None, act=None, alpha=0.3, mul=None):
     """`wB` is the core weight in [I][KH][KW][O] order (reduction channel contiguous);
     depthwise: [KH][KW][C]."""
     if dy.is_cuda:
-        return hip_backend().conv_dgrad(dy, wB, g, bias, act, alpha)
+        return hip_backend().conv_dgrad(dy, wB, g, bias, act, alpha, mul)
     wA = wB if g.depthwise else wB.permute(3, 1, 2, 0)
-    return cpu_ref.conv_dgrad(dy, wA, g, bias, act, alpha)
+    return _cpu_mul(cpu_ref.conv_dgrad(dy, wA, g, bias, act, alpha), mul)
 
 
 def conv_wgrad(x, dy, g, layout="A", out=None):

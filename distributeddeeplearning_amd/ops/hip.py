@@ -67,7 +67,8 @@ _optim_step = _sig("ddl_optim_step", None, vp, vp, vp, vp, vp, vp, cl, ci, cf, c
 _scale_emit = _sig("ddl_scale_emit", None, vp, vp, cl, cf, vp)
 _avg_delta = _sig("ddl_avg_delta", None, vp, vp, vp, vp, cl, cf, vp)
 _im2col = _sig("ddl_im2col_1ch", ci, vp, vp, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, vp)
-_col2im = _sig("ddl_col2im_1ch", ci, vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, cf, vp)
+_col2im = _sig("ddl_col2im_1ch", ci, vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, cf, vp, ci,
+               cf, vp)
 _gather = _sig("ddl_relayout_gather", None, vp, vp, vp, ci, cl, vp)
 _gemm_sk = _sig("ddl_gemm_sk", ci, vp, vp, vp, vp, cl, ci, ci, ci, ci, cf, vp)
 _philox = _sig("ddl_philox_uniform", None, vp, cl, vp, cf, cf, vp)
@@ -343,7 +344,25 @@ def im2col_1ch(img, g: ConvGeom):
     return col
 
 
-def col2im_1ch(col, g: ConvGeom, bias=None, act=None, alpha=0.3, out=None):
+def _mul_args(mul, like):
+    """`mul` = (y, act, alpha): fused activation backward of the layer below, result *= act'(y).  -> ctypes args."""
+    if mul is None:
+        return None, 0, 0.0
+    y, act, alpha = mul
+    _chk_act(y, "mul y")
+    if y.numel() != like.numel():
+        raise ValueError(f"fused act backward: y has {y.numel()} elements, result {like.numel()}")
+    return y.data_ptr(), ACT_CODE[act], alpha
+
+
+def _mul_inplace(t, mul):
+    """The unfused form of `mul` for kernels without that epilogue: t *= act'(y), in place."""
+    if mul is not None:
+        y, act, alpha = mul
+        _act_bwd(t.data_ptr(), y.data_ptr(), t.data_ptr(), t.numel(), ACT_CODE[act], alpha, _stream())
+
+
+def col2im_1ch(col, g: ConvGeom, bias=None, act=None, alpha=0.3, out=None, mul=None):
     """taps-as-channels [B][g.OH][g.OW][pad8(T)] -> single-channel image [B][g.H][g.W][8] = act(bias + fold).
     `out`: write into this (contiguous, same shape) tensor instead of a fresh one."""
     _chk_act(col, "col")
@@ -360,8 +379,9 @@ def col2im_1ch(col, g: ConvGeom, bias=None, act=None, alpha=0.3, out=None):
         img = out
     else:
         img = torch.empty(B, g.H, g.W, 8, dtype=torch.bfloat16, device=col.device)
+    my, ma, mal = _mul_args(mul, img)
     rc = _col2im(col.data_ptr(), img.data_ptr(), _p(bias), B, g.H, g.W, g.OH, g.OW, g.KH, g.KW, g.sh, g.sw, g.dh,
-                 g.dw, g.pt, g.pl, Tp, ACT_CODE[act], alpha, _stream())
+                 g.dw, g.pt, g.pl, Tp, ACT_CODE[act], alpha, my, ma, mal, _stream())
     if rc:
         raise ValueError("col2im_1ch rejected")
     _done()
@@ -711,7 +731,7 @@ _CONV_CHOICE: Dict[Tuple, object] = {}
 AUTOTUNE = os.environ.get("DDL_AUTOTUNE", "1") == "1"
 
 
-def _run_pconv(pl, src, wgt, bias, dst, g, B, Hs, Ws, Cs, Hd, Wd, Nd, Nw, ss, sd, act, alpha):
+def _run_pconv(pl, src, wgt, bias, dst, g, B, Hs, Ws, Cs, Hd, Wd, Nd, Nw, ss, sd, act, alpha, mul=None):
     rc = _pconv(src.data_ptr(), wgt.data_ptr(), _p(bias), dst.data_ptr(), pl["classes"].data_ptr(),
                 pl["ktab"].data_ptr(), pl["ncls"], pl["nst"], B, Hs, Ws, Cs, Hd, Wd, Nd, Nw, ss[0], ss[1],
                 sd[0], sd[1], g.KH * g.KW, ACT_CODE[act], alpha, pl["IMG"], pl["BR"], pl["bands"],
@@ -719,6 +739,9 @@ def _run_pconv(pl, src, wgt, bias, dst, g, B, Hs, Ws, Cs, Hd, Wd, Nd, Nw, ss, sd
     if rc != 0:
         raise ValueError(f"pconv rejected its plan (rc={rc}): {g} B={B} "
                          f"{ {k: v for k, v in pl.items() if k not in ('classes', 'ktab')} }")
+    # measured: act'(y) inside pconv's store loop costs as much as the separate pass it replaces (the y load sits
+    # between the LDS transpose and the store) and slows every other pconv launch by ~1 %: kept as its own pass
+    _mul_inplace(dst, mul)
 
 
 def _run_igemm(src, wgt, bias, dst, g, mode, B, Hs, Ws, Cs, Hd, Wd, Nd, Nw, ss, sd, act, alpha, tile=None):
@@ -758,7 +781,7 @@ def _time_us(fn, reps=4, inner=4):
     return best
 
 
-def _igemm_call(src, wgt, bias, dst, g, mode, B, Hs, Ws, Cs, Hd, Wd, Nd, Nw, ss, sd, act, alpha):
+def _igemm_call(src, wgt, bias, dst, g, mode, B, Hs, Ws, Cs, Hd, Wd, Nd, Nw, ss, sd, act, alpha, mul=None):
     """Dispatch one class-grid convolution: the patch-resident kernel with a tuned plan, or the
     global-gather kernel.  The first (non-captured) call of each problem times the candidates on the
     real operands and caches the winner -- these shapes are static for a whole training run."""
@@ -766,6 +789,7 @@ def _igemm_call(src, wgt, bias, dst, g, mode, B, Hs, Ws, Cs, Hd, Wd, Nd, Nw, ss,
     tail = (B, Hs, Ws, Cs, Hd, Wd, Nd, Nw, ss, sd, act, alpha)
     if CONV_IMPL != "pconv":
         _run_igemm(src, wgt, bias, dst, g, mode, *tail)
+        _mul_inplace(dst, mul)
         _done()
         return
     slow = ACT_CODE[act] not in (0, 1, 6)
@@ -779,8 +803,8 @@ def _igemm_call(src, wgt, bias, dst, g, mode, B, Hs, Ws, Cs, Hd, Wd, Nd, Nw, ss,
                     [("pconv", pl) for pl in _pconv_candidates(g, mode, B, Cs, Nd, ss, src.device)]
             timed = []
             for kind, pl in cands:
-                fn = (lambda pl=pl: _run_igemm(src, wgt, bias, dst, g, mode, *tail, tile=pl)) if kind == "igemm" else \
-                     (lambda pl=pl: _run_pconv(pl, src, wgt, bias, dst, g, *tail))
+                fn = (lambda pl=pl: (_run_igemm(src, wgt, bias, dst, g, mode, *tail, tile=pl), _mul_inplace(dst, mul))) \
+                    if kind == "igemm" else (lambda pl=pl: _run_pconv(pl, src, wgt, bias, dst, g, *tail, mul=mul))
                 timed.append((_time_us(fn), kind, pl))
             timed.sort(key=lambda t: t[0])
             choice = (timed[0][1], timed[0][2])
@@ -794,9 +818,10 @@ def _igemm_call(src, wgt, bias, dst, g, mode, B, Hs, Ws, Cs, Hd, Wd, Nd, Nw, ss,
             choice = ("pconv", pl) if pl is not None else ("igemm", None)
         _CONV_CHOICE[key] = choice
     if choice[0] == "pconv":
-        _run_pconv(choice[1], *args, *tail)
+        _run_pconv(choice[1], *args, *tail, mul=mul)
     else:
         _run_igemm(src, wgt, bias, dst, g, mode, *tail, tile=choice[1])
+        _mul_inplace(dst, mul)
     _done()
 
 
@@ -816,7 +841,9 @@ def _is_1x1(g: ConvGeom) -> bool:
             and not g.depthwise)
 
 
-def conv_fprop(x, wA, bias, g: ConvGeom, act=None, alpha=0.3):
+def conv_fprop(x, wA, bias, g: ConvGeom, act=None, alpha=0.3, mul=None):
+    """`mul` = (y, act, alpha): multiply the (bf16) result by act'(y) -- the activation backward of the layer
+    below, fused into the epilogue when this runs as a transposed conv's input gradient."""
     _chk_act(x, "x")
     B = x.shape[0]
     Ip, Op = pad8(g.I), pad8(g.O)
@@ -831,6 +858,7 @@ def conv_fprop(x, wA, bias, g: ConvGeom, act=None, alpha=0.3):
                         g.KH, g.KW, g.sh, g.sw, g.dh, g.dw, g.pt, g.pl, g.O, ACT_CODE[act], alpha, _stream())
         if rc:
             raise ValueError("depthwise fprop rejected")
+        _mul_inplace(y, mul)
         _done()
         return y
     if wA.dim() != 4 or wA.shape[1:] != (g.KH, g.KW, Ip) or wA.shape[0] > Op:
@@ -842,14 +870,15 @@ def conv_fprop(x, wA, bias, g: ConvGeom, act=None, alpha=0.3):
         if rc < 0:
             raise ValueError(f"gemm_sk rejected the problem (rc={rc}): {g}")
         if rc == 0:
+            _mul_inplace(y, mul)
             _done()
             return y
     _igemm_call(x, wA, bias, y, g, "fprop", B, g.H, g.W, Ip, g.OH, g.OW, Op, min(wA.shape[0], g.O),
-                (g.sh, g.sw), (1, 1), act, alpha)
+                (g.sh, g.sw), (1, 1), act, alpha, mul)
     return y
 
 
-def conv_dgrad(dy, wB, g: ConvGeom, bias=None, act=None, alpha=0.3):
+def conv_dgrad(dy, wB, g: ConvGeom, bias=None, act=None, alpha=0.3, mul=None):
     _chk_act(dy, "dy")
     B = dy.shape[0]
     Ip, Op = pad8(g.I), pad8(g.O)
@@ -866,6 +895,7 @@ def conv_dgrad(dy, wB, g: ConvGeom, bias=None, act=None, alpha=0.3):
                         g.KH, g.KW, g.sh, g.sw, g.dh, g.dw, g.pt, g.pl, g.O, 0, 0.0, _stream())
         if rc:
             raise ValueError("depthwise dgrad rejected")
+        _mul_inplace(dx, mul)
         _done()
         return dx
     if wB.dim() != 4 or wB.shape[1:] != (g.KH, g.KW, Op) or wB.shape[0] > Ip:
@@ -877,10 +907,11 @@ def conv_dgrad(dy, wB, g: ConvGeom, bias=None, act=None, alpha=0.3):
         if rc < 0:
             raise ValueError(f"gemm_sk rejected the problem (rc={rc}): {g}")
         if rc == 0:
+            _mul_inplace(dx, mul)
             _done()
             return dx
     _igemm_call(dy, wB, bias, dx, g, "dgrad", B, g.OH, g.OW, Op, g.H, g.W, Ip, min(wB.shape[0], g.I),
-                (1, 1), (g.sh, g.sw), act, alpha)
+                (1, 1), (g.sh, g.sw), act, alpha, mul)
     return dx
 
 

@@ -109,3 +109,20 @@ def test_captured_step_with_wgrad_branch_matches_eager_bitwise():
     torch.cuda.synchronize()
     assert torch.equal(a.D.P, b.D.P) and torch.equal(a.G.P, b.G.P)
     assert torch.equal(a.D.S, b.D.S) and torch.equal(a.G.S, b.G.S)
+
+
+def test_fused_activation_backward_is_bit_exact(monkeypatch):
+    """act'(y) of the layer below applied in the input-gradient kernel's epilogue (pconv, col2im; other
+    kernels fall back to an in-place pass) must give the same bits as the separate act_bwd pass."""
+    from distributeddeeplearning_amd.models import network
+    real = torch.rand(80, 28, 28, 1, generator=torch.Generator().manual_seed(4))
+    a = GANTrainer(GANConfig(batch=80, seed=11), "cuda")
+    rp = a.D.prepare_input(real)
+    for _ in range(3):
+        a.train_step(rp, prepared=True)
+    monkeypatch.setattr(network, "FUSE_ACT_BWD", False)
+    b = GANTrainer(GANConfig(batch=80, seed=11), "cuda")
+    for _ in range(3):
+        b.train_step(rp, prepared=True)
+    torch.cuda.synchronize()
+    assert torch.equal(a.D.P, b.D.P) and torch.equal(a.G.P, b.G.P)
