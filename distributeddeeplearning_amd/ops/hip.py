@@ -798,6 +798,8 @@ def _igemm_call(src, wgt, bias, dst, g, mode, B, Hs, Ws, Cs, Hd, Wd, Nd, Nw, ss,
     if choice is None:
         if AUTOTUNE and not torch.cuda.is_current_stream_capturing():
             tiles = [1] if Nd <= 16 else ([3] if Nd <= 32 else ([4, 5, 2] if Nd <= 64 else [6, 8]))
+            if 64 < Nd <= 256:
+                tiles += [2, 4]          # 64-wide N tiles over a z-grid: more, smaller blocks for short pixel dims
             tiles = tiles + [t + 16 for t in tiles]          # deep (64-wide, 3 stages in flight) and shallow variants
             cands = [("igemm", t) for t in tiles] + \
                     [("pconv", pl) for pl in _pconv_candidates(g, mode, B, Cs, Nd, ss, src.device)]
