@@ -1,0 +1,177 @@
+// Fused "taps GEMM + fold" for transposed convolutions with ONE output channel (DCGAN's last generator
+// layer) and for the input gradient of convolutions with ONE input channel (the discriminator's first
+// layer):
+//
+//   z[p][t]      = sum_c x[b][p][c] * w[t][c]                          (1x1 GEMM: C channels -> T taps, MFMA)
+//   img[b][h][w] = act(bias + sum_t z[(h + pt - kh*dh)/sh][(w + pl - kw*dw)/sw][t])     (col2im fold)
+//
+// The unfused path (gemm_sk -> taps-as-channels tensor in HBM -> col2im_1ch) writes and re-reads a
+// [B][OH][OW][32] tensor (50 MB at the reference batch) that only ever lives between the two kernels.
+// Here a block owns (image, band of output rows): it computes the band's z rows straight from x with
+// v_mfma_f32_16x16x32_bf16 -- a lane's B fragment (8 consecutive channels of one pixel) is one 16-byte
+// global load, no LDS staging of x -- drops them into LDS as bf16 (the same rounding the HBM round trip
+// applied, so results are bit-identical to the unfused path), and folds from LDS exactly like
+// col2im_1ch.  T <= 32 taps (two 16-row MFMA tiles), C <= 128.
+#include "common.h"
+
+struct TapFoldArgs {
+    const bf16_t* x;          // [B][OH][OW][C]
+    const bf16_t* w;          // [T][C]
+    const float* bias;        // 1 value or null
+    uint4* img;               // [B][H][W][8 bf16] (channel 0 real)
+    const bf16_t* mul_y;      // optional: img *= act'(mul_y) (activation backward of the layer below), laid out like img
+    int mul_act; float mul_alpha;
+    int B, H, W, OH, OW, C, KH, KW, sh, sw, dh, dw, pt, pl, T, act;
+    float alpha;
+    int band_rows;
+};
+
+#define TF_ZP 68                               // bytes per z pixel in LDS: 32 taps * 2 + 4 (spreads the 2-byte gathers)
+#define TF_WP(KP) ((KP) * 2 + 32)
+
+__device__ __forceinline__ int tf_fdiv(int x, float inv) { return __float2int_rz(((float)x + 0.5f) * inv); }
+
+template <int KS, int SH, int SW>
+__global__ __launch_bounds__(256) void tapfold_kernel(const TapFoldArgs a) {
+    constexpr int KP = KS * 32, WP = TF_WP(KP);
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* sW = smem;                            // [32][WP]
+    char* sZ = smem + 32 * WP;                  // [npix16][TF_ZP]
+    const int sh = SH ? SH : a.sh, sw = SW ? SW : a.sw;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int fr = lane & 15, fq = lane >> 4;
+    const int b = blockIdx.x;
+    const int h0 = blockIdx.y * a.band_rows, h1 = min(a.H, h0 + a.band_rows);
+    const int lo = h0 + a.pt - (a.KH - 1) * a.dh;
+    const int oh_lo = lo <= 0 ? 0 : (lo + sh - 1) / sh;
+    const int oh_hi = min(a.OH - 1, (h1 - 1 + a.pt) / sh);
+    const int nrows = oh_hi - oh_lo + 1;
+    const int npix = nrows > 0 ? nrows * a.OW : 0;
+
+    // ---- weights -> LDS (zero rows beyond T, zero k beyond C)
+    for (int u = tid; u < 32 * (KP / 8); u += 256) {
+        int t = u / (KP / 8), k8 = u - t * (KP / 8);
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (t < a.T && k8 * 8 < a.C) v = *(const uint4*)(a.w + (long)t * a.C + k8 * 8);
+        *(uint4*)(sW + t * WP + k8 * 16) = v;
+    }
+    __syncthreads();
+    bf16x8_t wf[2][KS];
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) wf[tt][ks] = *(const bf16x8_t*)(sW + (16 * tt + fr) * WP + ks * 64 + fq * 16);
+
+    // ---- z rows of the band: 16 pixels per MFMA column block, two fragments of loads in flight per wave
+    const bf16_t* xb = a.x + ((long)b * a.OH + oh_lo) * a.OW * a.C;
+    for (int f0 = wave * 2; f0 * 16 < npix; f0 += 8) {
+        bf16x8_t xf[2][KS];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int p = (f0 + j) * 16 + fr;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const int k = ks * 32 + fq * 8;
+                uint4 v = make_uint4(0, 0, 0, 0);
+                if (p < npix && k < a.C) v = *(const uint4*)(xb + (long)p * a.C + k);
+                xf[j][ks] = __builtin_bit_cast(bf16x8_t, v);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int p = (f0 + j) * 16 + fr;
+            f32x4 acc[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+                for (int tt = 0; tt < 2; ++tt)
+                    acc[tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[tt][ks], xf[j][ks], acc[tt], 0, 0, 0);
+            if (p < npix) {
+                // a lane holds taps 16tt + 4fq .. +3 of pixel p
+#pragma unroll
+                for (int tt = 0; tt < 2; ++tt) {
+                    uint32_t* d = (uint32_t*)(sZ + p * TF_ZP + (16 * tt + 4 * fq) * 2);
+                    d[0] = pack2bf(acc[tt][0], acc[tt][1]);
+                    d[1] = pack2bf(acc[tt][2], acc[tt][3]);
+                }
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- fold (identical to col2im_1ch_kernel)
+    const float b0 = a.bias ? a.bias[0] : 0.f;
+    const float invW = 1.0f / (float)a.W;
+    for (int i = tid; i < (h1 - h0) * a.W; i += 256) {
+        int hl = tf_fdiv(i, invW), w = i - hl * a.W, h = h0 + hl;
+        float acc = 0.f;
+        for (int kh = 0; kh < a.KH; ++kh) {
+            int th = h + a.pt - kh * a.dh;
+            if (th < 0 || th % sh) continue;
+            int oh = th / sh;
+            if (oh > oh_hi) continue;
+            const char* row = sZ + (oh - oh_lo) * a.OW * TF_ZP + kh * a.KW * 2;
+            for (int kw = 0; kw < a.KW; ++kw) {
+                int tw = w + a.pl - kw * a.dw;
+                if (tw < 0 || tw % sw) continue;
+                int ow = tw / sw;
+                if (ow >= a.OW) continue;
+                acc += bf2f(*(const bf16_t*)(row + ow * TF_ZP + kw * 2));
+            }
+        }
+        float v = act_apply(acc + b0, a.act, a.alpha);
+        const long pix = ((long)b * a.H + h) * a.W + w;
+        if (a.mul_y) v = bf2f(f2bf(v)) * act_grad_y(bf2f(a.mul_y[pix * 8]), a.mul_act, a.mul_alpha);
+        a.img[pix] = make_uint4((uint32_t)f2bf(v), 0, 0, 0);
+    }
+}
+
+template <int KS, int SH, int SW>
+static void tapfold_launch(const TapFoldArgs& a, int bands, size_t smem, hipStream_t s) {
+    if (smem > 64 * 1024) {
+        static bool done = false;
+        if (!done) {
+            hipFuncSetAttribute((const void*)tapfold_kernel<KS, SH, SW>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                160 * 1024);
+            done = true;
+        }
+    }
+    tapfold_kernel<KS, SH, SW><<<dim3(a.B, bands), 256, smem, s>>>(a);
+}
+
+// Returns 0 on success, 1 if the shape is outside this kernel's range (nothing launched), < 0 on bad arguments.
+DDL_API int ddl_tapfold_1ch(const void* x, const void* w, const float* bias, void* img, int B, int H, int W, int OH,
+                            int OW, int C, int KH, int KW, int sh, int sw, int dh, int dw, int pt, int pl, int act,
+                            float alpha, const void* mul_y, int mul_act, float mul_alpha, hipStream_t s) {
+    if (C % 8 || C <= 0 || B <= 0 || KH * KW <= 0) return -1;
+    if (KH * KW > 32 || C > 128) return 1;
+    if ((long)B * OH * OW * C >= (1L << 31) || (long)B * H * W * 8 >= (1L << 31)) return 1;
+    TapFoldArgs a;
+    a.x = (const bf16_t*)x; a.w = (const bf16_t*)w; a.bias = bias; a.img = (uint4*)img;
+    a.mul_y = (const bf16_t*)mul_y; a.mul_act = mul_act; a.mul_alpha = mul_alpha;
+    a.B = B; a.H = H; a.W = W; a.OH = OH; a.OW = OW; a.C = C; a.KH = KH; a.KW = KW; a.sh = sh; a.sw = sw;
+    a.dh = dh; a.dw = dw; a.pt = pt; a.pl = pl; a.T = KH * KW; a.act = act; a.alpha = alpha;
+    const int KS = (C + 31) / 32;
+    // band height: the band's z rows ((rows-1)/sh + halo) stay under ~40 KiB of LDS
+    const size_t row_bytes = (size_t)OW * TF_ZP;
+    const int halo = ((KH - 1) * dh) / sh + 2;
+    int band = H;
+    while (band > 1 && ((size_t)((band - 1) / sh + halo)) * row_bytes > 40 * 1024) band = (band + 1) / 2;
+    const size_t zrows = (size_t)((band - 1) / sh + halo);
+    const size_t zbytes = (zrows * OW + 15) / 16 * 16 * TF_ZP;
+    const size_t smem = 32 * (size_t)TF_WP(KS * 32) + zbytes;
+    if (smem > 160 * 1024 || (long)band * W >= (1L << 21)) return 1;
+    a.band_rows = band;
+    const int bands = (H + band - 1) / band;
+    const int sv = (sh == 1 && sw == 1) ? 1 : ((sh == 2 && sw == 2) ? 2 : 0);
+#define TF_CASE(KS_) \
+    if (KS == KS_) { \
+        if (sv == 1) tapfold_launch<KS_, 1, 1>(a, bands, smem, s); \
+        else if (sv == 2) tapfold_launch<KS_, 2, 2>(a, bands, smem, s); \
+        else tapfold_launch<KS_, 0, 0>(a, bands, smem, s); \
+        return 0; \
+    }
+    TF_CASE(1) TF_CASE(2) TF_CASE(3) TF_CASE(4)
+#undef TF_CASE
+    return 1;
+}

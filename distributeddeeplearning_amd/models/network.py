@@ -213,9 +213,12 @@ class ConvOp(Op):
             y = hip.conv_fprop(xc, self.w_tap, self.bias, g1, self.act, self.alpha)
             if training:
                 self.x, self.y = xc, y
-        else:                           # 1x1 conv to taps -> col2im fold with bias + activation
-            z = hip.conv_fprop(x, self.w_main.reshape(g1.O, 1, 1, -1), None, g1)
-            y = hip.col2im_1ch(z, g, self.bias, self.act, self.alpha, out=self.out_buffer)
+        else:                           # 1x1 conv to taps -> col2im fold with bias + activation (one fused kernel)
+            y = hip.tapfold_1ch(x, self.w_main.reshape(g1.O, -1), g, self.bias, self.act, self.alpha,
+                                out=self.out_buffer)
+            if y is None:
+                z = hip.conv_fprop(x, self.w_main.reshape(g1.O, 1, 1, -1), None, g1)
+                y = hip.col2im_1ch(z, g, self.bias, self.act, self.alpha, out=self.out_buffer)
             if training:
                 self.x, self.y = x, y
         return y
@@ -232,7 +235,9 @@ class ConvOp(Op):
                     self._bias_grad(dy)
                 _BR.run(wg, dy)
             if need_dx:
-                dx = hip.col2im_1ch(hip.conv_dgrad(dy, self.w_tapT, g1), g, mul=mul)
+                dx = hip.tapfold_1ch(dy, self.w_tapT.reshape(T, -1), g, mul=mul)
+                if dx is None:
+                    dx = hip.col2im_1ch(hip.conv_dgrad(dy, self.w_tapT, g1), g, mul=mul)
         else:
             dyc = hip.im2col_1ch(dy, g)
             if need_dw:

@@ -69,6 +69,8 @@ _avg_delta = _sig("ddl_avg_delta", None, vp, vp, vp, vp, cl, cf, vp)
 _im2col = _sig("ddl_im2col_1ch", ci, vp, vp, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, vp)
 _col2im = _sig("ddl_col2im_1ch", ci, vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, cf, vp, ci,
                cf, vp)
+_tapfold = _sig("ddl_tapfold_1ch", ci, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, cf, vp, ci,
+                cf, vp)
 _gather = _sig("ddl_relayout_gather", None, vp, vp, vp, ci, cl, vp)
 _gemm_sk = _sig("ddl_gemm_sk", ci, vp, vp, vp, vp, cl, ci, ci, ci, ci, cf, vp)
 _philox = _sig("ddl_philox_uniform", None, vp, cl, vp, cf, cf, vp)
@@ -384,6 +386,44 @@ def col2im_1ch(col, g: ConvGeom, bias=None, act=None, alpha=0.3, out=None, mul=N
                  g.dw, g.pt, g.pl, Tp, ACT_CODE[act], alpha, my, ma, mal, _stream())
     if rc:
         raise ValueError("col2im_1ch rejected")
+    _done()
+    return img
+
+
+TAPFOLD = os.environ.get("DDL_TAPFOLD", "1") == "1"
+
+
+def tapfold_1ch(x, w, g: ConvGeom, bias=None, act=None, alpha=0.3, out=None, mul=None):
+    """Fused taps GEMM + fold (csrc/hip/onech_fused.hip): x [B][g.OH][g.OW][Cp], w [T][Cp] (bf16) ->
+    single-channel image [B][g.H][g.W][8] = act(bias + fold_t(x . w[t])), optionally *= act'(mul y).
+    Returns None when the shape is outside the fused kernel's range (caller uses gemm + col2im_1ch)."""
+    if not TAPFOLD:
+        return None
+    _chk_act(x, "x")
+    B, Cp = x.shape[0], x.shape[-1]
+    T = g.KH * g.KW
+    if tuple(x.shape[1:3]) != (g.OH, g.OW):
+        raise ValueError(f"tapfold_1ch: x {tuple(x.shape)} vs geometry {g}")
+    if not (w.is_cuda and w.dtype == torch.bfloat16 and w.is_contiguous()) or w.numel() < T * Cp:
+        raise ValueError("tapfold_1ch: weights must be contiguous bf16 [T][Cp]")
+    if T > 32 or Cp > 128:
+        return None
+    if bias is not None:
+        _chk_f32(bias, 1, "bias")
+    if out is not None:
+        _chk_act(out, "out")
+        if tuple(out.shape) != (B, g.H, g.W, 8):
+            raise ValueError(f"tapfold_1ch: out {tuple(out.shape)} != {(B, g.H, g.W, 8)}")
+        img = out
+    else:
+        img = torch.empty(B, g.H, g.W, 8, dtype=torch.bfloat16, device=x.device)
+    my, ma, mal = _mul_args(mul, img)
+    rc = _tapfold(x.data_ptr(), w.data_ptr(), _p(bias), img.data_ptr(), B, g.H, g.W, g.OH, g.OW, Cp, g.KH, g.KW,
+                  g.sh, g.sw, g.dh, g.dw, g.pt, g.pl, ACT_CODE[act], alpha, my, ma, mal, _stream())
+    if rc < 0:
+        raise ValueError(f"tapfold_1ch rejected its arguments (rc={rc})")
+    if rc > 0:
+        return None
     _done()
     return img
 

@@ -389,3 +389,28 @@ def test_onech_im2col_col2im(hip, case, B):
     assert float(out[..., 1:].float().abs().max()) == 0.0
     plain = hip.col2im_1ch(c.bfloat16().cuda().contiguous(), g)
     close(plain[..., 0].float().cpu(), fold, rtol=2e-2)
+
+
+@pytest.mark.parametrize("case", ONECH_CASES)
+@pytest.mark.parametrize("C", [32, 24, 64])
+def test_tapfold_fused_equals_gemm_plus_col2im(hip, case, C):
+    """Fused taps-GEMM + fold must reproduce the two-kernel path bit for bit (same MFMA order, same bf16
+    rounding of the taps tensor, same fold order), with bias/activation and the fused act' multiply."""
+    H, W, k, s, d, pad = case
+    g = G.conv2d_geom(H, W, 1, C, k, s, d, pad)
+    T, Tp = g.KH * g.KW, hip.pad8(g.KH * g.KW)
+    if T > 32:
+        pytest.skip("outside the fused kernel's range")
+    B = 19
+    torch.manual_seed(12)
+    x = (torch.randn(B, g.OH, g.OW, C) * 0.5).bfloat16().cuda().contiguous()
+    w = (torch.randn(T, C) * 0.2).bfloat16().cuda().contiguous()
+    bias = torch.tensor([0.1], device="cuda")
+    ymul = torch.rand(B, H, W, 8, device="cuda").bfloat16()
+    g1 = G.ConvGeom(g.OH, g.OW, C, g.OH, g.OW, T, 1, 1).check()
+    z = hip.conv_fprop(x, w.reshape(T, 1, 1, C), None, g1)
+    for kw in (dict(), dict(bias=bias, act="tanh01"), dict(mul=(ymul, "tanh01", 0.3))):
+        ref = hip.col2im_1ch(z, g, **kw)
+        got = hip.tapfold_1ch(x, w, g, **kw)
+        assert got is not None
+        assert torch.equal(got, ref), kw.keys()
