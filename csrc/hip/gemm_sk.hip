@@ -2,7 +2,8 @@
 //
 //     Y[m][n] = act(bias[n] + sum_k X[m][k] * W[n][k])      X [M][K], W [Nw][K], Y [M][Nd], bf16
 //
-// with K <= 128 and Nd <= 128: the taps-as-channels form of the single-channel convolutions, 1x1
+// with K <= 128; Nd <= 128 in one tile, wider outputs (the generator's Dense 128 -> 6272) as 128-wide
+// column tiles over blockIdx.y (X is re-read per tile from cache): the taps-as-channels form of the single-channel convolutions, 1x1
 // layers of the random search space, and their data gradients.  With so little K the kernel is a
 // pure streaming problem (read X once, write Y once), so there is no LDS staging of the pixel
 // operand at all: a lane's MFMA fragment -- 8 consecutive k of one row -- is exactly one 16-byte
@@ -31,12 +32,13 @@ __global__ __launch_bounds__(256) void gemm_sk_kernel(const GemmSkArgs a) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int fr = lane & 15, fq = lane >> 4;
     const int K = a.K;
+    const int n0 = blockIdx.y * BN;             // column tile
 
     // ---- weights -> LDS (zero rows beyond Nw, zero k beyond K)
     for (int u = tid; u < BN * (KP / 8); u += 256) {
         int n = u / (KP / 8), k8 = u - n * (KP / 8);
         uint4 v = make_uint4(0, 0, 0, 0);
-        if (n < a.Nw && k8 * 8 < K) v = *(const uint4*)(a.w + (long)n * K + k8 * 8);
+        if (n0 + n < a.Nw && k8 * 8 < K) v = *(const uint4*)(a.w + (long)(n0 + n) * K + k8 * 8);
         *(uint4*)(sW + n * WP + k8 * 16) = v;
     }
     __syncthreads();
@@ -46,7 +48,7 @@ __global__ __launch_bounds__(256) void gemm_sk_kernel(const GemmSkArgs a) {
     for (int t = 0; t < NT; ++t)
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            int n = 16 * t + 4 * fq + e;
+            int n = n0 + 16 * t + 4 * fq + e;
             bv[t][e] = (a.bias && n < a.Nw) ? a.bias[n] : 0.f;
         }
 
@@ -93,7 +95,7 @@ __global__ __launch_bounds__(256) void gemm_sk_kernel(const GemmSkArgs a) {
                     if (SLOW) v = act_apply(v, act, alpha);
                     else if (act == ACT_RELU) v = fmaxf(v, 0.f);
                     else if (act == ACT_LEAKY) v = v > 0.f ? v : alpha * v;
-                    acc[t][j][e] = (16 * t + 4 * fq + e < a.Nw) ? v : 0.f;
+                    acc[t][j][e] = (n0 + 16 * t + 4 * fq + e < a.Nw) ? v : 0.f;
                 }
         // ---- transposed store: 16 rows at a time through the wave's LDS scratch
 #pragma unroll
@@ -109,8 +111,8 @@ __global__ __launch_bounds__(256) void gemm_sk_kernel(const GemmSkArgs a) {
             for (int u = lane; u < 16 * (BN / 8); u += 64) {
                 int px = u / (BN / 8), c8 = u - px * (BN / 8);
                 long m = m0 + 16 * j + px;
-                if (m < a.M && c8 * 8 < a.Nd)
-                    *(uint4*)(a.y + m * a.Nd + c8 * 8) = *(const uint4*)(sE + px * EROW + c8 * 16);
+                if (m < a.M && n0 + c8 * 8 < a.Nd)
+                    *(uint4*)(a.y + m * a.Nd + n0 + c8 * 8) = *(const uint4*)(sE + px * EROW + c8 * 16);
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
             __builtin_amdgcn_wave_barrier();
@@ -125,7 +127,7 @@ static int launch_sk(const GemmSkArgs& a, hipStream_t s) {
     size_t smem = (size_t)BN * SK_WPITCH(KP) + 4 * 16 * (BN * 2 + 16);
     constexpr int FRG = NT >= 8 ? 1 : (NT >= 4 ? 2 : 4);
     long blocks = (a.M + 64 * FRG - 1) / (64 * FRG);
-    int grid = (int)(blocks > 8192 ? 8192 : blocks);
+    dim3 grid((unsigned)(blocks > 8192 ? 8192 : blocks), (unsigned)((a.Nd + BN - 1) / BN));
     const bool fast = a.act == ACT_LINEAR || a.act == ACT_RELU || a.act == ACT_LEAKY;
     if (fast) gemm_sk_kernel<NT, KS, false><<<grid, 256, smem, s>>>(a);
     else gemm_sk_kernel<NT, KS, true><<<grid, 256, smem, s>>>(a);
@@ -136,7 +138,9 @@ static int launch_sk(const GemmSkArgs& a, hipStream_t s) {
 DDL_API int ddl_gemm_sk(const void* x, const void* w, const float* bias, void* y, long M, int K, int Nd, int Nw,
                         int act, float alpha, hipStream_t s) {
     if (K % 8 || Nd % 8 || K <= 0 || Nd <= 0 || M <= 0) return -1;
-    if (K > 128 || Nd > 128) return 1;
+    if (K > 128) return 1;
+    // wide outputs: 128-wide column tiles, only while X (re-read once per tile) stays small next to Y
+    if (Nd > 128 && (M * (long)K > (8L << 20) || Nd > 65535 * 128L)) return 1;
     GemmSkArgs a{(const bf16_t*)x, (const bf16_t*)w, bias, (bf16_t*)y, M, K, Nd, Nw, act, alpha};
     const int NT = (Nd + 15) / 16, KS = (K + 31) / 32;
     const int nt = NT <= 1 ? 1 : (NT <= 2 ? 2 : (NT <= 4 ? 4 : 8));

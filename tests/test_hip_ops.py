@@ -414,3 +414,16 @@ def test_tapfold_fused_equals_gemm_plus_col2im(hip, case, C):
         got = hip.tapfold_1ch(x, w, g, **kw)
         assert got is not None
         assert torch.equal(got, ref), kw.keys()
+
+
+@pytest.mark.parametrize("K,N,B", [(128, 6272, 1000), (96, 300, 37), (40, 136, 70)])
+def test_dense_wide_output_skinny_k(hip, K, N, B):
+    """Dense with K <= 128 and a wide output (G1: 128 -> 6272) runs on gemm_sk's column tiles."""
+    g = G.dense_geom(K, N)
+    torch.manual_seed(13)
+    x = r16(torch.randn(B, 1, 1, K))
+    w = r16(torch.randn(N, 1, 1, K) / 8)
+    b = torch.randn(N)
+    y = hip.conv_fprop(dev(hip, x), padw(hip, w), b.cuda(), g, "relu")
+    close(host(hip, y, N), cpu_ref.conv_fprop(x, w, b, g, "relu"))
+    assert y.shape[-1] == hip.pad8(N) and (N % 8 == 0 or float(y[..., N:].float().abs().max()) == 0.0)
