@@ -285,10 +285,13 @@ DDL_API void ddl_argmax_match(const float* pred, const float* onehot, int B, int
 // kind: 0 adam, 1 sgd, 2 rmsprop, 3 adam_fresh_double.
 // If `avg` != nullptr the result is blended in place: p = (1-avg_w)*p_new + avg_w*avg[i]
 // (periodic weight averaging folded into the update, [R-ns]).
+// A one-thread launch advances the step counter.  (Folding the increment into optim_kernel through a
+// "last block to finish" atomic was measured slower: ~1000 blocks x one returning atomic on a single
+// word costs ~12 us at ~88 atomics/us, more than this launch.)
 __global__ void step_inc_kernel(int* step) { step[0] += 1; }
 
 __global__ void optim_kernel(float4* __restrict__ P, const float4* __restrict__ G, float4* __restrict__ Mo,
-                             float4* __restrict__ Vo, uint2* __restrict__ Pc, const int* __restrict__ step,
+                             float4* __restrict__ Vo, uint2* __restrict__ Pc, int* __restrict__ step,
                              long n4, int kind, float lr, float b1, float b2, float eps, float rho,
                              float gscale, const float4* __restrict__ avg, float avg_w) {
     float lr_t = lr, lr_2 = lr;
@@ -385,7 +388,8 @@ __device__ __forceinline__ void philox_round(uint32_t* c, uint32_t k0, uint32_t 
     c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
 }
 
-__global__ void philox_uniform_kernel(bf16_t* __restrict__ out, long n, const long* __restrict__ state,
+// state = {seed, offset, scratch}: the last block to finish advances the offset (see last_block_increments)
+__global__ void philox_uniform_kernel(bf16_t* __restrict__ out, long n, long* __restrict__ state,
                                       float lo, float hi) {
     const uint64_t seed = (uint64_t)state[0], off = (uint64_t)state[1];
     const long n4 = (n + 3) / 4;
@@ -403,16 +407,21 @@ __global__ void philox_uniform_kernel(bf16_t* __restrict__ out, long n, const lo
             }
         }
     }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long* done = (unsigned long long*)(state + 2);
+        if (atomicAdd(done, 1ULL) == (unsigned long long)gridDim.x - 1ULL) {
+            *done = 0ULL;
+            atomicAdd((unsigned long long*)(state + 1), 1ULL);
+        }
+    }
 }
-
-__global__ void philox_advance_kernel(long* state) { state[1] += 1; }
 
 DDL_API void ddl_philox_uniform(void* out, long n, long* state, float lo, float hi, hipStream_t s) {
     long n4 = (n + 3) / 4;
     long g = (n4 + 255) / 256;
     int grid = (int)(g > 2048 ? 2048 : (g < 1 ? 1 : g));
     philox_uniform_kernel<<<grid, 256, 0, s>>>((bf16_t*)out, n, state, lo, hi);
-    philox_advance_kernel<<<1, 1, 0, s>>>(state);
 }
 
 // Delayed (overlapped) periodic averaging, local-SGD style [R-ns]: while ranks kept training, an

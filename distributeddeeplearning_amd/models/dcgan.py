@@ -87,7 +87,7 @@ class DeviceRNG:
         self.device = torch.device(device)
         self.seed = int(seed)
         if self.device.type == "cuda":
-            self.state = torch.zeros(2, dtype=torch.int64, device=self.device)
+            self.state = torch.zeros(3, dtype=torch.int64, device=self.device)     # seed, offset, kernel scratch
             self.state[0] = self.seed
         else:
             self.gen = torch.Generator().manual_seed(self.seed)

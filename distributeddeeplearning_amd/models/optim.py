@@ -49,7 +49,8 @@ class FlatOptimizer:
         self.m = torch.zeros_like(net.P) if need_m else None
         self.v = torch.zeros_like(net.P) if need_v else None
         # device-side step counter so a captured hipGraph advances bias correction on replay
-        self.step_dev = torch.zeros(1, dtype=torch.int32, device=dev) if net.on_gpu else None
+        # [steps taken, scratch counter of the fused kernel's last-block increment]
+        self.step_dev = torch.zeros(2, dtype=torch.int32, device=dev) if net.on_gpu else None
 
     def zero_grad(self):
         self.net.G.zero_()
@@ -83,7 +84,8 @@ class FlatOptimizer:
         if self.v is not None and sd.get("v") is not None:
             self.v.copy_(sd["v"])
         if self.step_dev is not None:
-            self.step_dev.fill_(self.t)
+            self.step_dev.zero_()
+            self.step_dev[0] = self.t
 
 
 class ShardedFlatOptimizer(FlatOptimizer):
@@ -108,7 +110,7 @@ class ShardedFlatOptimizer(FlatOptimizer):
         self.pshard[:self.hi - self.lo].copy_(net.P[self.lo:self.hi])
         self.m = torch.zeros(self.chunk, dtype=net.P.dtype, device=dev) if cfg.kind == "adam" else None
         self.v = torch.zeros(self.chunk, dtype=net.P.dtype, device=dev) if cfg.kind in ("adam", "rmsprop") else None
-        self.step_dev = torch.zeros(1, dtype=torch.int32, device=dev) if net.on_gpu else None
+        self.step_dev = torch.zeros(2, dtype=torch.int32, device=dev) if net.on_gpu else None
 
     def step(self, grad_scale: Optional[float] = None):
         net, c, dp = self.net, self.cfg, self.dp

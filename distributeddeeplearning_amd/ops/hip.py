@@ -557,6 +557,8 @@ _OPT_KIND = {"adam": 0, "sgd": 1, "rmsprop": 2, "adam_fresh_double": 3}
 def optimizer_step(opt, grad_scale=1.0, avg_with=None, avg_weight=0.0):
     net, c = opt.net, opt.cfg
     n = net.P.numel()
+    if opt.step_dev.numel() < 2:
+        raise ValueError("step_dev must hold [steps, scratch]")
     if avg_with is not None:
         _chk_f32(avg_with, n, "avg_with")
     _optim_step(net.P.data_ptr(), net.G.data_ptr(), _p(opt.m), _p(opt.v), net.Pc.data_ptr(),
@@ -568,6 +570,8 @@ def optimizer_step(opt, grad_scale=1.0, avg_with=None, avg_weight=0.0):
 def optimizer_step_flat(P, G, m, v, Pc, step_dev, c, grad_scale=1.0):
     """The fused update on explicit flat tensors (a shard of a network's buffers: ZeRO-1 mode)."""
     n = P.numel()
+    if step_dev.numel() < 2:
+        raise ValueError("step_dev must hold [steps, scratch]")
     _chk_f32(G, n, "grad shard")
     _optim_step(P.data_ptr(), G.data_ptr(), _p(m), _p(v), _p(Pc), step_dev.data_ptr(), n, _OPT_KIND[c.kind],
                 c.lr, c.beta1, c.beta2, c.eps, c.rho, grad_scale, None, 0.0, _stream())
@@ -591,6 +595,8 @@ def avg_delta(P, Pc, total, snap, inv_world):
 def philox_uniform(shape, dtype, state, lo=-1.0, hi=1.0):
     if dtype != torch.bfloat16:
         raise ValueError("device noise is generated in bf16")
+    if state.dtype != torch.int64 or state.numel() < 3 or not state.is_cuda:
+        raise ValueError("philox state must be a cuda int64 tensor [seed, offset, scratch]")
     out = torch.empty(shape, dtype=dtype, device=state.device)
     _philox(out.data_ptr(), out.numel(), state.data_ptr(), lo, hi, _stream())
     _done()

@@ -326,7 +326,7 @@ def test_optimizers_match_oracle(hip, kind):
 
 
 def test_philox(hip):
-    st = torch.zeros(2, dtype=torch.int64, device="cuda")
+    st = torch.zeros(3, dtype=torch.int64, device="cuda")
     st[0] = 1234
     a = hip.philox_uniform((1000, 128), torch.bfloat16, st).float()
     b = hip.philox_uniform((1000, 128), torch.bfloat16, st).float()
