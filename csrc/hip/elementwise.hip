@@ -295,6 +295,15 @@ DDL_API void ddl_bn_batch_stats(const void* x, long rows, int C, float* part, co
                                                              shift, mean, invstd);
 }
 
+// Batch statistics from partials a producer kernel already wrote (pconv's STATS epilogue): finalize only.
+DDL_API void ddl_bn_stats_from_part(const float* part, int nblocks, long rows, int C, const float* gamma,
+                                    const float* beta, float* mm, float* mv, float momentum, float eps, int bessel,
+                                    int update_moving, float* scale, float* shift, float* mean, float* invstd,
+                                    hipStream_t s) {
+    bn_stats_finalize_kernel<<<FIN_GRID(C), FIN_BLOCK, 0, s>>>(part, nblocks, C, rows, gamma, beta, mm, mv, momentum,
+                                                             eps, bessel, update_moving, scale, shift, mean, invstd);
+}
+
 // Inference-phase BN: scale/shift from the moving statistics (tiny, one launch).
 __global__ void bn_infer_affine_kernel(const float* gamma, const float* beta, const float* mm, const float* mv,
                                        float eps, int C, float* scale, float* shift, float* invstd) {

@@ -40,6 +40,10 @@ struct PConvArgs {
     int pitch, img_bytes;          // bytes per patch pixel / per patch image
     int w_off, k_off, e_off;       // LDS offsets: weight stages, k-unit table, epilogue scratch
     float inv_per_img, inv_cs8, inv_PW;   // reciprocals for the staging loop's index split
+    // STATS instantiation: per-block partial sums of the (bf16-rounded) outputs and their squares, laid out
+    // part[2][Nd][gridDim.x] like the column-reduction kernels' partials -- the BatchNorm that follows reads
+    // its batch statistics from here instead of making a pass over the output tensor.
+    float* stats;
 };
 
 // floor(x / d) for 0 <= x < 2^22 via a float reciprocal (the +0.5 keeps x/d away from integers)
@@ -52,7 +56,7 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 // SLOW = the activation is one of the transcendental ones (sigmoid / softplus / tanh / softsign /
 // tanh01): only that instantiation carries their (fully unrolled) code.
-template <int BN, int FR, bool SLOW>
+template <int BN, int FR, bool SLOW, bool STATS>
 __global__ __launch_bounds__(256, (BN * FR >= 512 ? 1 : 2)) void pconv_kernel(const PConvArgs a) {
     constexpr int NT = BN / 16;                        // 16-channel MFMA tiles per wave
     constexpr int RW = (BN * 8 + 255) / 256;           // 16-B weight units staged per thread per stage
@@ -135,6 +139,14 @@ __global__ __launch_bounds__(256, (BN * FR >= 512 ? 1 : 2)) void pconv_kernel(co
         }
     };
     if (HOIST_BIAS) load_bias();
+
+    float st_s[STATS ? NT : 1][4], st_q[STATS ? NT : 1][4];
+    if (STATS) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) st_s[t][e] = st_q[t][e] = 0.f;
+    }
 
     for (int ci = 0; ci < a.n_classes; ++ci) {
         const PClass cd = a.classes[ci];
@@ -283,6 +295,14 @@ __global__ __launch_bounds__(256, (BN * FR >= 512 ? 1 : 2)) void pconv_kernel(co
                         for (int e = 0; e < 4; ++e) v[e] = (16 * t + e < nlim) ? acc[t][j][e] : 0.f;
                         *(uint2*)(sE + fr * EROW + (16 * t + 4 * fq) * 2) =
                             make_uint2(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]));
+                        if (STATS) {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                const float r = ok ? bf2f(f2bf(v[e])) : 0.f;     // what the stored tensor holds
+                                st_s[t][e] += r;
+                                st_q[t][e] = fmaf(r, r, st_q[t][e]);
+                            }
+                        }
                     }
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
                     __builtin_amdgcn_wave_barrier();
@@ -302,27 +322,65 @@ __global__ __launch_bounds__(256, (BN * FR >= 512 ? 1 : 2)) void pconv_kernel(co
             }
         }
     }
+
+    if (STATS) {
+        // lanes sharing fq hold the same channels for 16 different pixels: fold them, then the four waves
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int o = 1; o < 16; o <<= 1) {
+                    st_s[t][e] += __shfl_xor(st_s[t][e], o, 64);
+                    st_q[t][e] += __shfl_xor(st_q[t][e], o, 64);
+                }
+        __syncthreads();                                   // every wave is done with the weight stages
+        float* red = (float*)sW;                           // [4 waves][BN][2]
+        if (fr == 0) {
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int c = 16 * t + 4 * fq + e;
+                    red[(wave * BN + c) * 2 + 0] = st_s[t][e];
+                    red[(wave * BN + c) * 2 + 1] = st_q[t][e];
+                }
+        }
+        __syncthreads();
+        if (tid < BN && n0 + tid < a.Nd) {
+            float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) { s0 += red[(w * BN + tid) * 2]; s1 += red[(w * BN + tid) * 2 + 1]; }
+            const size_t nb = gridDim.x;
+            a.stats[((size_t)(n0 + tid)) * nb + blockIdx.x] = s0;
+            a.stats[((size_t)(a.Nd + n0 + tid)) * nb + blockIdx.x] = s1;
+        }
+    }
 }
 
-template <int BN, int FR, bool SLOW>
+template <int BN, int FR, bool SLOW, bool STATS>
 static int launch_pconv2(PConvArgs& a, int units, size_t smem, hipStream_t s) {
     if (smem > 64 * 1024) {
         static bool done = false;
         if (!done) {
-            hipFuncSetAttribute((const void*)pconv_kernel<BN, FR, SLOW>, hipFuncAttributeMaxDynamicSharedMemorySize,
+            hipFuncSetAttribute((const void*)pconv_kernel<BN, FR, SLOW, STATS>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 160 * 1024);
             done = true;
         }
     }
     dim3 grid(units, (a.Nd + BN - 1) / BN);
-    pconv_kernel<BN, FR, SLOW><<<grid, 256, smem, s>>>(a);
+    pconv_kernel<BN, FR, SLOW, STATS><<<grid, 256, smem, s>>>(a);
     return 0;
 }
 
 template <int BN, int FR>
 static int launch_pconv(PConvArgs& a, int units, size_t smem, hipStream_t s) {
     const bool fast = a.act == ACT_LINEAR || a.act == ACT_RELU || a.act == ACT_LEAKY;
-    return fast ? launch_pconv2<BN, FR, false>(a, units, smem, s) : launch_pconv2<BN, FR, true>(a, units, smem, s);
+    if (a.stats)
+        return fast ? launch_pconv2<BN, FR, false, true>(a, units, smem, s)
+                    : launch_pconv2<BN, FR, true, true>(a, units, smem, s);
+    return fast ? launch_pconv2<BN, FR, false, false>(a, units, smem, s)
+                : launch_pconv2<BN, FR, true, false>(a, units, smem, s);
 }
 
 DDL_API int ddl_pconv_lds_bytes(int BN, int total_stages, long patch_bytes) {
@@ -338,7 +396,7 @@ DDL_API int ddl_pconv(const void* src, const void* wgt, const float* bias, void*
                       const void* ktab, int n_classes, int total_stages, int B, int Hs, int Ws, int Cs, int Hd,
                       int Wd, int Nd, int Nw, int ssh, int ssw, int sdh, int sdw, int Ttot, int act, float alpha,
                       int IMG, int BR, int bands, int omin_h, int omin_w, int PH, int PW, int pitch, int BN, int FR,
-                      hipStream_t s) {
+                      float* stats, hipStream_t s) {
     if (Cs % 8 != 0 || Cs <= 0 || Nd <= 0 || Nd % 8 != 0 || n_classes <= 0 || B <= 0 || IMG <= 0 || BR <= 0) return -1;
     if (pitch % 16 != 0 || pitch < Cs * 2) return -1;
     if ((long)B * Hs * Ws * Cs >= (1L << 31) || (long)B * Hd * Wd * Nd >= (1L << 31)) return -3;
@@ -346,6 +404,7 @@ DDL_API int ddl_pconv(const void* src, const void* wgt, const float* bias, void*
     PConvArgs a;
     a.src = (const bf16_t*)src; a.wgt = (const bf16_t*)wgt; a.bias = bias; a.dst = (bf16_t*)dst;
     a.classes = (const PClass*)classes; a.ktab = (const int2*)ktab;
+    a.stats = stats;
     a.n_classes = n_classes; a.total_stages = total_stages;
     a.B = B; a.Hs = Hs; a.Ws = Ws; a.Cs = Cs; a.Hd = Hd; a.Wd = Wd; a.Nd = Nd; a.Nw = Nw;
     a.ssh = ssh; a.ssw = ssw; a.sdh = sdh; a.sdw = sdw; a.wrow = Ttot * Cs; a.act = act; a.alpha = alpha;

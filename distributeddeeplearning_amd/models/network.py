@@ -253,14 +253,19 @@ class ConvOp(Op):
         g = self.g
         if self.onech:
             return self._fwd_onech(x, training)
+        # a batch-statistics BN right behind this layer: let the conv kernel emit the statistics' partial sums
+        bn = self.next_bn
+        so = {} if (training and bn is not None and bn.mode == "batch" and x.is_cuda) else None
         if self.kind == "dense":
             B = x.shape[0]
             x4 = x.reshape(B, 1, 1, -1)
             y = F.conv_fprop(x4, self._w4(self.w_main), self.bias, g, self.act, self.alpha).reshape(B, -1)
         elif self.kind == "conv2d_transpose":
-            y = F.conv_dgrad(x, self.w_main, g, self.bias, self.act, self.alpha)
+            y = F.conv_dgrad(x, self.w_main, g, self.bias, self.act, self.alpha, stats_out=so)
         else:
-            y = F.conv_fprop(x, self.w_main, self.bias, g, self.act, self.alpha)
+            y = F.conv_fprop(x, self.w_main, self.bias, g, self.act, self.alpha, stats_out=so)
+        if so:
+            bn.pre_stats = (so["part"], so["nb"])
         if training:
             self.x, self.y = x, y
         return y
@@ -326,13 +331,19 @@ class BNOp(Op):
         self.x = self.y = self.mean = self.invstd = None
         self.used_batch_stats = False
         self.bias_grad_for = None      # ConvOp (with a fused activation) whose bias gradient our backward emits
+        self.pre_stats = None          # (partials, n_blocks) left by the producing conv kernel for the next fwd
 
     def fwd(self, x, training):
         use_batch = training and self.mode == "batch"
         if not training:            # pure inference: one fused launch, nothing kept
             return F.bn_apply_infer(x, self.gamma, self.beta, self.moving_mean, self.moving_var, self.eps,
                                     self.post_act, self.post_alpha, self.C)
-        if use_batch:
+        pre, self.pre_stats = self.pre_stats, None
+        if use_batch and pre is not None:
+            scale, shift, mean, invstd = F.bn_train_affine_from_part(
+                pre[0], pre[1], x.numel() // x.shape[-1], self.gamma, self.beta, self.moving_mean,
+                self.moving_var, self.momentum, self.eps, self.rank4, True)
+        elif use_batch:
             scale, shift, mean, invstd = F.bn_train_affine(x, self.gamma, self.beta, self.moving_mean,
                                                            self.moving_var, self.momentum, self.eps,
                                                            self.rank4, True)

@@ -38,19 +38,20 @@ def _cpu_mul(t, mul):
     return cpu_ref.act_bwd(t, y.reshape(t.shape), act, alpha)
 
 
-def conv_fprop(x, wA, bias, g, act=None, alpha=0.3, mul=None):
+def conv_fprop(x, wA, bias, g, act=None, alpha=0.3, mul=None, stats_out=None):
     """`mul` = (y, act, alpha): result *= act'(y), the activation backward of the layer below (fused
-    into the kernel epilogue on device)."""
+    into the kernel epilogue on device).  `stats_out` (dict): on device, a kernel that can emit the
+    output's per-channel partial sums for a following BatchNorm leaves them in stats_out["part"/"nb"]."""
     if x.is_cuda:
-        return hip_backend().conv_fprop(x, wA, bias, g, act, alpha, mul)
+        return hip_backend().conv_fprop(x, wA, bias, g, act, alpha, mul, stats_out)
     return _cpu_mul(cpu_ref.conv_fprop(x, wA, bias, g, act, alpha), mul)
 
 
-def conv_dgrad(dy, wB, g, bias=None, act=None, alpha=0.3, mul=None):
+def conv_dgrad(dy, wB, g, bias=None, act=None, alpha=0.3, mul=None, stats_out=None):
     """`wB` is the core weight in [I][KH][KW][O] order (reduction channel contiguous);
     depthwise: [KH][KW][C]."""
     if dy.is_cuda:
-        return hip_backend().conv_dgrad(dy, wB, g, bias, act, alpha, mul)
+        return hip_backend().conv_dgrad(dy, wB, g, bias, act, alpha, mul, stats_out)
     wA = wB if g.depthwise else wB.permute(3, 1, 2, 0)
     return _cpu_mul(cpu_ref.conv_dgrad(dy, wA, g, bias, act, alpha), mul)
 
@@ -118,6 +119,12 @@ def bn_train_affine(x, gamma, beta, mm, mv, momentum, eps, bessel, update_moving
         v = var * (count / max(count - 1, 1)) if bessel else var
         mv.mul_(momentum).add_(v, alpha=1 - momentum)
     return scale, shift, mean, invstd
+
+
+def bn_train_affine_from_part(part, nb, rows, gamma, beta, mm, mv, momentum, eps, bessel, update_moving=True):
+    """Device only: batch statistics from partial sums the producing conv kernel already wrote."""
+    return hip_backend().bn_train_affine_from_part(part, nb, rows, gamma, beta, mm, mv, momentum, eps, bessel,
+                                                   update_moving)
 
 
 def bn_infer_affine(gamma, beta, mm, mv, eps):

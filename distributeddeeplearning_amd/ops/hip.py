@@ -46,6 +46,7 @@ _act_fwd = _sig("ddl_act_fwd", None, vp, vp, cl, ci, ci, ci, cf, vp)
 _act_bwd = _sig("ddl_act_bwd", None, vp, vp, vp, cl, ci, cf, vp)
 _colreduce_blocks = _sig("ddl_colreduce_blocks", ci, cl, ci)
 _bn_batch_stats = _sig("ddl_bn_batch_stats", None, vp, cl, ci, vp, vp, vp, vp, vp, cf, cf, ci, ci, vp, vp, vp, vp, vp)
+_bn_stats_from_part = _sig("ddl_bn_stats_from_part", None, vp, ci, cl, ci, vp, vp, vp, vp, cf, cf, ci, ci, vp, vp, vp, vp, vp)
 _bn_infer_affine = _sig("ddl_bn_infer_affine", None, vp, vp, vp, vp, cf, ci, vp, vp, vp, vp)
 _bn_apply = _sig("ddl_bn_apply", None, vp, vp, vp, vp, cl, ci, ci, ci, cf, vp)
 _bn_apply_infer = _sig("ddl_bn_apply_infer", None, vp, vp, vp, vp, vp, vp, cf, cl, ci, ci, ci, cf, vp)
@@ -77,7 +78,7 @@ _philox = _sig("ddl_philox_uniform", None, vp, cl, vp, cf, cf, vp)
 _igemm = _sig("ddl_igemm_conv", ci, vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci,
               ci, ci, ci, ci, cf, ci, ci, vp, vp)
 _pconv = _sig("ddl_pconv", ci, vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, cf,
-              ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, vp)
+              ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, vp, vp)
 _pconv_lds = _sig("ddl_pconv_lds_bytes", ci, ci, ci, cl)
 _wgrad_ksplit = _sig("ddl_wgrad_ksplit", ci, ci, ci, ci, ci)
 _wgrad = _sig("ddl_conv_wgrad", ci, vp, vp, vp, vp, cl, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci,
@@ -198,6 +199,20 @@ def bn_train_affine(x, gamma, beta, mm, mv, momentum, eps, bessel, update_moving
     _bn_batch_stats(x.data_ptr(), rows, Cp, part.data_ptr(), gamma.data_ptr(), beta.data_ptr(), mm.data_ptr(),
                     mv.data_ptr(), momentum, eps, int(bool(bessel)), int(bool(update_moving)),
                     out[0].data_ptr(), out[1].data_ptr(), out[2].data_ptr(), out[3].data_ptr(), _stream())
+    _done()
+    return out[0], out[1], out[2], out[3]
+
+
+def bn_train_affine_from_part(part, nb, rows, gamma, beta, mm, mv, momentum, eps, bessel, update_moving=True):
+    """`bn_train_affine` when the producer kernel already left per-block partial sums part[2][Cp][nb]."""
+    Cp = gamma.numel()
+    _chk_f32(part, 2 * Cp * nb, "stats partials")
+    for t, n in ((gamma, "gamma"), (beta, "beta"), (mm, "moving_mean"), (mv, "moving_var")):
+        _chk_f32(t, Cp, n)
+    out = torch.empty(4, Cp, dtype=torch.float32, device=gamma.device)
+    _bn_stats_from_part(part.data_ptr(), nb, rows, Cp, gamma.data_ptr(), beta.data_ptr(), mm.data_ptr(), mv.data_ptr(),
+                        momentum, eps, int(bool(bessel)), int(bool(update_moving)), out[0].data_ptr(),
+                        out[1].data_ptr(), out[2].data_ptr(), out[3].data_ptr(), _stream())
     _done()
     return out[0], out[1], out[2], out[3]
 
@@ -777,11 +792,17 @@ _CONV_CHOICE: Dict[Tuple, object] = {}
 AUTOTUNE = os.environ.get("DDL_AUTOTUNE", "1") == "1"
 
 
-def _run_pconv(pl, src, wgt, bias, dst, g, B, Hs, Ws, Cs, Hd, Wd, Nd, Nw, ss, sd, act, alpha, mul=None):
+def _pconv_units(pl, B):
+    return -(-B // pl["IMG"]) * pl["bands"]
+
+
+def _run_pconv(pl, src, wgt, bias, dst, g, B, Hs, Ws, Cs, Hd, Wd, Nd, Nw, ss, sd, act, alpha, mul=None, stats=None):
+    """`stats`: fp32 tensor of 2 * Nd * units elements that receives per-block column sums / sums of squares
+    of the output (layout [2][Nd][units]) for the BatchNorm that follows."""
     rc = _pconv(src.data_ptr(), wgt.data_ptr(), _p(bias), dst.data_ptr(), pl["classes"].data_ptr(),
                 pl["ktab"].data_ptr(), pl["ncls"], pl["nst"], B, Hs, Ws, Cs, Hd, Wd, Nd, Nw, ss[0], ss[1],
                 sd[0], sd[1], g.KH * g.KW, ACT_CODE[act], alpha, pl["IMG"], pl["BR"], pl["bands"],
-                pl["omin_h"], pl["omin_w"], pl["PH"], pl["PW"], pl["pitch"], pl["BN"], pl["FR"], _stream())
+                pl["omin_h"], pl["omin_w"], pl["PH"], pl["PW"], pl["pitch"], pl["BN"], pl["FR"], _p(stats), _stream())
     if rc != 0:
         raise ValueError(f"pconv rejected its plan (rc={rc}): {g} B={B} "
                          f"{ {k: v for k, v in pl.items() if k not in ('classes', 'ktab')} }")
@@ -827,7 +848,11 @@ def _time_us(fn, reps=4, inner=4):
     return best
 
 
-def _igemm_call(src, wgt, bias, dst, g, mode, B, Hs, Ws, Cs, Hd, Wd, Nd, Nw, ss, sd, act, alpha, mul=None):
+PCONV_STATS = os.environ.get("DDL_PCONV_STATS", "1") == "1"
+
+
+def _igemm_call(src, wgt, bias, dst, g, mode, B, Hs, Ws, Cs, Hd, Wd, Nd, Nw, ss, sd, act, alpha, mul=None,
+                stats_out=None):
     """Dispatch one class-grid convolution: the patch-resident kernel with a tuned plan, or the
     global-gather kernel.  The first (non-captured) call of each problem times the candidates on the
     real operands and caches the winner -- these shapes are static for a whole training run."""
@@ -866,7 +891,12 @@ def _igemm_call(src, wgt, bias, dst, g, mode, B, Hs, Ws, Cs, Hd, Wd, Nd, Nw, ss,
             choice = ("pconv", pl) if pl is not None else ("igemm", None)
         _CONV_CHOICE[key] = choice
     if choice[0] == "pconv":
-        _run_pconv(choice[1], *args, *tail, mul=mul)
+        stats = None
+        if stats_out is not None and PCONV_STATS and mul is None:
+            nb = _pconv_units(choice[1], B)
+            stats = torch.empty(2 * Nd * nb, dtype=torch.float32, device=src.device)
+            stats_out["part"], stats_out["nb"] = stats, nb
+        _run_pconv(choice[1], *args, *tail, mul=mul, stats=stats)
     else:
         _run_igemm(src, wgt, bias, dst, g, mode, *tail, tile=choice[1])
         _mul_inplace(dst, mul)
@@ -889,7 +919,7 @@ def _is_1x1(g: ConvGeom) -> bool:
             and not g.depthwise)
 
 
-def conv_fprop(x, wA, bias, g: ConvGeom, act=None, alpha=0.3, mul=None):
+def conv_fprop(x, wA, bias, g: ConvGeom, act=None, alpha=0.3, mul=None, stats_out=None):
     """`mul` = (y, act, alpha): multiply the (bf16) result by act'(y) -- the activation backward of the layer
     below, fused into the epilogue when this runs as a transposed conv's input gradient."""
     _chk_act(x, "x")
@@ -922,11 +952,11 @@ def conv_fprop(x, wA, bias, g: ConvGeom, act=None, alpha=0.3, mul=None):
             _done()
             return y
     _igemm_call(x, wA, bias, y, g, "fprop", B, g.H, g.W, Ip, g.OH, g.OW, Op, min(wA.shape[0], g.O),
-                (g.sh, g.sw), (1, 1), act, alpha, mul)
+                (g.sh, g.sw), (1, 1), act, alpha, mul, stats_out)
     return y
 
 
-def conv_dgrad(dy, wB, g: ConvGeom, bias=None, act=None, alpha=0.3, mul=None):
+def conv_dgrad(dy, wB, g: ConvGeom, bias=None, act=None, alpha=0.3, mul=None, stats_out=None):
     _chk_act(dy, "dy")
     B = dy.shape[0]
     Ip, Op = pad8(g.I), pad8(g.O)
@@ -959,7 +989,7 @@ def conv_dgrad(dy, wB, g: ConvGeom, bias=None, act=None, alpha=0.3, mul=None):
             _done()
             return dx
     _igemm_call(dy, wB, bias, dx, g, "dgrad", B, g.OH, g.OW, Op, g.H, g.W, Ip, min(wB.shape[0], g.I),
-                (1, 1), (g.sh, g.sw), act, alpha, mul)
+                (1, 1), (g.sh, g.sw), act, alpha, mul, stats_out)
     return dx
 
 

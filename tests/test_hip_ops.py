@@ -427,3 +427,36 @@ def test_dense_wide_output_skinny_k(hip, K, N, B):
     y = hip.conv_fprop(dev(hip, x), padw(hip, w), b.cuda(), g, "relu")
     close(host(hip, y, N), cpu_ref.conv_fprop(x, w, b, g, "relu"))
     assert y.shape[-1] == hip.pad8(N) and (N % 8 == 0 or float(y[..., N:].float().abs().max()) == 0.0)
+
+
+@pytest.mark.parametrize("shape", [(14, 14, 32, 64, "same", 2, "linear"), (7, 7, 40, 24, "same", 1, "relu")])
+@pytest.mark.parametrize("B", [5, 130])
+def test_pconv_emits_batchnorm_statistics(hip, shape, B):
+    """pconv's STATS epilogue: per-block partial sums of the stored (bf16) output == a column reduction of it."""
+    H, W, I, O, pad, s, act = shape
+    g = G.conv2d_geom(H, W, I, O, (5, 5), (s, s), (1, 1), pad)
+    torch.manual_seed(21)
+    x = dev(hip, r16(torch.randn(B, H, W, I)))
+    w = padw(hip, r16(torch.randn(O, 5, 5, I) / 20))
+    bias = torch.randn(O).cuda()
+    Ip, Op = hip.pad8(I), hip.pad8(O)
+    pl = hip._pconv_plan(g, "fprop", B, Ip, Op, (g.sh, g.sw), x.device, min_rows=16)
+    assert pl is not None
+    nb = hip._pconv_units(pl, B)
+    y = torch.empty(B, g.OH, g.OW, Op, dtype=torch.bfloat16, device="cuda")
+    part = torch.full((2 * Op * nb,), float("nan"), device="cuda")
+    hip._run_pconv(pl, x, w, bias, y, g, B, g.H, g.W, Ip, g.OH, g.OW, Op, O, (g.sh, g.sw), (1, 1), act, 0.3,
+                   stats=part)
+    y2 = hip.conv_fprop(x, w, bias, g, act)
+    assert torch.equal(y, y2) or torch.allclose(y.float(), y2.float(), rtol=2e-2, atol=2e-2)
+    sums = part.view(2, Op, nb).double().sum(-1).cpu()
+    yf = y.float().reshape(-1, Op).double().cpu()
+    assert torch.allclose(sums[0], yf.sum(0), rtol=1e-4, atol=1e-2)
+    assert torch.allclose(sums[1], (yf * yf).sum(0), rtol=1e-4, atol=1e-2)
+    gamma, beta = torch.ones(Op).cuda(), torch.zeros(Op).cuda()
+    mm1, mv1, mm2, mv2 = (torch.zeros(Op).cuda(), torch.ones(Op).cuda(), torch.zeros(Op).cuda(), torch.ones(Op).cuda())
+    a = hip.bn_train_affine_from_part(part, nb, B * g.OH * g.OW, gamma, beta, mm1, mv1, 0.99, 1e-3, True)
+    b = hip.bn_train_affine(y, gamma, beta, mm2, mv2, 0.99, 1e-3, True)
+    for u, v in zip(a, b):
+        assert torch.allclose(u, v, rtol=1e-4, atol=1e-5)
+    assert torch.allclose(mm1, mm2, rtol=1e-4, atol=1e-6) and torch.allclose(mv1, mv2, rtol=1e-4, atol=1e-6)
