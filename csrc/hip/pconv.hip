@@ -44,6 +44,9 @@ struct PConvArgs {
     // part[2][Nd][gridDim.x] like the column-reduction kernels' partials -- the BatchNorm that follows reads
     // its batch statistics from here instead of making a pass over the output tensor.
     float* stats;
+    // AFFINE instantiation: an inference-phase BatchNorm right behind this layer, folded into the epilogue:
+    // out = act(conv + bias) * k + (beta - moving_mean * k), k = gamma * rsqrt(moving_var + eps)
+    const float* bn_gamma; const float* bn_beta; const float* bn_mean; const float* bn_var; float bn_eps;
 };
 
 // floor(x / d) for 0 <= x < 2^22 via a float reciprocal (the +0.5 keeps x/d away from integers)
@@ -56,8 +59,10 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 // SLOW = the activation is one of the transcendental ones (sigmoid / softplus / tanh / softsign /
 // tanh01): only that instantiation carries their (fully unrolled) code.
-template <int BN, int FR, bool SLOW, bool STATS>
+// EPI: 0 = plain epilogue, 1 = STATS (batch-statistics partials for a following BN), 2 = AFFINE (inference BN folded in)
+template <int BN, int FR, bool SLOW, int EPI>
 __global__ __launch_bounds__(256, (BN * FR >= 512 ? 1 : 2)) void pconv_kernel(const PConvArgs a) {
+    constexpr bool STATS = EPI == 1, AFFINE = EPI == 2;
     constexpr int NT = BN / 16;                        // 16-channel MFMA tiles per wave
     constexpr int RW = (BN * 8 + 255) / 256;           // 16-B weight units staged per thread per stage
     constexpr int PASS = 4 * FR * 16;                  // rows per pass (4 waves x FR fragments x 16 px)
@@ -140,6 +145,22 @@ __global__ __launch_bounds__(256, (BN * FR >= 512 ? 1 : 2)) void pconv_kernel(co
     };
     if (HOIST_BIAS) load_bias();
 
+    float bnk[AFFINE ? NT : 1][4], bnh[AFFINE ? NT : 1][4];
+    if (AFFINE) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int n = n0 + 16 * t + 4 * fq + e;
+                float k = 0.f, h = 0.f;
+                if (n < a.Nw) {
+                    k = a.bn_gamma[n] * rsqrtf(a.bn_var[n] + a.bn_eps);
+                    h = a.bn_beta[n] - a.bn_mean[n] * k;
+                }
+                bnk[t][e] = k;
+                bnh[t][e] = h;
+            }
+    }
     float st_s[STATS ? NT : 1][4], st_q[STATS ? NT : 1][4];
     if (STATS) {
 #pragma unroll
@@ -276,6 +297,14 @@ __global__ __launch_bounds__(256, (BN * FR >= 512 ? 1 : 2)) void pconv_kernel(co
                                 acc[t][j][e] = x > 0.f ? x : alpha * x;
                             }
                 }
+                if (AFFINE) {
+#pragma unroll
+                    for (int t = 0; t < NT; ++t)
+#pragma unroll
+                        for (int j = 0; j < FR; ++j)
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) acc[t][j][e] = fmaf(acc[t][j][e], bnk[t][e], bnh[t][e]);
+                }
                 // channels >= Nw (padding lanes) must be exactly zero
                 const int nlim = a.Nw - n0 - 4 * fq;       // channel 16t + e is real iff 16t + e < nlim
 #pragma unroll
@@ -358,18 +387,18 @@ __global__ __launch_bounds__(256, (BN * FR >= 512 ? 1 : 2)) void pconv_kernel(co
     }
 }
 
-template <int BN, int FR, bool SLOW, bool STATS>
+template <int BN, int FR, bool SLOW, int EPI>
 static int launch_pconv2(PConvArgs& a, int units, size_t smem, hipStream_t s) {
     if (smem > 64 * 1024) {
         static bool done = false;
         if (!done) {
-            hipFuncSetAttribute((const void*)pconv_kernel<BN, FR, SLOW, STATS>, hipFuncAttributeMaxDynamicSharedMemorySize,
+            hipFuncSetAttribute((const void*)pconv_kernel<BN, FR, SLOW, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 160 * 1024);
             done = true;
         }
     }
     dim3 grid(units, (a.Nd + BN - 1) / BN);
-    pconv_kernel<BN, FR, SLOW, STATS><<<grid, 256, smem, s>>>(a);
+    pconv_kernel<BN, FR, SLOW, EPI><<<grid, 256, smem, s>>>(a);
     return 0;
 }
 
@@ -377,10 +406,10 @@ template <int BN, int FR>
 static int launch_pconv(PConvArgs& a, int units, size_t smem, hipStream_t s) {
     const bool fast = a.act == ACT_LINEAR || a.act == ACT_RELU || a.act == ACT_LEAKY;
     if (a.stats)
-        return fast ? launch_pconv2<BN, FR, false, true>(a, units, smem, s)
-                    : launch_pconv2<BN, FR, true, true>(a, units, smem, s);
-    return fast ? launch_pconv2<BN, FR, false, false>(a, units, smem, s)
-                : launch_pconv2<BN, FR, true, false>(a, units, smem, s);
+        return fast ? launch_pconv2<BN, FR, false, 1>(a, units, smem, s) : launch_pconv2<BN, FR, true, 1>(a, units, smem, s);
+    if (a.bn_gamma)
+        return fast ? launch_pconv2<BN, FR, false, 2>(a, units, smem, s) : launch_pconv2<BN, FR, true, 2>(a, units, smem, s);
+    return fast ? launch_pconv2<BN, FR, false, 0>(a, units, smem, s) : launch_pconv2<BN, FR, true, 0>(a, units, smem, s);
 }
 
 DDL_API int ddl_pconv_lds_bytes(int BN, int total_stages, long patch_bytes) {
@@ -396,7 +425,8 @@ DDL_API int ddl_pconv(const void* src, const void* wgt, const float* bias, void*
                       const void* ktab, int n_classes, int total_stages, int B, int Hs, int Ws, int Cs, int Hd,
                       int Wd, int Nd, int Nw, int ssh, int ssw, int sdh, int sdw, int Ttot, int act, float alpha,
                       int IMG, int BR, int bands, int omin_h, int omin_w, int PH, int PW, int pitch, int BN, int FR,
-                      float* stats, hipStream_t s) {
+                      float* stats, const float* bn_gamma, const float* bn_beta, const float* bn_mean,
+                      const float* bn_var, float bn_eps, hipStream_t s) {
     if (Cs % 8 != 0 || Cs <= 0 || Nd <= 0 || Nd % 8 != 0 || n_classes <= 0 || B <= 0 || IMG <= 0 || BR <= 0) return -1;
     if (pitch % 16 != 0 || pitch < Cs * 2) return -1;
     if ((long)B * Hs * Ws * Cs >= (1L << 31) || (long)B * Hd * Wd * Nd >= (1L << 31)) return -3;
@@ -405,6 +435,8 @@ DDL_API int ddl_pconv(const void* src, const void* wgt, const float* bias, void*
     a.src = (const bf16_t*)src; a.wgt = (const bf16_t*)wgt; a.bias = bias; a.dst = (bf16_t*)dst;
     a.classes = (const PClass*)classes; a.ktab = (const int2*)ktab;
     a.stats = stats;
+    if (stats && bn_gamma) return -1;
+    a.bn_gamma = bn_gamma; a.bn_beta = bn_beta; a.bn_mean = bn_mean; a.bn_var = bn_var; a.bn_eps = bn_eps;
     a.n_classes = n_classes; a.total_stages = total_stages;
     a.B = B; a.Hs = Hs; a.Ws = Ws; a.Cs = Cs; a.Hd = Hd; a.Wd = Wd; a.Nd = Nd; a.Nw = Nw;
     a.ssh = ssh; a.ssw = ssw; a.sdh = sdh; a.sdw = sdw; a.wrow = Ttot * Cs; a.act = act; a.alpha = alpha;

@@ -256,16 +256,22 @@ class ConvOp(Op):
         # a batch-statistics BN right behind this layer: let the conv kernel emit the statistics' partial sums
         bn = self.next_bn
         so = {} if (training and bn is not None and bn.mode == "batch" and x.is_cuda) else None
+        # pure inference with a plain BN behind: the conv epilogue can apply the BN's affine itself
+        bi = None
+        if not training and bn is not None and bn.post_act in (None, "linear") and x.is_cuda:
+            so, bi = {}, (bn.gamma, bn.beta, bn.moving_mean, bn.moving_var, bn.eps)
         if self.kind == "dense":
             B = x.shape[0]
             x4 = x.reshape(B, 1, 1, -1)
             y = F.conv_fprop(x4, self._w4(self.w_main), self.bias, g, self.act, self.alpha).reshape(B, -1)
         elif self.kind == "conv2d_transpose":
-            y = F.conv_dgrad(x, self.w_main, g, self.bias, self.act, self.alpha, stats_out=so)
+            y = F.conv_dgrad(x, self.w_main, g, self.bias, self.act, self.alpha, stats_out=so, bn_infer=bi)
         else:
-            y = F.conv_fprop(x, self.w_main, self.bias, g, self.act, self.alpha, stats_out=so)
-        if so:
+            y = F.conv_fprop(x, self.w_main, self.bias, g, self.act, self.alpha, stats_out=so, bn_infer=bi)
+        if so and "part" in so:
             bn.pre_stats = (so["part"], so["nb"])
+        elif so and so.get("affine"):
+            bn.applied_by_producer = True
         if training:
             self.x, self.y = x, y
         return y
@@ -332,9 +338,13 @@ class BNOp(Op):
         self.used_batch_stats = False
         self.bias_grad_for = None      # ConvOp (with a fused activation) whose bias gradient our backward emits
         self.pre_stats = None          # (partials, n_blocks) left by the producing conv kernel for the next fwd
+        self.applied_by_producer = False   # inference forward: the producing conv already applied this BN
 
     def fwd(self, x, training):
         use_batch = training and self.mode == "batch"
+        if not training and self.applied_by_producer:
+            self.applied_by_producer = False
+            return x
         if not training:            # pure inference: one fused launch, nothing kept
             return F.bn_apply_infer(x, self.gamma, self.beta, self.moving_mean, self.moving_var, self.eps,
                                     self.post_act, self.post_alpha, self.C)

@@ -38,20 +38,22 @@ def _cpu_mul(t, mul):
     return cpu_ref.act_bwd(t, y.reshape(t.shape), act, alpha)
 
 
-def conv_fprop(x, wA, bias, g, act=None, alpha=0.3, mul=None, stats_out=None):
+def conv_fprop(x, wA, bias, g, act=None, alpha=0.3, mul=None, stats_out=None, bn_infer=None):
     """`mul` = (y, act, alpha): result *= act'(y), the activation backward of the layer below (fused
     into the kernel epilogue on device).  `stats_out` (dict): on device, a kernel that can emit the
-    output's per-channel partial sums for a following BatchNorm leaves them in stats_out["part"/"nb"]."""
+    output's per-channel partial sums for a following BatchNorm leaves them in stats_out["part"/"nb"];
+    with `bn_infer` = (gamma, beta, moving_mean, moving_var, eps) a kernel that can fold that inference-phase
+    BatchNorm into its epilogue does so and sets stats_out["affine"]."""
     if x.is_cuda:
-        return hip_backend().conv_fprop(x, wA, bias, g, act, alpha, mul, stats_out)
+        return hip_backend().conv_fprop(x, wA, bias, g, act, alpha, mul, stats_out, bn_infer)
     return _cpu_mul(cpu_ref.conv_fprop(x, wA, bias, g, act, alpha), mul)
 
 
-def conv_dgrad(dy, wB, g, bias=None, act=None, alpha=0.3, mul=None, stats_out=None):
+def conv_dgrad(dy, wB, g, bias=None, act=None, alpha=0.3, mul=None, stats_out=None, bn_infer=None):
     """`wB` is the core weight in [I][KH][KW][O] order (reduction channel contiguous);
     depthwise: [KH][KW][C]."""
     if dy.is_cuda:
-        return hip_backend().conv_dgrad(dy, wB, g, bias, act, alpha, mul, stats_out)
+        return hip_backend().conv_dgrad(dy, wB, g, bias, act, alpha, mul, stats_out, bn_infer)
     wA = wB if g.depthwise else wB.permute(3, 1, 2, 0)
     return _cpu_mul(cpu_ref.conv_dgrad(dy, wA, g, bias, act, alpha), mul)
 

@@ -78,7 +78,7 @@ _philox = _sig("ddl_philox_uniform", None, vp, cl, vp, cf, cf, vp)
 _igemm = _sig("ddl_igemm_conv", ci, vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci,
               ci, ci, ci, ci, cf, ci, ci, vp, vp)
 _pconv = _sig("ddl_pconv", ci, vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, cf,
-              ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, vp, vp)
+              ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, vp, vp, vp, vp, vp, cf, vp)
 _pconv_lds = _sig("ddl_pconv_lds_bytes", ci, ci, ci, cl)
 _wgrad_ksplit = _sig("ddl_wgrad_ksplit", ci, ci, ci, ci, ci)
 _wgrad = _sig("ddl_conv_wgrad", ci, vp, vp, vp, vp, cl, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci,
@@ -796,13 +796,22 @@ def _pconv_units(pl, B):
     return -(-B // pl["IMG"]) * pl["bands"]
 
 
-def _run_pconv(pl, src, wgt, bias, dst, g, B, Hs, Ws, Cs, Hd, Wd, Nd, Nw, ss, sd, act, alpha, mul=None, stats=None):
+def _run_pconv(pl, src, wgt, bias, dst, g, B, Hs, Ws, Cs, Hd, Wd, Nd, Nw, ss, sd, act, alpha, mul=None, stats=None,
+               bn_infer=None):
     """`stats`: fp32 tensor of 2 * Nd * units elements that receives per-block column sums / sums of squares
-    of the output (layout [2][Nd][units]) for the BatchNorm that follows."""
+    of the output (layout [2][Nd][units]) for the BatchNorm that follows.
+    `bn_infer` = (gamma, beta, moving_mean, moving_var, eps): fold an inference-phase BatchNorm into the epilogue."""
+    bg = bb = bm = bvv = None
+    beps = 0.0
+    if bn_infer is not None:
+        gamma, beta, mm, mv, beps = bn_infer
+        for t, n in ((gamma, "gamma"), (beta, "beta"), (mm, "moving_mean"), (mv, "moving_var")):
+            _chk_f32(t, Nw, n)
+        bg, bb, bm, bvv = gamma.data_ptr(), beta.data_ptr(), mm.data_ptr(), mv.data_ptr()
     rc = _pconv(src.data_ptr(), wgt.data_ptr(), _p(bias), dst.data_ptr(), pl["classes"].data_ptr(),
                 pl["ktab"].data_ptr(), pl["ncls"], pl["nst"], B, Hs, Ws, Cs, Hd, Wd, Nd, Nw, ss[0], ss[1],
                 sd[0], sd[1], g.KH * g.KW, ACT_CODE[act], alpha, pl["IMG"], pl["BR"], pl["bands"],
-                pl["omin_h"], pl["omin_w"], pl["PH"], pl["PW"], pl["pitch"], pl["BN"], pl["FR"], _p(stats), _stream())
+                pl["omin_h"], pl["omin_w"], pl["PH"], pl["PW"], pl["pitch"], pl["BN"], pl["FR"], _p(stats), bg, bb, bm, bvv, beps, _stream())
     if rc != 0:
         raise ValueError(f"pconv rejected its plan (rc={rc}): {g} B={B} "
                          f"{ {k: v for k, v in pl.items() if k not in ('classes', 'ktab')} }")
@@ -852,7 +861,7 @@ PCONV_STATS = os.environ.get("DDL_PCONV_STATS", "1") == "1"
 
 
 def _igemm_call(src, wgt, bias, dst, g, mode, B, Hs, Ws, Cs, Hd, Wd, Nd, Nw, ss, sd, act, alpha, mul=None,
-                stats_out=None):
+                stats_out=None, bn_infer=None):
     """Dispatch one class-grid convolution: the patch-resident kernel with a tuned plan, or the
     global-gather kernel.  The first (non-captured) call of each problem times the candidates on the
     real operands and caches the winner -- these shapes are static for a whole training run."""
@@ -892,11 +901,15 @@ def _igemm_call(src, wgt, bias, dst, g, mode, B, Hs, Ws, Cs, Hd, Wd, Nd, Nw, ss,
         _CONV_CHOICE[key] = choice
     if choice[0] == "pconv":
         stats = None
-        if stats_out is not None and PCONV_STATS and mul is None:
+        if bn_infer is not None and (stats_out is None or mul is not None or not PCONV_STATS):
+            bn_infer = None
+        if bn_infer is not None:
+            stats_out["affine"] = True                   # the caller skips its BatchNorm pass
+        elif stats_out is not None and PCONV_STATS and mul is None:
             nb = _pconv_units(choice[1], B)
             stats = torch.empty(2 * Nd * nb, dtype=torch.float32, device=src.device)
             stats_out["part"], stats_out["nb"] = stats, nb
-        _run_pconv(choice[1], *args, *tail, mul=mul, stats=stats)
+        _run_pconv(choice[1], *args, *tail, mul=mul, stats=stats, bn_infer=bn_infer)
     else:
         _run_igemm(src, wgt, bias, dst, g, mode, *tail, tile=choice[1])
         _mul_inplace(dst, mul)
@@ -919,7 +932,7 @@ def _is_1x1(g: ConvGeom) -> bool:
             and not g.depthwise)
 
 
-def conv_fprop(x, wA, bias, g: ConvGeom, act=None, alpha=0.3, mul=None, stats_out=None):
+def conv_fprop(x, wA, bias, g: ConvGeom, act=None, alpha=0.3, mul=None, stats_out=None, bn_infer=None):
     """`mul` = (y, act, alpha): multiply the (bf16) result by act'(y) -- the activation backward of the layer
     below, fused into the epilogue when this runs as a transposed conv's input gradient."""
     _chk_act(x, "x")
@@ -952,11 +965,11 @@ def conv_fprop(x, wA, bias, g: ConvGeom, act=None, alpha=0.3, mul=None, stats_ou
             _done()
             return y
     _igemm_call(x, wA, bias, y, g, "fprop", B, g.H, g.W, Ip, g.OH, g.OW, Op, min(wA.shape[0], g.O),
-                (g.sh, g.sw), (1, 1), act, alpha, mul, stats_out)
+                (g.sh, g.sw), (1, 1), act, alpha, mul, stats_out, bn_infer)
     return y
 
 
-def conv_dgrad(dy, wB, g: ConvGeom, bias=None, act=None, alpha=0.3, mul=None, stats_out=None):
+def conv_dgrad(dy, wB, g: ConvGeom, bias=None, act=None, alpha=0.3, mul=None, stats_out=None, bn_infer=None):
     _chk_act(dy, "dy")
     B = dy.shape[0]
     Ip, Op = pad8(g.I), pad8(g.O)
@@ -989,7 +1002,7 @@ def conv_dgrad(dy, wB, g: ConvGeom, bias=None, act=None, alpha=0.3, mul=None, st
             _done()
             return dx
     _igemm_call(dy, wB, bias, dx, g, "dgrad", B, g.OH, g.OW, Op, g.H, g.W, Ip, min(wB.shape[0], g.I),
-                (1, 1), (g.sh, g.sw), act, alpha, mul, stats_out)
+                (1, 1), (g.sh, g.sw), act, alpha, mul, stats_out, bn_infer)
     return dx
 
 

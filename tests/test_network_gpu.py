@@ -126,3 +126,18 @@ def test_fused_activation_backward_is_bit_exact(monkeypatch):
         b.train_step(rp, prepared=True)
     torch.cuda.synchronize()
     assert torch.equal(a.D.P, b.D.P) and torch.equal(a.G.P, b.G.P)
+
+
+def test_generator_inference_forward_with_folded_batchnorm():
+    """training=False: inference BN is folded into the producing conv's epilogue where the kernel allows
+    (pconv AFFINE) -- same outputs as the CPU oracle with non-trivial moving statistics."""
+    c, g = _pair(generator_spec(), 6)
+    gen = torch.Generator().manual_seed(1)
+    S = torch.rand(c.S.numel(), generator=gen) + 0.5
+    c.S.copy_(S)
+    g.S.copy_(S.cuda())
+    z = (torch.rand(200, 128, generator=gen) * 2 - 1).bfloat16().float()
+    yc = c.forward(c.prepare_input(z), training=False)
+    yg = g.forward(g.prepare_input(z), training=False)
+    assert _rel(g.to_logical(yg).cpu(), yc) < 3e-2
+    assert not any(getattr(op, "applied_by_producer", False) for op in g.ops)      # flags consumed
