@@ -263,7 +263,8 @@ class ConvOp(Op):
         if self.kind == "dense":
             B = x.shape[0]
             x4 = x.reshape(B, 1, 1, -1)
-            y = F.conv_fprop(x4, self._w4(self.w_main), self.bias, g, self.act, self.alpha).reshape(B, -1)
+            y = F.conv_fprop(x4, self._w4(self.w_main), self.bias, g, self.act, self.alpha, stats_out=so,
+                             bn_infer=bi).reshape(B, -1)
         elif self.kind == "conv2d_transpose":
             y = F.conv_dgrad(x, self.w_main, g, self.bias, self.act, self.alpha, stats_out=so, bn_infer=bi)
         else:
