@@ -256,16 +256,11 @@ DDL_API int ddl_colreduce_blocks(long rows, int C) {
 }
 
 // BN forward statistics -> per-channel affine (scale, shift), saved (mean, invstd), moving update.
-__global__ void bn_stats_finalize_kernel(const float* __restrict__ part, int nblocks, int C, long rows,
-                                         const float* __restrict__ gamma, const float* __restrict__ beta,
-                                         float* __restrict__ mm, float* __restrict__ mv, float momentum,
-                                         float eps, int bessel, int update_moving, float* __restrict__ scale,
-                                         float* __restrict__ shift, float* __restrict__ mean_out,
-                                         float* __restrict__ invstd_out) {
-    int c = FIN_CHANNEL();
-    double s0, s1;
-    reduce_partials(part, nblocks, C, c, true, s0, s1);
-    if (c >= C || !FIN_LEADER()) return;
+__device__ __forceinline__ void bn_stats_emit(int c, double s0, double s1, long rows, const float* __restrict__ gamma,
+                                              const float* __restrict__ beta, float* __restrict__ mm,
+                                              float* __restrict__ mv, float momentum, float eps, int bessel,
+                                              int update_moving, float* __restrict__ scale, float* __restrict__ shift,
+                                              float* __restrict__ mean_out, float* __restrict__ invstd_out) {
     double mean = s0 / (double)rows;
     double var = s1 / (double)rows - mean * mean;
     if (var < 0) var = 0;
@@ -279,6 +274,53 @@ __global__ void bn_stats_finalize_kernel(const float* __restrict__ part, int nbl
         double v = bessel && rows > 1 ? var * ((double)rows / (double)(rows - 1)) : var;
         mm[c] = mm[c] * momentum + (float)mean * (1.f - momentum);
         mv[c] = mv[c] * momentum + (float)v * (1.f - momentum);
+    }
+}
+
+__global__ void bn_stats_finalize_kernel(const float* __restrict__ part, int nblocks, int C, long rows,
+                                         const float* __restrict__ gamma, const float* __restrict__ beta,
+                                         float* __restrict__ mm, float* __restrict__ mv, float momentum,
+                                         float eps, int bessel, int update_moving, float* __restrict__ scale,
+                                         float* __restrict__ shift, float* __restrict__ mean_out,
+                                         float* __restrict__ invstd_out) {
+    int c = FIN_CHANNEL();
+    double s0, s1;
+    reduce_partials(part, nblocks, C, c, true, s0, s1);
+    if (c >= C || !FIN_LEADER()) return;
+    bn_stats_emit(c, s0, s1, rows, gamma, beta, mm, mv, momentum, eps, bessel, update_moving, scale, shift, mean_out,
+                  invstd_out);
+}
+
+// Many partials per channel (a producer kernel with thousands of blocks): one block per channel, 256 lanes walk
+// the channel's contiguous partial row (4 independent loads per trip), fixed-order tree in fp64 -> deterministic.
+__global__ __launch_bounds__(256) void bn_stats_finalize_wide_kernel(
+    const float* __restrict__ part, int nblocks, int C, long rows, const float* __restrict__ gamma,
+    const float* __restrict__ beta, float* __restrict__ mm, float* __restrict__ mv, float momentum, float eps,
+    int bessel, int update_moving, float* __restrict__ scale, float* __restrict__ shift,
+    float* __restrict__ mean_out, float* __restrict__ invstd_out) {
+    __shared__ double red[2][4];
+    const int c = blockIdx.x;
+    const float* p0 = part + (size_t)c * nblocks;
+    const float* p1 = part + ((size_t)C + c) * nblocks;
+    double a0 = 0, a1 = 0;
+    int b = threadIdx.x;
+    for (; b + 768 < nblocks; b += 1024) {
+        float u[4], v[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { u[k] = p0[b + 256 * k]; v[k] = p1[b + 256 * k]; }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { a0 += u[k]; a1 += v[k]; }
+    }
+    for (; b < nblocks; b += 256) { a0 += p0[b]; a1 += p1[b]; }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { a0 += __shfl_down(a0, o, 64); a1 += __shfl_down(a1, o, 64); }
+    if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = a0; red[1][threadIdx.x >> 6] = a1; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const double s0 = ((red[0][0] + red[0][1]) + red[0][2]) + red[0][3];
+        const double s1 = ((red[1][0] + red[1][1]) + red[1][2]) + red[1][3];
+        bn_stats_emit(c, s0, s1, rows, gamma, beta, mm, mv, momentum, eps, bessel, update_moving, scale, shift,
+                      mean_out, invstd_out);
     }
 }
 
@@ -300,8 +342,13 @@ DDL_API void ddl_bn_stats_from_part(const float* part, int nblocks, long rows, i
                                     const float* beta, float* mm, float* mv, float momentum, float eps, int bessel,
                                     int update_moving, float* scale, float* shift, float* mean, float* invstd,
                                     hipStream_t s) {
-    bn_stats_finalize_kernel<<<FIN_GRID(C), FIN_BLOCK, 0, s>>>(part, nblocks, C, rows, gamma, beta, mm, mv, momentum,
-                                                             eps, bessel, update_moving, scale, shift, mean, invstd);
+    if (nblocks > 1024)
+        bn_stats_finalize_wide_kernel<<<C, 256, 0, s>>>(part, nblocks, C, rows, gamma, beta, mm, mv, momentum, eps,
+                                                        bessel, update_moving, scale, shift, mean, invstd);
+    else
+        bn_stats_finalize_kernel<<<FIN_GRID(C), FIN_BLOCK, 0, s>>>(part, nblocks, C, rows, gamma, beta, mm, mv,
+                                                                 momentum, eps, bessel, update_moving, scale, shift,
+                                                                 mean, invstd);
 }
 
 // Inference-phase BN: scale/shift from the moving statistics (tiny, one launch).

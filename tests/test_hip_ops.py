@@ -430,7 +430,7 @@ def test_dense_wide_output_skinny_k(hip, K, N, B):
 
 
 @pytest.mark.parametrize("shape", [(14, 14, 32, 64, "same", 2, "linear"), (7, 7, 40, 24, "same", 1, "relu")])
-@pytest.mark.parametrize("B", [5, 130])
+@pytest.mark.parametrize("B", [5, 130, 1300])
 def test_pconv_emits_batchnorm_statistics(hip, shape, B):
     """pconv's STATS epilogue: per-block partial sums of the stored (bf16) output == a column reduction of it."""
     H, W, I, O, pad, s, act = shape
@@ -440,9 +440,11 @@ def test_pconv_emits_batchnorm_statistics(hip, shape, B):
     w = padw(hip, r16(torch.randn(O, 5, 5, I) / 20))
     bias = torch.randn(O).cuda()
     Ip, Op = hip.pad8(I), hip.pad8(O)
-    pl = hip._pconv_plan(g, "fprop", B, Ip, Op, (g.sh, g.sw), x.device, min_rows=16)
+    # B = 1300 with one image per unit: > 1024 partials per channel -> the wide combine kernel
+    pl = hip._pconv_plan(g, "fprop", B, Ip, Op, (g.sh, g.sw), x.device, min_rows=16, img=1 if B > 1000 else None)
     assert pl is not None
     nb = hip._pconv_units(pl, B)
+    assert B < 1000 or nb > 1024
     y = torch.empty(B, g.OH, g.OW, Op, dtype=torch.bfloat16, device="cuda")
     part = torch.full((2 * Op * nb,), float("nan"), device="cuda")
     hip._run_pconv(pl, x, w, bias, y, g, B, g.H, g.W, Ip, g.OH, g.OW, Op, O, (g.sh, g.sw), (1, 1), act, 0.3,
