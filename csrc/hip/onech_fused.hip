@@ -13,6 +13,7 @@
 // applied, so results are bit-identical to the unfused path), and folds from LDS exactly like
 // col2im_1ch.  T <= 32 taps (two 16-row MFMA tiles), C <= 128.
 #include "common.h"
+#include <cstdlib>
 
 struct TapFoldArgs {
     const bf16_t* x;          // [B][OH][OW][C]
@@ -155,8 +156,9 @@ DDL_API int ddl_tapfold_1ch(const void* x, const void* w, const float* bias, voi
     // band height: the band's z rows ((rows-1)/sh + halo) stay under ~40 KiB of LDS
     const size_t row_bytes = (size_t)OW * TF_ZP;
     const int halo = ((KH - 1) * dh) / sh + 2;
+    static const size_t band_cap = getenv("DDL_TAPFOLD_LDS_KB") ? (size_t)atol(getenv("DDL_TAPFOLD_LDS_KB")) * 1024 : 40 * 1024;
     int band = H;
-    while (band > 1 && ((size_t)((band - 1) / sh + halo)) * row_bytes > 40 * 1024) band = (band + 1) / 2;
+    while (band > 1 && ((size_t)((band - 1) / sh + halo)) * row_bytes > band_cap) band = (band + 1) / 2;
     const size_t zrows = (size_t)((band - 1) / sh + halo);
     const size_t zbytes = (zrows * OW + 15) / 16 * 16 * TF_ZP;
     const size_t smem = 32 * (size_t)TF_WP(KS * 32) + zbytes;
