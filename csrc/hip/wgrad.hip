@@ -476,72 +476,84 @@ __global__ __launch_bounds__(256) void dw_dgrad_fast_kernel(const bf16_t* __rest
     }
 }
 
-// dW[t][c] partials: block = (pixel chunk, tap) as in the generic kernel -- nine times the blocks and a
-// tiny register footprint hide the gather latency better than one block holding all taps' accumulators
-// (measured: 771 vs 544 us per classifier step) -- but with 32-bit magic-number index arithmetic and
-// four pixels' loads in flight per lane.
+// dW[t][c] partials: block = (pixel chunk, kernel ROW): the K taps of one kernel row share the dY load and
+// their X pixels are neighbours.  One block per tap (nine dY reads) and one block for all nine taps (one
+// dY read, 72 accumulators: 771 vs 544 us per classifier step) were both measured slower: K x the
+// blocks with a small register footprint hide the gather latency, K x fewer dY reads cut the traffic.
+template <int K>
 __global__ __launch_bounds__(256) void dw_wgrad_fast_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x,
-                                                            float* __restrict__ part, const DwArgs a, int KW, int T) {
+                                                            float* __restrict__ part, const DwArgs a) {
     __shared__ float red[256][9];
     const int cg = a.C / 8;
     const int cgl = cg < 256 ? cg : 256;
     const int rpi = 256 / cgl;
     const int gch = blockIdx.z * 256 + threadIdx.x % cgl, rl = threadIdx.x / cgl;
-    const int tap = blockIdx.y, kh = tap / KW, kw = tap - kh * KW;
-    const int offh = kh * a.dh - a.pt, offw = kw * a.dw - a.pl;
+    const int kh = blockIdx.y;
+    const int offh = kh * a.dh - a.pt;
     const unsigned M = a.total;                  // B * OH * OW
-    float acc[8];
+    float acc[K][8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+    for (int t = 0; t < K; ++t)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[t][j] = 0.f;
     if (rl < rpi && gch < cg) {
         const unsigned stride = gridDim.x * (unsigned)rpi;
-        auto src = [&](unsigned m, bool& v) {
+        auto one = [&](unsigned m, uint4& g4, uint4 (&x4)[K]) {
             const unsigned q = fdivu(m, a.dOW);
             const int ow = (int)(m - q * a.OW);
             const unsigned b = fdivu(q, a.dOH);
             const int oh = (int)(q - b * a.OH);
-            const int ih = oh * a.sh + offh, iw = ow * a.sw + offw;
-            v = ((unsigned)ih < (unsigned)a.H) & ((unsigned)iw < (unsigned)a.W);
-            return x + (size_t)b * a.H * a.W * a.C + (v ? (ih * a.W + iw) * a.C : 0) + gch * 8;
-        };
-        auto fma8 = [&](const uint4& g4, const uint4& x4) {
-            float gf[8], xf[8];
-            unpack8(g4, gf);
-            unpack8(x4, xf);
+            const int ih = oh * a.sh + offh;
+            const bool vh = (unsigned)ih < (unsigned)a.H;
+            const bf16_t* xb = x + (size_t)b * a.H * a.W * a.C + gch * 8;
+            g4 = *(const uint4*)(dy + (size_t)m * a.C + gch * 8);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) acc[j] = fmaf(gf[j], xf[j], acc[j]);
+            for (int kw = 0; kw < K; ++kw) {
+                const int iw = ow * a.sw + kw * a.dw - a.pl;
+                const bool v = vh & ((unsigned)iw < (unsigned)a.W);
+                const uint4 ld = *(const uint4*)(xb + (v ? (ih * a.W + iw) * a.C : 0));
+                x4[kw] = v ? ld : make_uint4(0, 0, 0, 0);
+            }
+        };
+        auto fma = [&](const uint4& g4, const uint4 (&x4)[K]) {
+            float gf[8];
+            unpack8(g4, gf);
+#pragma unroll
+            for (int kw = 0; kw < K; ++kw) {
+                float xf[8];
+                unpack8(x4[kw], xf);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc[kw][j] = fmaf(gf[j], xf[j], acc[kw][j]);
+            }
         };
         unsigned m = blockIdx.x * (unsigned)rpi + rl;
-        for (; m + 3 * stride < M; m += 4 * stride) {
-            uint4 g4[4], x4[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                bool v;
-                const bf16_t* px = src(m + u * stride, v);
-                const uint4 ld = *(const uint4*)px;
-                x4[u] = v ? ld : make_uint4(0, 0, 0, 0);
-                g4[u] = *(const uint4*)(dy + (size_t)(m + u * stride) * a.C + gch * 8);
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) fma8(g4[u], x4[u]);
+        for (; m + stride < M; m += 2 * stride) {
+            uint4 gA, gB, xA[K], xB[K];
+            one(m, gA, xA);
+            one(m + stride, gB, xB);
+            fma(gA, xA);
+            fma(gB, xB);
         }
         for (; m < M; m += stride) {
-            bool v;
-            const bf16_t* px = src(m, v);
-            const uint4 ld = *(const uint4*)px;
-            fma8(*(const uint4*)(dy + (size_t)m * a.C + gch * 8), v ? ld : make_uint4(0, 0, 0, 0));
+            uint4 gA, xA[K];
+            one(m, gA, xA);
+            fma(gA, xA);
         }
     }
 #pragma unroll
-    for (int j = 0; j < 8; ++j) red[threadIdx.x][j] = acc[j];
-    __syncthreads();
-    if (rl == 0 && gch < cg) {
-        for (int r = 1; r < rpi; ++r)
+    for (int kw = 0; kw < K; ++kw) {
+        __syncthreads();
 #pragma unroll
-            for (int j = 0; j < 8; ++j) red[threadIdx.x][j] += red[threadIdx.x + r * cgl][j];
-        float* o = part + ((size_t)blockIdx.x * T + tap) * a.C + gch * 8;
+        for (int j = 0; j < 8; ++j) red[threadIdx.x][j] = acc[kw][j];
+        __syncthreads();
+        if (rl == 0 && gch < cg) {
+            for (int r = 1; r < rpi; ++r)
 #pragma unroll
-        for (int j = 0; j < 8; ++j) o[j] = red[threadIdx.x][j];
+                for (int j = 0; j < 8; ++j) red[threadIdx.x][j] += red[threadIdx.x + r * cgl][j];
+            float* o = part + ((size_t)blockIdx.x * K * K + kh * K + kw) * a.C + gch * 8;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] = red[threadIdx.x][j];
+        }
     }
 }
 
@@ -563,8 +575,8 @@ static void dw_fast_launch(int mode, const void* a_, const void* w, const float*
         else
             dw_dgrad_fast_kernel<K><<<g, 256, 0, s>>>((const bf16_t*)a_, (const bf16_t*)w, (bf16_t*)out, a);
     } else {
-        dw_wgrad_fast_kernel<<<dim3(nb, K * K, (cg + 255) / 256), 256, 0, s>>>((const bf16_t*)a_, (const bf16_t*)w,
-                                                                               part, a, K, K * K);
+        dw_wgrad_fast_kernel<K><<<dim3(nb, K, (cg + 255) / 256), 256, 0, s>>>((const bf16_t*)a_, (const bf16_t*)w,
+                                                                              part, a);
     }
 }
 
