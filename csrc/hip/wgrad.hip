@@ -391,6 +391,7 @@ struct DwArgs {
     float alpha;
     unsigned total;
     FastDiv dcg, dOW, dOH, dW_, dH_, dsh, dsw;
+    FastDiv dsh_hc[3], dsw_wc[3];     // dgrad: dividers by the class-grid height / width of parity ph / pw (strides <= 3)
 };
 
 template <int K>
@@ -437,42 +438,63 @@ __global__ __launch_bounds__(256) void dw_fprop_fast_kernel(const bf16_t* __rest
     }
 }
 
+// Input gradient by output-parity class (blockIdx.y = ph * sw + pw): dx pixels (ph + sh*i, pw + sw*j) of one
+// class are reached by the SAME taps -- those with (ph + pt - kh*dh) % sh == 0 -- so the tap test is uniform
+// per block and the other taps cost nothing (a per-pixel test made a stride-2 3x3 layer issue nine masked
+// loads and 72 FMAs for 2.25 live taps on average: ALU-bound at 300 us for a 426 MB tensor).
 template <int K>
 __global__ __launch_bounds__(256) void dw_dgrad_fast_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ w,
                                                             bf16_t* __restrict__ dx, const DwArgs a) {
     const int cg = a.C / 8;
-    for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < a.total; i += gridDim.x * 256u) {
+    const int ph = blockIdx.y / a.sw, pw = blockIdx.y - ph * a.sw;
+    const int Hc = (a.H - ph + a.sh - 1) / a.sh, Wc = (a.W - pw + a.sw - 1) / a.sw;     // class grid
+    if (Hc <= 0 || Wc <= 0) return;
+    // live taps of this class and their dY offsets: th = ph + pt - kh*dh + sh*i  ->  oh = oh0[kh] + i
+    int oh0[K], ow0[K];
+    bool lh[K], lw[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        const int th0 = ph + a.pt - k * a.dh, tw0 = pw + a.pl - k * a.dw;
+        const int qh = th0 >= 0 ? th0 / a.sh : -((-th0 + a.sh - 1) / a.sh);            // floor division
+        const int qw = tw0 >= 0 ? tw0 / a.sw : -((-tw0 + a.sw - 1) / a.sw);
+        lh[k] = qh * a.sh == th0;
+        lw[k] = qw * a.sw == tw0;
+        oh0[k] = qh;
+        ow0[k] = qw;
+    }
+    const FastDiv dWc = a.dsw_wc[pw], dHc = a.dsh_hc[ph];
+    const unsigned total = (unsigned)a.B * Hc * Wc * cg;
+    for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < total; i += gridDim.x * 256u) {
         const unsigned p = fdivu(i, a.dcg);
         const int gch = (int)(i - p * cg);
-        const unsigned q = fdivu(p, a.dW_);
-        const int iw = (int)(p - q * a.W);
-        const unsigned b = fdivu(q, a.dH_);
-        const int ih = (int)(q - b * a.H);
+        const unsigned q = fdivu(p, dWc);
+        const int jc = (int)(p - q * Wc);
+        const unsigned b = fdivu(q, dHc);
+        const int ic = (int)(q - b * Hc);
         const bf16_t* gb = dy + (size_t)b * a.OH * a.OW * a.C + gch * 8;
-        uint4 gv[K * K], wv[K * K];
-#pragma unroll
-        for (int kh = 0; kh < K; ++kh)
-#pragma unroll
-            for (int kw = 0; kw < K; ++kw) {
-                const int th = ih + a.pt - kh * a.dh, tw = iw + a.pl - kw * a.dw;
-                const int oh = (int)fdivu((unsigned)max(th, 0), a.dsh), ow = (int)fdivu((unsigned)max(tw, 0), a.dsw);
-                const bool v = (th >= 0) & (tw >= 0) & (oh * a.sh == th) & (ow * a.sw == tw) & (oh < a.OH) & (ow < a.OW);
-                const uint4 ld = *(const uint4*)(gb + (v ? (oh * a.OW + ow) * a.C : 0));
-                gv[kh * K + kw] = v ? ld : make_uint4(0, 0, 0, 0);
-                wv[kh * K + kw] = *(const uint4*)(w + (kh * K + kw) * a.C + gch * 8);
-            }
         float acc[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) acc[j] = 0.f;
 #pragma unroll
-        for (int t = 0; t < K * K; ++t) {
-            float gf[8], wf[8];
-            unpack8(gv[t], gf);
-            unpack8(wv[t], wf);
+        for (int kh = 0; kh < K; ++kh) {
+            if (!lh[kh]) continue;                                   // block-uniform
+            const int oh = oh0[kh] + ic;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) acc[j] = fmaf(gf[j], wf[j], acc[j]);
+            for (int kw = 0; kw < K; ++kw) {
+                if (!lw[kw]) continue;                               // block-uniform
+                const int ow = ow0[kw] + jc;
+                const bool v = ((unsigned)oh < (unsigned)a.OH) & ((unsigned)ow < (unsigned)a.OW);
+                const uint4 ld = *(const uint4*)(gb + (v ? (oh * a.OW + ow) * a.C : 0));
+                const uint4 g4 = v ? ld : make_uint4(0, 0, 0, 0);
+                float gf[8], wf[8];
+                unpack8(g4, gf);
+                unpack8(*(const uint4*)(w + (kh * K + kw) * a.C + gch * 8), wf);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc[j] = fmaf(gf[j], wf[j], acc[j]);
+            }
         }
-        *(uint4*)(dx + (size_t)i * 8) = pack8(acc);
+        const int ih = ph + a.sh * ic, iw = pw + a.sw * jc;
+        *(uint4*)(dx + ((size_t)(b * a.H + ih) * a.W + iw) * a.C + gch * 8) = pack8(acc);
     }
 }
 
@@ -570,10 +592,15 @@ static void dw_fast_launch(int mode, const void* a_, const void* w, const float*
     if (mode == 0 || mode == 1) {
         unsigned g = (a.total + 255u) / 256u;
         if (g > 8192u) g = 8192u;
-        if (mode == 0)
+        if (mode == 0) {
             dw_fprop_fast_kernel<K><<<g, 256, 0, s>>>((const bf16_t*)a_, (const bf16_t*)w, bias, (bf16_t*)out, a);
-        else
-            dw_dgrad_fast_kernel<K><<<g, 256, 0, s>>>((const bf16_t*)a_, (const bf16_t*)w, (bf16_t*)out, a);
+        } else {
+            const int classes = a.sh * a.sw;
+            unsigned gx = (g + classes - 1) / classes;
+            if (gx < 1) gx = 1;
+            dw_dgrad_fast_kernel<K><<<dim3(gx, classes), 256, 0, s>>>((const bf16_t*)a_, (const bf16_t*)w,
+                                                                      (bf16_t*)out, a);
+        }
     } else {
         dw_wgrad_fast_kernel<K><<<dim3(nb, K, (cg + 255) / 256), 256, 0, s>>>((const bf16_t*)a_, (const bf16_t*)w,
                                                                               part, a);
@@ -586,13 +613,18 @@ DDL_API int ddl_depthwise(int mode, const void* a, const void* w, const float* b
     if (C % 8) return -1;
     const int cg = C / 8;
     const long in_elems = (long)B * H * W * C, out_elems = (long)B * OH * OW * C;
-    if (KH == KW && KH <= 3 && in_elems < (1L << 31) && out_elems < (1L << 31)) {
+    if (KH == KW && KH <= 3 && in_elems < (1L << 31) && out_elems < (1L << 31) && sh <= 3 && sw <= 3) {
         DwArgs d;
         d.B = B; d.H = H; d.W = W; d.C = C; d.OH = OH; d.OW = OW; d.sh = sh; d.sw = sw; d.dh = dh; d.dw = dw;
         d.pt = pt; d.pl = pl; d.c_true = c_true; d.act = act; d.alpha = alpha;
         d.total = (unsigned)(mode == 0 ? (long)B * OH * OW * cg : (mode == 1 ? (long)B * H * W * cg : (long)B * OH * OW));
         d.dcg = make_fastdiv(cg); d.dOW = make_fastdiv(OW); d.dOH = make_fastdiv(OH);
         d.dW_ = make_fastdiv(W); d.dH_ = make_fastdiv(H); d.dsh = make_fastdiv(sh); d.dsw = make_fastdiv(sw);
+        for (int p_ = 0; p_ < 3; ++p_) {
+            const int hc = p_ < sh ? (H - p_ + sh - 1) / sh : 1, wc = p_ < sw ? (W - p_ + sw - 1) / sw : 1;
+            d.dsh_hc[p_] = make_fastdiv(hc > 0 ? hc : 1);
+            d.dsw_wc[p_] = make_fastdiv(wc > 0 ? wc : 1);
+        }
         const int nb = mode == 2 ? ddl_dw_wgrad_blocks((long)B * OH * OW, C) : 0;
         if (KH == 1) dw_fast_launch<1>(mode, a, w, bias, out, part, d, nb, s);
         else if (KH == 2) dw_fast_launch<2>(mode, a, w, bias, out, part, d, nb, s);
