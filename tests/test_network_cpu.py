@@ -142,3 +142,20 @@ def test_gan_proper_mode_learns_and_generates_in_unit_range(tmp_path):
     t2 = GANTrainer(GANConfig(batch=16, seed=0), "cpu")
     assert t2.load_checkpoint(tmp_path / "gan.ck") == 7
     assert all(torch.equal(a, b) for a, b in zip(t.G.logical_state().values(), t2.G.logical_state().values()))
+
+
+def test_fused_activation_backward_matches_separate_pass_cpu(monkeypatch):
+    """Network.backward applies act'(y) of the layer below inside the input-gradient op (and across the
+    G -> D boundary via input_mul / dy_premultiplied): same parameters as the separate act_bwd pass."""
+    import torch
+    from distributeddeeplearning_amd.models import network
+    from distributeddeeplearning_amd.models.dcgan import GANConfig, GANTrainer
+    real = torch.rand(12, 28, 28, 1, generator=torch.Generator().manual_seed(2))
+    a = GANTrainer(GANConfig(batch=12, seed=4), "cpu")
+    for _ in range(2):
+        a.train_step(real)
+    monkeypatch.setattr(network, "FUSE_ACT_BWD", False)
+    b = GANTrainer(GANConfig(batch=12, seed=4), "cpu")
+    for _ in range(2):
+        b.train_step(real)
+    assert torch.allclose(a.D.P, b.D.P, rtol=1e-5, atol=1e-7) and torch.allclose(a.G.P, b.G.P, rtol=1e-5, atol=1e-7)
