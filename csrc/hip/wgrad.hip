@@ -166,8 +166,16 @@ __global__ __launch_bounds__(256) void slab_reduce_wide_kernel(const float4* __r
     const long i = (long)blockIdx.x * 32 + col;
     float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
     if (i < n4) {
-        for (int k = kl; k < ksplit; k += 8) {
-            float4 v = slab[k * stride4 + i];
+        int k = kl;
+        for (; k + 24 < ksplit; k += 32) {            // four independent 16-byte loads per trip, fixed order
+            float4 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = slab[(long)(k + 8 * u) * stride4 + i];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { s.x += v[u].x; s.y += v[u].y; s.z += v[u].z; s.w += v[u].w; }
+        }
+        for (; k < ksplit; k += 8) {
+            float4 v = slab[(long)k * stride4 + i];
             s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
         }
     }
