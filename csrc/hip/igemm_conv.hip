@@ -421,7 +421,15 @@ __global__ void splitk_finish_kernel(const float* __restrict__ slab, const float
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < MN; i += (long)gridDim.x * blockDim.x) {
         int n = (int)(i % Nd);
         float s = 0.f;
-        for (int k = 0; k < ksplit; ++k) s += slab[k * MN + i];
+        int k = 0;
+        for (; k + 7 < ksplit; k += 8) {               // eight independent loads per trip, summed in slab order
+            float v8[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v8[u] = slab[(long)(k + u) * MN + i];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s += v8[u];
+        }
+        for (; k < ksplit; ++k) s += slab[(long)k * MN + i];
         float v = 0.f;
         if (n < Nw) v = act_apply(s + (bias ? bias[n] : 0.f), act, alpha);
         dst[i] = f2bf(v);
