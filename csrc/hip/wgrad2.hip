@@ -90,6 +90,16 @@ __global__ __launch_bounds__(256, (TPW * (TN / 16) * (TC / 16) * 4 > 160 ? 1 : 2
     }
     const int chan_y = (n0 + 4 * tp) * 2;
 
+    // Branch-free bounds-checked buffer loads for the staging gathers: an out-of-range unit gets an offset beyond
+    // the descriptor and reads as zero.  (A predicated global_load compiles to an exec-masked branch after which
+    // the compiler can no longer count outstanding loads: the eight loads per thread were serialised.)
+    typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+    const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)a.x, 0, (int)((unsigned)a.B * a.H * a.W * a.Cx * 2u), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsY = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)a.dy, 0, (int)((unsigned)a.B * a.OH * a.OW * a.Ny * 2u), 0x00020000);
+    constexpr unsigned OOB_OFF = 0xFFFFFFF0u;
+
     for (int unit = blockIdx.x; unit < a.n_units; unit += gridDim.x) {
         const int grp = unit / a.bands, band = unit - grp * a.bands;
         const int b0 = grp * a.IMG, i0 = band * a.BR;
@@ -101,7 +111,7 @@ __global__ __launch_bounds__(256, (TPW * (TN / 16) * (TC / 16) * 4 > 160 ? 1 : 2
             const int per_img = a.PH * a.PW * cx8;
             // eight independent 16-byte loads in flight per thread before the first LDS store
             for (int base = tid; base < a.IMG * per_img; base += 256 * 8) {
-                uint4 v[8];
+                u32x4_t v[8];
                 int dst[8];
 #pragma unroll
                 for (int k = 0; k < 8; ++k) {
@@ -112,20 +122,20 @@ __global__ __launch_bounds__(256, (TPW * (TN / 16) * (TC / 16) * 4 > 160 ? 1 : 2
                     int pix = fdiv2(r, a.inv_cx8), c8 = r - pix * cx8;
                     int pr = fdiv2(pix, a.inv_PW), pc = pix - pr * a.PW;
                     int sr = row0 + pr, sc = col0 + pc, b = b0 + img;
-                    v[k] = make_uint4(0, 0, 0, 0);
-                    if (in && b < a.B && (unsigned)sr < (unsigned)a.H && (unsigned)sc < (unsigned)a.W)
-                        v[k] = *(const uint4*)(a.x + (((long)b * a.H + sr) * a.W + sc) * a.Cx + c8 * 8);
+                    const bool ok = in & (b < a.B) & ((unsigned)sr < (unsigned)a.H) & ((unsigned)sc < (unsigned)a.W);
+                    const unsigned off = ok ? (unsigned)(((b * a.H + sr) * a.W + sc) * a.Cx + c8 * 8) * 2u : OOB_OFF;
+                    v[k] = __builtin_amdgcn_raw_buffer_load_b128(rsX, off, 0, 0);
                     dst[k] = in ? img * a.ximg_bytes + pix * a.xpitch + c8 * 16 : -1;
                 }
 #pragma unroll
                 for (int k = 0; k < 8; ++k)
-                    if (dst[k] >= 0) *(uint4*)(sX + dst[k]) = v[k];
+                    if (dst[k] >= 0) *(u32x4_t*)(sX + dst[k]) = v[k];
             }
             // ... and the dY tile: pixel m = (img, il, jl) of the band; rows past the band / batch are zero
             const int per_row = a.BR * a.OW * ny8;
             const int mpad = (a.Mmax + 31) / 32 * 32;
             for (int base = tid; base < mpad * ny8; base += 256 * 8) {
-                uint4 v[8];
+                u32x4_t v[8];
                 int dst[8];
 #pragma unroll
                 for (int k = 0; k < 8; ++k) {
@@ -136,14 +146,14 @@ __global__ __launch_bounds__(256, (TPW * (TN / 16) * (TC / 16) * 4 > 160 ? 1 : 2
                     int img = fdiv2(m, a.inv_rows), rem = m - img * (a.BR * a.OW);
                     int il = fdiv2(rem, a.inv_OW), jl = rem - il * a.OW;
                     int b = b0 + img;
-                    v[k] = make_uint4(0, 0, 0, 0);
-                    if (in && m < a.Mmax && b < a.B && il < nrow)
-                        v[k] = *(const uint4*)(a.dy + (((long)b * a.OH + i0 + il) * a.OW + jl) * a.Ny + c8 * 8);
+                    const bool ok = in & (m < a.Mmax) & (b < a.B) & (il < nrow);
+                    const unsigned off = ok ? (unsigned)(((b * a.OH + i0 + il) * a.OW + jl) * a.Ny + c8 * 8) * 2u : OOB_OFF;
+                    v[k] = __builtin_amdgcn_raw_buffer_load_b128(rsY, off, 0, 0);
                     dst[k] = in ? m * a.ypitch + c8 * 16 : -1;
                 }
 #pragma unroll
                 for (int k = 0; k < 8; ++k)
-                    if (dst[k] >= 0) *(uint4*)(sY + dst[k]) = v[k];
+                    if (dst[k] >= 0) *(u32x4_t*)(sY + dst[k]) = v[k];
             }
             (void)per_row;
         }
