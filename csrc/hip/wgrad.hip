@@ -25,7 +25,20 @@ struct WgradArgs {
     long slab_stride;         // elements per k-split slab
     int M, chunk;             // total pixels, pixels per k-split (multiple of 128)
     int tiles_c;              // number of c tiles (blockIdx.z = nt * tiles_c + ct)
+    unsigned mg_ohw, mg_ow;   // magic multipliers for m / (OH*OW) and rem / OW (0 = power of two: shift only)
+    int sf_ohw, sf_ow;
 };
+
+// floor(x / d) for 0 <= x < 2^31 with d's magic pair (host: magic_div)
+__device__ __forceinline__ int fastdiv(int x, unsigned mg, int sf) {
+    return mg ? (int)(__umulhi((unsigned)x, mg) >> sf) : (x >> sf);
+}
+static void magic_div(int d, unsigned* mg, int* sf) {
+    int s = 0;
+    while ((2L << s) <= d) ++s;                 // 2^s <= d < 2^(s+1)
+    *sf = s;
+    *mg = ((1L << s) == d) ? 0u : (unsigned)(((1UL << (32 + s)) / (unsigned long)d) + 1UL);
+}
 
 __device__ __forceinline__ s16x4 tr_read(const char* p) {
     return __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(p));
@@ -71,35 +84,45 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a) {
     const int g = lane >> 4, li = lane & 15, tq = li >> 2, tp = li & 3;
     const int tr_off = (4 * g + tq) * 32 + tp * 8;
 
-    for (int mb = m_begin + wave * 32; mb < m_end; mb += 128) {
-        uint4 ry[PY], rx[PX];
+    // Branch-free bounds-checked buffer loads (an out-of-range unit gets an offset past the descriptor and
+    // reads as zero), software-pipelined one 32-pixel slice ahead: the gathers of slice s+1 are in flight
+    // while slice s goes LDS -> transposed fragments -> MFMA.
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    const __amdgpu_buffer_rsrc_t rsY = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)a.dy, 0, (int)((unsigned)a.M * a.Ny * 2u), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)a.x, 0, (int)((unsigned)a.B * a.H * a.W * a.Cx * 2u), 0x00020000);
+    auto gload = [&](int mb, u32x4 (&ry)[PY], u32x4 (&rx)[PX]) {
 #pragma unroll
         for (int p = 0; p < PY; ++p) {
             int m = mb + yrow + p * RPY;
-            bool ok = ycol_ok && m < m_end;
-            ry[p] = ok ? *(const uint4*)(a.dy + (long)m * a.Ny + n0 + ycol * 8) : make_uint4(0, 0, 0, 0);
+            bool ok = ycol_ok & (m < m_end);
+            unsigned off = ok ? (unsigned)(m * a.Ny + n0 + ycol * 8) * 2u : 0xFFFFFFF0u;
+            ry[p] = __builtin_amdgcn_raw_buffer_load_b128(rsY, off, 0, 0);
         }
 #pragma unroll
         for (int p = 0; p < PX; ++p) {
             int m = mb + xrow + p * RPX;
-            bool ok = xcol_ok && m < m_end;
+            bool ok = xcol_ok & (m < m_end);
             int mm = ok ? m : 0;
-            int b = mm / OHW, rem = mm - b * OHW;
-            int oh = rem / a.OW, ow = rem - oh * a.OW;
+            int b = fastdiv(mm, a.mg_ohw, a.sf_ohw), rem = mm - b * OHW;
+            int oh = fastdiv(rem, a.mg_ow, a.sf_ow), ow = rem - oh * a.OW;
             int ih = oh * a.sh + offh, iw = ow * a.sw + offw;
-            ok = ok && (unsigned)ih < (unsigned)a.H && (unsigned)iw < (unsigned)a.W;
-            rx[p] = ok ? *(const uint4*)(a.x + (((long)b * a.H + ih) * a.W + iw) * a.Cx + c0 + xcol * 8)
-                       : make_uint4(0, 0, 0, 0);
+            ok = ok & ((unsigned)ih < (unsigned)a.H) & ((unsigned)iw < (unsigned)a.W);
+            unsigned off = ok ? (unsigned)(((b * a.H + ih) * a.W + iw) * a.Cx + c0 + xcol * 8) * 2u : 0xFFFFFFF0u;
+            rx[p] = __builtin_amdgcn_raw_buffer_load_b128(rsX, off, 0, 0);
         }
+    };
+    auto consume = [&](const u32x4 (&ry)[PY], const u32x4 (&rx)[PX]) {
 #pragma unroll
         for (int p = 0; p < PY; ++p) {
             int row = yrow + p * RPY;
-            *(uint4*)(sY + (ycol >> 1) * 1024 + row * 32 + (ycol & 1) * 16) = ry[p];
+            *(u32x4*)(sY + (ycol >> 1) * 1024 + row * 32 + (ycol & 1) * 16) = ry[p];
         }
 #pragma unroll
         for (int p = 0; p < PX; ++p) {
             int row = xrow + p * RPX;
-            *(uint4*)(sX + (xcol >> 1) * 1024 + row * 32 + (xcol & 1) * 16) = rx[p];
+            *(u32x4*)(sX + (xcol >> 1) * 1024 + row * 32 + (xcol & 1) * 16) = rx[p];
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __builtin_amdgcn_wave_barrier();
@@ -123,6 +146,17 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a) {
                 acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fy[i], fx[j], acc[i][j], 0, 0, 0);
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
         __builtin_amdgcn_wave_barrier();
+    };
+    {
+        u32x4 ryA[PY], rxA[PX], ryB[PY], rxB[PX];
+        const int mb0 = m_begin + wave * 32;
+        gload(mb0, ryA, rxA);
+        for (int mb = mb0; mb < m_end; mb += 256) {       // two slices per trip; a slice past m_end is all zeros
+            gload(mb + 128, ryB, rxB);
+            consume(ryA, rxA);
+            gload(mb + 256, ryA, rxA);
+            consume(ryB, rxB);
+        }
     }
 
     // ---- cross-wave reduction through LDS, then one slab write per block
@@ -230,7 +264,7 @@ DDL_API int ddl_conv_wgrad(const void* dy, const void* x, float* out, float* sla
                            hipStream_t s) {
     if (Ny % 8 || Cx % 8 || ksplit < 1) return -1;
     long M = (long)B * OH * OW;
-    if (M >= (1L << 31) || (long)B * H * W * Cx >= (1L << 31)) return -3;
+    if (M >= (1L << 31) || M * Ny >= (1L << 31) || (long)B * H * W * Cx >= (1L << 31)) return -3;
     WgradArgs a;
     a.dy = (const bf16_t*)dy; a.x = (const bf16_t*)x;
     a.slab = ksplit == 1 ? out : slab;
@@ -238,6 +272,8 @@ DDL_API int ddl_conv_wgrad(const void* dy, const void* x, float* out, float* sla
     a.KH = KH; a.KW = KW; a.sh = sh; a.sw = sw; a.dh = dh; a.dw = dw; a.pt = pt; a.pl = pl;
     a.n_lim = n_lim; a.c_lim = c_lim; a.sn = sn; a.st = st; a.sc = sc;
     a.slab_stride = numel; a.M = (int)M;
+    magic_div(OH * OW, &a.mg_ohw, &a.sf_ohw);
+    magic_div(OW, &a.mg_ow, &a.sf_ow);
     long chunk = (M + ksplit - 1) / ksplit;
     a.chunk = (int)((chunk + 127) / 128 * 128);
     int tn = n_lim > 32 ? 64 : (n_lim > 16 ? 32 : 16);
