@@ -278,18 +278,17 @@ __global__ __launch_bounds__(256) void igemm_conv_kernel_k32(const ConvArgs a) {
     // ---- per-thread staging assignment: kgroup q (8 k-elements), rows r0 + 64*r
     const int q = tid & 3, r0 = tid >> 2;
     const int HW = cd.Hc * cd.Wc;
-    long abase[RA];
+    int abase[RA];                            // element offsets fit 31 bits (checked on the host)
     int aih[RA], aiw[RA];
-    bool aval[RA];
 #pragma unroll
     for (int r = 0; r < RA; ++r) {
         int m = m0 + r0 + 64 * r;
-        aval[r] = m < cd.M;
-        int mm = aval[r] ? m : 0;
+        bool v = m < cd.M;
+        int mm = v ? m : 0;
         int b = mm / HW, rem = mm - b * HW;
         int i = rem / cd.Wc, j = rem - i * cd.Wc;
-        abase[r] = (long)b * a.Hs * a.Ws * a.Cs;
-        aih[r] = i * a.ssh;
+        abase[r] = b * a.Hs * a.Ws * a.Cs;
+        aih[r] = v ? i * a.ssh : -(1 << 24);  // invalid rows fail the bounds test below
         aiw[r] = j * a.ssw;
     }
     const int Cs = a.Cs;
@@ -299,31 +298,45 @@ __global__ __launch_bounds__(256) void igemm_conv_kernel_k32(const ConvArgs a) {
     const int nsteps = max(0, min(nsteps_all, s_begin + per_split) - s_begin);
     int tap = (s_begin * 32 + q * 8) / Cs, c = (s_begin * 32 + q * 8) - tap * Cs;
 
-    uint4 regA[RA], regW[RW];
+    // branch-free bounds-checked buffer loads (see the deep variant): a predicated global_load is an exec-masked
+    // branch and serialises the gathers of a stage
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)a.src, 0, (int)((unsigned)a.B * a.Hs * a.Ws * Cs * 2u), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)a.wgt, 0, (int)((unsigned)a.Nw * a.Ttot * Cs * 2u), 0x00020000);
+    const int last_tap = max(cd.ntaps - 1, 0);
+    int wbase[RW];
+#pragma unroll
+    for (int r = 0; r < RW; ++r) {
+        int nl = r0 + 64 * r, n = n0 + nl;
+        wbase[r] = (nl < BN && n < a.Nw) ? n * a.Ttot * Cs : -1;
+    }
+
+    u32x4 regA[RA], regW[RW];
     auto gload = [&]() {
         const bool tv = tap < cd.ntaps;
-        int4 te = tv ? sT[tap] : make_int4(0, 0, 0, 0);
+        const int4 te = sT[min(tap, last_tap)];
 #pragma unroll
         for (int r = 0; r < RA; ++r) {
             int ih = aih[r] + te.x, iw = aiw[r] + te.y;
-            bool ok = tv && aval[r] && (unsigned)ih < (unsigned)a.Hs && (unsigned)iw < (unsigned)a.Ws;
-            regA[r] = ok ? *(const uint4*)(a.src + abase[r] + ((long)ih * a.Ws + iw) * Cs + c)
-                         : make_uint4(0, 0, 0, 0);
+            bool ok = tv & ((unsigned)ih < (unsigned)a.Hs) & ((unsigned)iw < (unsigned)a.Ws);
+            unsigned off = ok ? (unsigned)(abase[r] + (ih * a.Ws + iw) * Cs + c) * 2u : 0xFFFFFFF0u;
+            regA[r] = __builtin_amdgcn_raw_buffer_load_b128(rsA, off, 0, 0);
         }
 #pragma unroll
         for (int r = 0; r < RW; ++r) {
-            int nl = r0 + 64 * r, n = n0 + nl;
-            bool ok = tv && nl < BN && n < a.Nw;
-            regW[r] = ok ? *(const uint4*)(a.wgt + ((long)n * a.Ttot + te.z) * Cs + c) : make_uint4(0, 0, 0, 0);
+            bool ok = tv & (wbase[r] >= 0);
+            unsigned off = ok ? (unsigned)(wbase[r] + te.z * Cs + c) * 2u : 0xFFFFFFF0u;
+            regW[r] = __builtin_amdgcn_raw_buffer_load_b128(rsW, off, 0, 0);
         }
     };
     auto lstore = [&](int buf) {
 #pragma unroll
         for (int r = 0; r < RA; ++r)
-            *(uint4*)(sA + (buf * BM + r0 + 64 * r) * PITCH1 + q * 16) = regA[r];
+            *(u32x4*)(sA + (buf * BM + r0 + 64 * r) * PITCH1 + q * 16) = regA[r];
 #pragma unroll
         for (int r = 0; r < RW; ++r)
-            if (r0 + 64 * r < BN) *(uint4*)(sW + (buf * BN + r0 + 64 * r) * PITCH1 + q * 16) = regW[r];
+            if (r0 + 64 * r < BN) *(u32x4*)(sW + (buf * BN + r0 + 64 * r) * PITCH1 + q * 16) = regW[r];
     };
     auto advance = [&]() {
         c += 32;
