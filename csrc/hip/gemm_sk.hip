@@ -52,6 +52,12 @@ __global__ __launch_bounds__(256) void gemm_sk_kernel(const GemmSkArgs a) {
             bv[t][e] = (a.bias && n < a.Nw) ? a.bias[n] : 0.f;
         }
 
+    // branch-free bounds-checked loads of X (rows >= M / k >= K read as zero): predicated global loads
+    // become exec-masked branches and the FRG x KS loads of an iteration no longer overlap
+    typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+    const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)a.x, 0, (int)((unsigned)(a.M * K * 2)), 0x00020000);
+
     for (long m0 = ((long)blockIdx.x * 4 + wave) * WROWS; m0 < a.M; m0 += (long)gridDim.x * 4 * WROWS) {
         // ---- all X fragments of the wave's 64 rows: FR x KS independent 16-byte loads in flight
         bf16x8_t xf[FRG][KS];
@@ -61,8 +67,9 @@ __global__ __launch_bounds__(256) void gemm_sk_kernel(const GemmSkArgs a) {
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
                 int k = ks * 32 + fq * 8;
-                uint4 v = make_uint4(0, 0, 0, 0);
-                if (m < a.M && k < K) v = *(const uint4*)(a.x + m * K + k);
+                const bool ok = (m < a.M) & (k < K);
+                const unsigned off = ok ? (unsigned)(m * K + k) * 2u : 0xFFFFFFF0u;
+                const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(rsX, off, 0, 0);
                 xf[j][ks] = __builtin_bit_cast(bf16x8_t, v);
             }
         }
@@ -138,7 +145,7 @@ static int launch_sk(const GemmSkArgs& a, hipStream_t s) {
 DDL_API int ddl_gemm_sk(const void* x, const void* w, const float* bias, void* y, long M, int K, int Nd, int Nw,
                         int act, float alpha, hipStream_t s) {
     if (K % 8 || Nd % 8 || K <= 0 || Nd <= 0 || M <= 0) return -1;
-    if (K > 128) return 1;
+    if (K > 128 || M * (long)K >= (1L << 31)) return 1;
     // wide outputs: 128-wide column tiles, only while X (re-read once per tile) stays small next to Y
     if (Nd > 128 && (M * (long)K > (8L << 20) || Nd > 65535 * 128L)) return 1;
     GemmSkArgs a{(const bf16_t*)x, (const bf16_t*)w, bias, (bf16_t*)y, M, K, Nd, Nw, act, alpha};

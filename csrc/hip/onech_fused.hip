@@ -64,7 +64,10 @@ __global__ __launch_bounds__(256) void tapfold_kernel(const TapFoldArgs a) {
         for (int ks = 0; ks < KS; ++ks) wf[tt][ks] = *(const bf16x8_t*)(sW + (16 * tt + fr) * WP + ks * 64 + fq * 16);
 
     // ---- z rows of the band: 16 pixels per MFMA column block, two fragments of loads in flight per wave
-    const bf16_t* xb = a.x + ((long)b * a.OH + oh_lo) * a.OW * a.C;
+    typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+    const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)a.x, 0, (int)((unsigned)a.B * a.OH * a.OW * a.C * 2u), 0x00020000);
+    const unsigned xb = (unsigned)((b * a.OH + oh_lo) * a.OW * a.C);      // element offset of the band's first z row
     for (int f0 = wave * 2; f0 * 16 < npix; f0 += 8) {
         bf16x8_t xf[2][KS];
 #pragma unroll
@@ -73,8 +76,9 @@ __global__ __launch_bounds__(256) void tapfold_kernel(const TapFoldArgs a) {
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
                 const int k = ks * 32 + fq * 8;
-                uint4 v = make_uint4(0, 0, 0, 0);
-                if (p < npix && k < a.C) v = *(const uint4*)(xb + (long)p * a.C + k);
+                const bool ok = (p < npix) & (k < a.C);
+                const unsigned off = ok ? (xb + (unsigned)(p * a.C + k)) * 2u : 0xFFFFFFF0u;
+                const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(rsX, off, 0, 0);
                 xf[j][ks] = __builtin_bit_cast(bf16x8_t, v);
             }
         }
