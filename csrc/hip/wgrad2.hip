@@ -181,15 +181,16 @@ __global__ __launch_bounds__(256, (TPW * (TN / 16) * (TC / 16) * 4 > 160 ? 1 : 2
                     s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
                     fx[q][j] = __builtin_bit_cast(bf16x8_t, v);
                 }
+            // Unconditional: a tap slot this wave does not own aliases tap 0 and accumulates values that are never
+            // written.  (Guarding the MFMAs by `q < ntaps_w` makes the compiler shuffle the accumulator file
+            // through v_accvgpr moves at every slice.)
 #pragma unroll
             for (int q = 0; q < TPW; ++q)
-                if (q < ntaps_w) {                 // wave-uniform
 #pragma unroll
-                    for (int i = 0; i < SN; ++i)
+                for (int i = 0; i < SN; ++i)
 #pragma unroll
-                        for (int j = 0; j < SC; ++j)
-                            acc[q][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fy[i], fx[q][j], acc[q][i][j], 0, 0, 0);
-                }
+                    for (int j = 0; j < SC; ++j)
+                        acc[q][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fy[i], fx[q][j], acc[q][i][j], 0, 0, 0);
         }
     }
 
