@@ -47,14 +47,19 @@ __device__ __forceinline__ s16x4 tr_read(const char* p) {
 template <int TN, int TC>
 __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a) {
     constexpr int SN = TN / 16, SC = TC / 16;           // 16-channel sub-tiles
-    constexpr int STAGE = (SN + SC) * 1024;             // bytes per wave: [sub][32 px][16 ch] bf16
+    // sub-tile strides: 1 KiB of data + a skew, so the 16-byte staging stores of one pixel row (its 2*S units go
+    // to S different sub-tiles) and of the next rows land in different banks (unskewed, sub-tiles alias: 4-way
+    // conflicts for 64 channels, measured 66 % of LDS cycles)
+    constexpr int SYS = 1024 + (SN >= 4 ? 32 : (SN == 2 ? 64 : 0));
+    constexpr int SXS = 1024 + (SC >= 4 ? 32 : (SC == 2 ? 64 : 0));
+    constexpr int STAGE = SN * SYS + SC * SXS;          // bytes per wave: [sub][32 px][16 ch] bf16
     constexpr int RED = TN * TC * 4;                    // bytes per wave partial tile
     constexpr int PER_WAVE = STAGE > RED ? STAGE : RED;
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     char* sY = smem + wave * PER_WAVE;
-    char* sX = sY + SN * 1024;
+    char* sX = sY + SN * SYS;
 
     const int ks = blockIdx.x, tap = blockIdx.y;
     const int nt = blockIdx.z / a.tiles_c, ct = blockIdx.z - nt * a.tiles_c;
@@ -117,25 +122,25 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a) {
 #pragma unroll
         for (int p = 0; p < PY; ++p) {
             int row = yrow + p * RPY;
-            *(u32x4*)(sY + (ycol >> 1) * 1024 + row * 32 + (ycol & 1) * 16) = ry[p];
+            *(u32x4*)(sY + (ycol >> 1) * SYS + row * 32 + (ycol & 1) * 16) = ry[p];
         }
 #pragma unroll
         for (int p = 0; p < PX; ++p) {
             int row = xrow + p * RPX;
-            *(u32x4*)(sX + (xcol >> 1) * 1024 + row * 32 + (xcol & 1) * 16) = rx[p];
+            *(u32x4*)(sX + (xcol >> 1) * SXS + row * 32 + (xcol & 1) * 16) = rx[p];
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __builtin_amdgcn_wave_barrier();
         bf16x8_t fy[SN], fx[SC];
 #pragma unroll
         for (int i = 0; i < SN; ++i) {
-            s16x4 lo = tr_read(sY + i * 1024 + tr_off), hi = tr_read(sY + i * 1024 + tr_off + 512);
+            s16x4 lo = tr_read(sY + i * SYS + tr_off), hi = tr_read(sY + i * SYS + tr_off + 512);
             s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
             fy[i] = __builtin_bit_cast(bf16x8_t, v);
         }
 #pragma unroll
         for (int j = 0; j < SC; ++j) {
-            s16x4 lo = tr_read(sX + j * 1024 + tr_off), hi = tr_read(sX + j * 1024 + tr_off + 512);
+            s16x4 lo = tr_read(sX + j * SXS + tr_off), hi = tr_read(sX + j * SXS + tr_off + 512);
             s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
             fx[j] = __builtin_bit_cast(bf16x8_t, v);
         }
@@ -238,7 +243,9 @@ DDL_API void ddl_slab_reduce(const float* slab, float* out, long n, long stride,
 
 template <int TN, int TC>
 static void launch_wgrad(const WgradArgs& a, int ksplit, int taps, int tiles, hipStream_t s) {
-    constexpr int STAGE = (TN / 16 + TC / 16) * 1024, RED = TN * TC * 4;
+    constexpr int SN = TN / 16, SC = TC / 16;           // must mirror the kernel's skewed sub-tile strides
+    constexpr int STAGE = SN * (1024 + (SN >= 4 ? 32 : (SN == 2 ? 64 : 0))) + SC * (1024 + (SC >= 4 ? 32 : (SC == 2 ? 64 : 0)));
+    constexpr int RED = TN * TC * 4;
     constexpr int PER_WAVE = STAGE > RED ? STAGE : RED;
     wgrad_kernel<TN, TC><<<dim3(ksplit, taps, tiles), 256, 4 * PER_WAVE, s>>>(a);
 }

@@ -42,6 +42,7 @@ __device__ __forceinline__ s16x4 tr_read2(const char* p) {
 template <int TN, int TC, int TPW>
 __global__ __launch_bounds__(256, (TPW * (TN / 16) * (TC / 16) * 4 > 160 ? 1 : 2)) void wgrad2_kernel(const Wg2Args a) {
     constexpr int SN = TN / 16, SC = TC / 16;
+    constexpr bool PIPE = TPW * SN * SC * 4 > 160;       // the one-block-per-CU variants
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* sX = smem;
     char* sY = smem + a.y_off;
@@ -161,10 +162,9 @@ __global__ __launch_bounds__(256, (TPW * (TN / 16) * (TC / 16) * 4 > 160 ? 1 : 2
 
         // ---- every wave walks all 32-pixel slices; its taps' accumulators stay in registers.  All of a
         // slice's fragments are fetched first (one burst of transposing LDS reads), then the MFMAs run.
-        for (int m0 = 0; m0 < a.Mmax; m0 += 32) {
+        auto load = [&](int m0, bf16x8_t (&fy)[SN], bf16x8_t (&fx)[TPW][SC]) {
             const int plo = m0 + 4 * g + tq, phi = plo + 16;
             const int xlo = sTbl[plo < a.Mmax ? plo : 0], xhi = sTbl[phi < a.Mmax ? phi : 0];
-            bf16x8_t fy[SN], fx[TPW][SC];
 #pragma unroll
             for (int i = 0; i < SN; ++i) {
                 s16x4 lo = tr_read2(sY + plo * a.ypitch + chan_y + i * 32);
@@ -181,9 +181,11 @@ __global__ __launch_bounds__(256, (TPW * (TN / 16) * (TC / 16) * 4 > 160 ? 1 : 2
                     s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
                     fx[q][j] = __builtin_bit_cast(bf16x8_t, v);
                 }
-            // Unconditional: a tap slot this wave does not own aliases tap 0 and accumulates values that are never
-            // written.  (Guarding the MFMAs by `q < ntaps_w` makes the compiler shuffle the accumulator file
-            // through v_accvgpr moves at every slice.)
+        };
+        // Unconditional MFMAs: a tap slot this wave does not own aliases tap 0 and accumulates values that are
+        // never written.  (Guarding them by `q < ntaps_w` makes the compiler shuffle the accumulator file
+        // through v_accvgpr moves at every slice.)
+        auto mma = [&](const bf16x8_t (&fy)[SN], const bf16x8_t (&fx)[TPW][SC]) {
 #pragma unroll
             for (int q = 0; q < TPW; ++q)
 #pragma unroll
@@ -191,6 +193,27 @@ __global__ __launch_bounds__(256, (TPW * (TN / 16) * (TC / 16) * 4 > 160 ? 1 : 2
 #pragma unroll
                     for (int j = 0; j < SC; ++j)
                         acc[q][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fy[i], fx[q][j], acc[q][i][j], 0, 0, 0);
+        };
+        if constexpr (PIPE) {
+            // one block (one wave per SIMD) per CU: nothing else hides the LDS latency, so the next slice's
+            // fragments are requested before the current slice's MFMAs (two register sets, 512-VGPR budget)
+            bf16x8_t fyA[SN], fxA[TPW][SC], fyB[SN], fxB[TPW][SC];
+            load(0, fyA, fxA);
+            for (int m0 = 0; m0 < a.Mmax; m0 += 64) {
+                const bool n1 = m0 + 32 < a.Mmax;          // block-uniform
+                if (n1) load(m0 + 32, fyB, fxB);
+                mma(fyA, fxA);
+                if (n1) {
+                    if (m0 + 64 < a.Mmax) load(m0 + 64, fyA, fxA);
+                    mma(fyB, fxB);
+                }
+            }
+        } else {
+            for (int m0 = 0; m0 < a.Mmax; m0 += 32) {
+                bf16x8_t fy[SN], fx[TPW][SC];
+                load(m0, fy, fx);
+                mma(fy, fx);
+            }
         }
     }
 

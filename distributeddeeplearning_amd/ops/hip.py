@@ -1044,6 +1044,20 @@ def _tr_pitch(nbytes: int) -> int:
     return (p if p % 2 else p + 1) * 32
 
 
+W2_XPITCH_SKEW = os.environ.get("DDL_W2_XPITCH_SKEW", "1") == "1"
+
+
+def _tr_pitch_x(nbytes: int, sw: int) -> int:
+    """Pixel pitch of wgrad2's X patch.  Consecutive output pixels read patch pixels `sw` apart, so it is
+    sw * pitch that has to be an odd multiple of 32 B: for stride 2 an odd multiple of 16 B (16 B keeps the
+    staging stores aligned).  With the plain pitch every stride-2 layer read X through 2-way bank conflicts
+    (44 % of the kernel's LDS cycles, profiles/r1_dcgan28_pmc_counters.md)."""
+    if sw == 2 and W2_XPITCH_SKEW:
+        p = (nbytes + 15) // 16
+        return (p if p % 2 else p + 1) * 16
+    return _tr_pitch(nbytes)
+
+
 def _wgrad2_one_plan(g, B, Cx, Ny, n_lim, c_lim, tn, tc, TPW, budget_kb=None):
     """One wgrad2 launch plan for an output tile (tn x tc), TPW taps per wave and an LDS budget (which
     sets how many images / rows a unit holds and with it how many blocks share a CU)."""
@@ -1054,7 +1068,7 @@ def _wgrad2_one_plan(g, B, Cx, Ny, n_lim, c_lim, tn, tc, TPW, budget_kb=None):
     if budget_kb is None:
         budget_kb = 150 if one_block else 76
     budget = budget_kb * 1024
-    xp, yp = _tr_pitch(Cx * 2), _tr_pitch(Ny * 2)
+    xp, yp = _tr_pitch_x(Cx * 2, g.sw), _tr_pitch(Ny * 2)
     PW = (g.OW - 1) * g.sw + (g.KW - 1) * g.dw + 1
     lds = lambda img, br: _wgrad2_lds(img, br, g.OW, Ny, (br - 1) * g.sh + (g.KH - 1) * g.dh + 1, PW, xp, yp, T)
     IMG, BR = 0, g.OH
