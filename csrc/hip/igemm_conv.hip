@@ -248,7 +248,13 @@ __global__ __launch_bounds__(256) void igemm_conv_kernel(const ConvArgs a) {
 // ---- the shallow variant: 32-wide K stages, loads one step ahead.  Less LDS and fewer registers per
 // block (more resident blocks), and no pipeline ramp: it wins on short reductions and on grids
 // that already fill the CUs several times over; the autotuner times both.
-#define PITCH1 96             // 32-wide K stage: 64 B of bf16 K-data + 32 B pad
+// LDS rows are 64 B (one 32-wide K stage), unpadded, with the 16-byte slot XOR-swizzled by the row's group of
+// four: slot' = slot ^ ((-(row >> 2)) & 3).  ds_write_b128 is served in groups of 8 contiguous lanes over 32
+// banks (two whole rows = one 128-byte bank row, any in-row permutation is conflict-free); ds_read_b128 in the
+// four 16-lane groups {0-3,12-15,20-27},... over 64 banks, and this XOR sends the four lanes of a group that
+// share (row mod 4) to four different slots.  The padded layout (96 B) conflicted 2-way on every store
+// (30 % of LDS cycles, profiles/r1_dcgan64_pmc_counters.md) and used 1.5x the LDS.
+#define PITCH1 64
 
 template <int BM, int BN>
 __global__ __launch_bounds__(256) void igemm_conv_kernel_k32(const ConvArgs a) {
@@ -277,6 +283,7 @@ __global__ __launch_bounds__(256) void igemm_conv_kernel_k32(const ConvArgs a) {
 
     // ---- per-thread staging assignment: kgroup q (8 k-elements), rows r0 + 64*r
     const int q = tid & 3, r0 = tid >> 2;
+    const int qsw = (q ^ ((-(r0 >> 2)) & 3)) * 16;      // swizzled store slot (rows r0 + 64 r share it)
     const int HW = cd.Hc * cd.Wc;
     int abase[RA];                            // element offsets fit 31 bits (checked on the host)
     int aih[RA], aiw[RA];
@@ -333,10 +340,10 @@ __global__ __launch_bounds__(256) void igemm_conv_kernel_k32(const ConvArgs a) {
     auto lstore = [&](int buf) {
 #pragma unroll
         for (int r = 0; r < RA; ++r)
-            *(u32x4*)(sA + (buf * BM + r0 + 64 * r) * PITCH1 + q * 16) = regA[r];
+            *(u32x4*)(sA + (buf * BM + r0 + 64 * r) * PITCH1 + qsw) = regA[r];
 #pragma unroll
         for (int r = 0; r < RW; ++r)
-            if (r0 + 64 * r < BN) *(u32x4*)(sW + (buf * BN + r0 + 64 * r) * PITCH1 + q * 16) = regW[r];
+            if (r0 + 64 * r < BN) *(u32x4*)(sW + (buf * BN + r0 + 64 * r) * PITCH1 + qsw) = regW[r];
     };
     auto advance = [&]() {
         c += 32;
@@ -357,6 +364,7 @@ __global__ __launch_bounds__(256) void igemm_conv_kernel_k32(const ConvArgs a) {
     __syncthreads();
 
     const int fr = lane & 15, fq = lane >> 4;
+    const int fqsw = (fq ^ ((-(fr >> 2)) & 3)) * 16;   // swizzled read slot (tile bases are multiples of 16 rows)
     for (int s = 0; s < nsteps; ++s) {
         const int cur = s & 1;
         const bool more = s + 1 < nsteps;
@@ -364,10 +372,10 @@ __global__ __launch_bounds__(256) void igemm_conv_kernel_k32(const ConvArgs a) {
         bf16x8_t wf[NT], xf[4];
 #pragma unroll
         for (int i = 0; i < NT; ++i)
-            wf[i] = *(const bf16x8_t*)(sW + (cur * BN + wn * WN + 16 * i + fr) * PITCH1 + fq * 16);
+            wf[i] = *(const bf16x8_t*)(sW + (cur * BN + wn * WN + 16 * i + fr) * PITCH1 + fqsw);
 #pragma unroll
         for (int j = 0; j < 4; ++j)
-            xf[j] = *(const bf16x8_t*)(sA + (cur * BM + wm * 64 + 16 * j + fr) * PITCH1 + fq * 16);
+            xf[j] = *(const bf16x8_t*)(sA + (cur * BM + wm * 64 + 16 * j + fr) * PITCH1 + fqsw);
 #pragma unroll
         for (int i = 0; i < NT; ++i)
 #pragma unroll
