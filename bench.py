@@ -16,7 +16,10 @@ import os
 import sys
 import time
 
-import torch
+# the host driver only supports dmabuf IPC: must be in the environment before the HIP runtime starts
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+import torch  # noqa: E402
 
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
