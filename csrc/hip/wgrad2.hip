@@ -30,6 +30,7 @@ struct Wg2Args {
     int y_off, t_off, k_off;           // LDS offsets: dY tile, pixel table, tap-offset table (X patch at 0)
     int Mmax;                          // pixels per full unit (IMG * BR * OW)
     int tiles_c, ngroups;
+    int scx8, sny8;                    // 16-byte channel units staged per pixel: min(Cx, TC) / 8, min(Ny, TN) / 8
     float inv_xper_img, inv_cx8, inv_PW, inv_yrow, inv_OW, inv_rows;
 };
 
@@ -79,7 +80,9 @@ __global__ __launch_bounds__(256, (TPW * (TN / 16) * (TC / 16) * 4 > 160 ? 1 : 2
 #pragma unroll
             for (int j = 0; j < SC; ++j) acc[q][i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    const int cx8 = a.Cx >> 3, ny8 = a.Ny >> 3;
+    // only the tile's channels are staged (c0 .. c0+TC of X, n0 .. n0+TN of dY): with 2 x 2 output tiles the full
+    // rows would be staged by four blocks that each use half of them
+    const int cx8 = a.scx8, ny8 = a.sny8;
     // this wave's tap offsets into the patch (taps it does not own alias tap 0: read, never accumulated)
     int toff[TPW];
 #pragma unroll
@@ -87,9 +90,9 @@ __global__ __launch_bounds__(256, (TPW * (TN / 16) * (TC / 16) * 4 > 160 ? 1 : 2
         int t = gw + q * G;
         int tt = t < T ? t : 0;
         int kh = tt / a.KW, kw = tt - kh * a.KW;
-        toff[q] = (kh * a.dh * a.PW + kw * a.dw) * a.xpitch + (c0 + 4 * tp) * 2;
+        toff[q] = (kh * a.dh * a.PW + kw * a.dw) * a.xpitch + (4 * tp) * 2;
     }
-    const int chan_y = (n0 + 4 * tp) * 2;
+    const int chan_y = (4 * tp) * 2;
 
     // Branch-free bounds-checked buffer loads for the staging gathers: an out-of-range unit gets an offset beyond
     // the descriptor and reads as zero.  (A predicated global_load compiles to an exec-masked branch after which
@@ -123,8 +126,9 @@ __global__ __launch_bounds__(256, (TPW * (TN / 16) * (TC / 16) * 4 > 160 ? 1 : 2
                     int pix = fdiv2(r, a.inv_cx8), c8 = r - pix * cx8;
                     int pr = fdiv2(pix, a.inv_PW), pc = pix - pr * a.PW;
                     int sr = row0 + pr, sc = col0 + pc, b = b0 + img;
-                    const bool ok = in & (b < a.B) & ((unsigned)sr < (unsigned)a.H) & ((unsigned)sc < (unsigned)a.W);
-                    const unsigned off = ok ? (unsigned)(((b * a.H + sr) * a.W + sc) * a.Cx + c8 * 8) * 2u : OOB_OFF;
+                    const bool ok = in & (b < a.B) & ((unsigned)sr < (unsigned)a.H) & ((unsigned)sc < (unsigned)a.W) &
+                                    (c0 + c8 * 8 < a.Cx);
+                    const unsigned off = ok ? (unsigned)(((b * a.H + sr) * a.W + sc) * a.Cx + c0 + c8 * 8) * 2u : OOB_OFF;
                     v[k] = __builtin_amdgcn_raw_buffer_load_b128(rsX, off, 0, 0);
                     dst[k] = in ? img * a.ximg_bytes + pix * a.xpitch + c8 * 16 : -1;
                 }
@@ -147,8 +151,8 @@ __global__ __launch_bounds__(256, (TPW * (TN / 16) * (TC / 16) * 4 > 160 ? 1 : 2
                     int img = fdiv2(m, a.inv_rows), rem = m - img * (a.BR * a.OW);
                     int il = fdiv2(rem, a.inv_OW), jl = rem - il * a.OW;
                     int b = b0 + img;
-                    const bool ok = in & (m < a.Mmax) & (b < a.B) & (il < nrow);
-                    const unsigned off = ok ? (unsigned)(((b * a.OH + i0 + il) * a.OW + jl) * a.Ny + c8 * 8) * 2u : OOB_OFF;
+                    const bool ok = in & (m < a.Mmax) & (b < a.B) & (il < nrow) & (n0 + c8 * 8 < a.Ny);
+                    const unsigned off = ok ? (unsigned)(((b * a.OH + i0 + il) * a.OW + jl) * a.Ny + n0 + c8 * 8) * 2u : OOB_OFF;
                     v[k] = __builtin_amdgcn_raw_buffer_load_b128(rsY, off, 0, 0);
                     dst[k] = in ? m * a.ypitch + c8 * 16 : -1;
                 }
@@ -283,7 +287,8 @@ DDL_API int ddl_conv_wgrad2(const void* dy, const void* x, float* slab, long num
     a.PW = (OW - 1) * sw + (KW - 1) * dw + 1;
     a.xpitch = xpitch; a.ypitch = ypitch; a.ximg_bytes = a.PH * a.PW * xpitch;
     a.Mmax = IMG * BR * OW;
-    if (xpitch % 16 || ypitch % 16 || xpitch < Cx * 2 || ypitch < Ny * 2) return -1;
+    a.scx8 = (Cx < TC ? Cx : TC) / 8; a.sny8 = (Ny < TN ? Ny : TN) / 8;
+    if (xpitch % 16 || ypitch % 16 || xpitch < a.scx8 * 16 || ypitch < a.sny8 * 16) return -1;
     if ((long)IMG * a.PH * a.PW * (Cx / 8) >= (1L << 22) || (long)(a.Mmax + 32) * (Ny / 8) >= (1L << 22)) return -2;
     long xbytes = ((long)IMG * a.ximg_bytes + 15) / 16 * 16;
     long mpad = (a.Mmax + 31) / 32 * 32;
@@ -296,10 +301,10 @@ DDL_API int ddl_conv_wgrad2(const void* dy, const void* x, float* slab, long num
     a.tiles_c = (c_lim + TC - 1) / TC;
     a.ngroups = ngroups;
     if (4 * ngroups * TPW < KH * KW) return -4;           // not every tap would be owned by a wave
-    a.inv_xper_img = 1.0f / (float)(a.PH * a.PW * (Cx / 8));
-    a.inv_cx8 = 1.0f / (float)(Cx / 8);
+    a.inv_xper_img = 1.0f / (float)(a.PH * a.PW * a.scx8);
+    a.inv_cx8 = 1.0f / (float)a.scx8;
     a.inv_PW = 1.0f / (float)a.PW;
-    a.inv_yrow = 1.0f / (float)(Ny / 8);
+    a.inv_yrow = 1.0f / (float)a.sny8;
     a.inv_OW = 1.0f / (float)OW;
     a.inv_rows = 1.0f / (float)(BR * OW);
     int tiles = tiles_n * a.tiles_c;

@@ -1068,7 +1068,8 @@ def _wgrad2_one_plan(g, B, Cx, Ny, n_lim, c_lim, tn, tc, TPW, budget_kb=None):
     if budget_kb is None:
         budget_kb = 150 if one_block else 76
     budget = budget_kb * 1024
-    xp, yp = _tr_pitch_x(Cx * 2, g.sw), _tr_pitch(Ny * 2)
+    # only the output tile's channels are staged: pitches follow the tile, not the tensor
+    xp, yp = _tr_pitch_x(min(Cx, tc) * 2, g.sw), _tr_pitch(min(Ny, tn) * 2)
     PW = (g.OW - 1) * g.sw + (g.KW - 1) * g.dw + 1
     lds = lambda img, br: _wgrad2_lds(img, br, g.OW, Ny, (br - 1) * g.sh + (g.KH - 1) * g.dh + 1, PW, xp, yp, T)
     IMG, BR = 0, g.OH
