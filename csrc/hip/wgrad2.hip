@@ -43,7 +43,9 @@ __device__ __forceinline__ s16x4 tr_read2(const char* p) {
 template <int TN, int TC, int TPW>
 __global__ __launch_bounds__(256, (TPW * (TN / 16) * (TC / 16) * 4 > 160 ? 1 : 2)) void wgrad2_kernel(const Wg2Args a) {
     constexpr int SN = TN / 16, SC = TC / 16;
-    constexpr bool PIPE = TPW * SN * SC * 4 > 160;       // the one-block-per-CU variants
+    // the one-block-per-CU variants (512-register budget) whose fragment sets leave room: they prefetch the next
+    // slice's fragments and stage with deeper rounds
+    constexpr bool PIPE = TPW * SN * SC * 4 > 160 && (SN + TPW * SC) * 8 <= 160;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* sX = smem;
     char* sY = smem + a.y_off;
@@ -109,58 +111,70 @@ __global__ __launch_bounds__(256, (TPW * (TN / 16) * (TC / 16) * 4 > 160 ? 1 : 2
         const int b0 = grp * a.IMG, i0 = band * a.BR;
         const int nrow = min(a.BR, a.OH - i0);
         __syncthreads();                          // previous unit fully consumed (also orders the tables)
-        // ---- stage X patch (zero halo / missing images) ...
+        // ---- stage the X patch (zero halo / missing images) and the dY tile (pixel m = (img, il, jl) of the band;
+        // rows past the band / batch are zero).  The kernel is bound by this phase, so it runs as one stream of
+        // rounds of NLD 16-byte loads per thread -- X rounds, then dY rounds -- with the loads of round r+1
+        // issued before the LDS stores of round r: 2 * NLD loads per thread in flight, no drain between X and dY.
         {
             const int row0 = i0 * a.sh - a.pt, col0 = -a.pl;
             const int per_img = a.PH * a.PW * cx8;
-            // eight independent 16-byte loads in flight per thread before the first LDS store
-            for (int base = tid; base < a.IMG * per_img; base += 256 * 8) {
-                u32x4_t v[8];
-                int dst[8];
-#pragma unroll
-                for (int k = 0; k < 8; ++k) {
-                    int u = base + k * 256;
-                    bool in = u < a.IMG * per_img;
-                    int uu = in ? u : 0;
-                    int img = fdiv2(uu, a.inv_xper_img), r = uu - img * per_img;
-                    int pix = fdiv2(r, a.inv_cx8), c8 = r - pix * cx8;
-                    int pr = fdiv2(pix, a.inv_PW), pc = pix - pr * a.PW;
-                    int sr = row0 + pr, sc = col0 + pc, b = b0 + img;
-                    const bool ok = in & (b < a.B) & ((unsigned)sr < (unsigned)a.H) & ((unsigned)sc < (unsigned)a.W) &
-                                    (c0 + c8 * 8 < a.Cx);
-                    const unsigned off = ok ? (unsigned)(((b * a.H + sr) * a.W + sc) * a.Cx + c0 + c8 * 8) * 2u : OOB_OFF;
-                    v[k] = __builtin_amdgcn_raw_buffer_load_b128(rsX, off, 0, 0);
-                    dst[k] = in ? img * a.ximg_bytes + pix * a.xpitch + c8 * 16 : -1;
-                }
-#pragma unroll
-                for (int k = 0; k < 8; ++k)
-                    if (dst[k] >= 0) *(u32x4_t*)(sX + dst[k]) = v[k];
-            }
-            // ... and the dY tile: pixel m = (img, il, jl) of the band; rows past the band / batch are zero
-            const int per_row = a.BR * a.OW * ny8;
+            const int nx = a.IMG * per_img;
             const int mpad = (a.Mmax + 31) / 32 * 32;
-            for (int base = tid; base < mpad * ny8; base += 256 * 8) {
-                u32x4_t v[8];
-                int dst[8];
+            const int nyu = mpad * ny8;
+            constexpr int NLD = PIPE ? 6 : 4, RND = 256 * NLD;       // loads per thread per round, units per round
+            const int rx = (nx + RND - 1) / RND, R = rx + (nyu + RND - 1) / RND;
+            auto issue = [&](int r, u32x4_t (&v)[NLD], int (&dst)[NLD]) {
+                if (r < rx) {                                  // block-uniform
+                    const int base = tid + r * RND;
 #pragma unroll
-                for (int k = 0; k < 8; ++k) {
-                    int u = base + k * 256;
-                    bool in = u < mpad * ny8;
-                    int uu = in ? u : 0;
-                    int m = fdiv2(uu, a.inv_yrow), c8 = uu - m * ny8;
-                    int img = fdiv2(m, a.inv_rows), rem = m - img * (a.BR * a.OW);
-                    int il = fdiv2(rem, a.inv_OW), jl = rem - il * a.OW;
-                    int b = b0 + img;
-                    const bool ok = in & (m < a.Mmax) & (b < a.B) & (il < nrow) & (n0 + c8 * 8 < a.Ny);
-                    const unsigned off = ok ? (unsigned)(((b * a.OH + i0 + il) * a.OW + jl) * a.Ny + n0 + c8 * 8) * 2u : OOB_OFF;
-                    v[k] = __builtin_amdgcn_raw_buffer_load_b128(rsY, off, 0, 0);
-                    dst[k] = in ? m * a.ypitch + c8 * 16 : -1;
+                    for (int k = 0; k < NLD; ++k) {
+                        int u = base + k * 256;
+                        bool in = u < nx;
+                        int uu = in ? u : 0;
+                        int img = fdiv2(uu, a.inv_xper_img), rr = uu - img * per_img;
+                        int pix = fdiv2(rr, a.inv_cx8), c8 = rr - pix * cx8;
+                        int pr = fdiv2(pix, a.inv_PW), pc = pix - pr * a.PW;
+                        int sr = row0 + pr, sc = col0 + pc, bb = b0 + img;
+                        const bool ok = in & (bb < a.B) & ((unsigned)sr < (unsigned)a.H) & ((unsigned)sc < (unsigned)a.W) &
+                                        (c0 + c8 * 8 < a.Cx);
+                        const unsigned off = ok ? (unsigned)(((bb * a.H + sr) * a.W + sc) * a.Cx + c0 + c8 * 8) * 2u : OOB_OFF;
+                        v[k] = __builtin_amdgcn_raw_buffer_load_b128(rsX, off, 0, 0);
+                        dst[k] = in ? img * a.ximg_bytes + pix * a.xpitch + c8 * 16 : -1;
+                    }
+                } else {
+                    const int base = tid + (r - rx) * RND;
+#pragma unroll
+                    for (int k = 0; k < NLD; ++k) {
+                        int u = base + k * 256;
+                        bool in = u < nyu;
+                        int uu = in ? u : 0;
+                        int m = fdiv2(uu, a.inv_yrow), c8 = uu - m * ny8;
+                        int img = fdiv2(m, a.inv_rows), rem = m - img * (a.BR * a.OW);
+                        int il = fdiv2(rem, a.inv_OW), jl = rem - il * a.OW;
+                        int bb = b0 + img;
+                        const bool ok = in & (m < a.Mmax) & (bb < a.B) & (il < nrow) & (n0 + c8 * 8 < a.Ny);
+                        const unsigned off = ok ? (unsigned)(((bb * a.OH + i0 + il) * a.OW + jl) * a.Ny + n0 + c8 * 8) * 2u : OOB_OFF;
+                        v[k] = __builtin_amdgcn_raw_buffer_load_b128(rsY, off, 0, 0);
+                        dst[k] = in ? a.y_off + m * a.ypitch + c8 * 16 : -1;
+                    }
                 }
+            };
+            auto store = [&](const u32x4_t (&v)[NLD], const int (&dst)[NLD]) {
 #pragma unroll
-                for (int k = 0; k < 8; ++k)
-                    if (dst[k] >= 0) *(u32x4_t*)(sY + dst[k]) = v[k];
+                for (int k = 0; k < NLD; ++k)
+                    if (dst[k] >= 0) *(u32x4_t*)(smem + dst[k]) = v[k];
+            };
+            u32x4_t vA[NLD], vB[NLD];
+            int dA[NLD], dB[NLD];
+            issue(0, vA, dA);
+            for (int r = 0; r < R; r += 2) {
+                if (r + 1 < R) issue(r + 1, vB, dB);
+                store(vA, dA);
+                if (r + 1 < R) {
+                    if (r + 2 < R) issue(r + 2, vA, dA);
+                    store(vB, dB);
+                }
             }
-            (void)per_row;
         }
         __syncthreads();
 
