@@ -24,6 +24,7 @@ struct Wg2Args {
     int n_lim, c_lim;
     long sn, st, sc;          // output strides (elements)
     long slab_stride;
+    int frag;                 // slab in fragment order (see the epilogue); else in the gradient's own layout
     int IMG, BR, bands, n_units;
     int PH, PW, xpitch, ximg_bytes;   // X patch: rows/cols (with halo), bytes per pixel / per image
     int ypitch;                        // dY tile bytes per pixel
@@ -235,7 +236,27 @@ __global__ __launch_bounds__(256, (TPW * (TN / 16) * (TC / 16) * 4 > 160 ? 1 : 2
         }
     }
 
-    // ---- one slab write per wave tap: lane holds rows 16i + 4g + e, column 16j + li of the tile
+    // ---- one slab write per wave tap: lane holds rows 16i + 4g + e, column 16j + li of the tile.
+    // Fragment order ([split][tile][group][wave][q][i][j][lane] float4): every store instruction of a wave is one
+    // contiguous KiB.  Written in the gradient's own layout the same data leaves as 16- or 64-byte pieces, and with
+    // 256 partial copies of the gradient (50 MB per call at the reference batch) that store burst was a third of
+    // the kernel; slab_reduce_frag (below) sums the copies and scatters only the final, small gradient.
+    if (a.frag) {
+        float4* o4 = (float4*)a.slab +
+                     ((((long)blockIdx.x * gridDim.z + blockIdx.z) * a.ngroups + group) * 4 + wave) * (TPW * SN * SC * 64) + lane;
+#pragma unroll
+        for (int q = 0; q < TPW; ++q) {
+            if (q < ntaps_w) {
+#pragma unroll
+                for (int i = 0; i < SN; ++i)
+#pragma unroll
+                    for (int j = 0; j < SC; ++j)
+                        o4[((q * SN + i) * SC + j) * 64] =
+                            make_float4(acc[q][i][j][0], acc[q][i][j][1], acc[q][i][j][2], acc[q][i][j][3]);
+            }
+        }
+        return;
+    }
     float* out = a.slab + (long)blockIdx.x * a.slab_stride;
 #pragma unroll
     for (int q = 0; q < TPW; ++q) {
@@ -259,6 +280,80 @@ __global__ __launch_bounds__(256, (TPW * (TN / 16) * (TC / 16) * 4 > 160 ? 1 : 2
                 }
         }
     }
+}
+
+// Sum the fragment-order slabs over the splits (fixed order: deterministic) and scatter into the gradient.
+// One thread column per float4 of a slab, eight split lanes per column combined through LDS.
+struct FragDecode {
+    int TN, TC, TPW, SN, SC, ngroups, tiles_c, T, n_lim, c_lim;
+    long sn, st, sc;
+};
+
+__global__ __launch_bounds__(256) void slab_reduce_frag_kernel(const float4* __restrict__ slab, float* __restrict__ out,
+                                                               long e4, int nsplit, const FragDecode d) {
+    __shared__ float4 red[8][33];
+    const int col = threadIdx.x & 31, kl = threadIdx.x >> 5;
+    const long f = (long)blockIdx.x * 32 + col;
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    // decode first: slots of taps no wave owns are never written (uninitialised memory) and must not be read
+    int n = 0, c = 0, tap = d.T;
+    if (f < e4) {
+        const int lane = (int)(f & 63);
+        long r = f >> 6;
+        const int j = (int)(r % d.SC); r /= d.SC;
+        const int i = (int)(r % d.SN); r /= d.SN;
+        const int q = (int)(r % d.TPW); r /= d.TPW;
+        const int wave = (int)(r & 3); r >>= 2;
+        const int group = (int)(r % d.ngroups);
+        const int z = (int)(r / d.ngroups);
+        const int nt = z / d.tiles_c, ct = z - nt * d.tiles_c;
+        tap = group * 4 + wave + q * 4 * d.ngroups;
+        n = nt * d.TN + 16 * i + 4 * (lane >> 4);
+        c = ct * d.TC + 16 * j + (lane & 15);
+    }
+    const bool live = tap < d.T;                 // uniform per 64 consecutive f (a wave of the producer)
+    if (live) {
+        int k = kl;
+        for (; k + 24 < nsplit; k += 32) {       // four independent 16-byte loads per trip, fixed order
+            float4 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = slab[(long)(k + 8 * u) * e4 + f];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { s.x += v[u].x; s.y += v[u].y; s.z += v[u].z; s.w += v[u].w; }
+        }
+        for (; k < nsplit; k += 8) {
+            float4 v = slab[(long)k * e4 + f];
+            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        }
+    }
+    red[kl][col] = s;
+    __syncthreads();
+    if (kl == 0 && live && c < d.c_lim) {
+#pragma unroll
+        for (int q = 1; q < 8; ++q) {
+            float4 v = red[q][col];
+            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        }
+        const float sv[4] = {s.x, s.y, s.z, s.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            if (n + e < d.n_lim) out[(n + e) * d.sn + tap * d.st + c * d.sc] = sv[e];
+    }
+}
+
+// floats per split of a fragment-order slab
+DDL_API long ddl_wgrad2_frag_elems(int TN, int TC, int TPW, int ngroups, int n_lim, int c_lim) {
+    long tiles = (long)((n_lim + TN - 1) / TN) * ((c_lim + TC - 1) / TC);
+    return tiles * ngroups * 4 * TPW * (TN / 16) * (TC / 16) * 256;
+}
+
+DDL_API int ddl_slab_reduce_frag(const float* slab, float* out, int nsplit, int TN, int TC, int TPW, int ngroups,
+                                 int T, int n_lim, int c_lim, long sn, long st, long sc, hipStream_t s) {
+    if (nsplit < 1 || TN % 16 || TC % 16 || TPW < 1 || ngroups < 1) return -1;
+    FragDecode d{TN, TC, TPW, TN / 16, TC / 16, ngroups, (c_lim + TC - 1) / TC, T, n_lim, c_lim, sn, st, sc};
+    const long e4 = ddl_wgrad2_frag_elems(TN, TC, TPW, ngroups, n_lim, c_lim) / 4;
+    slab_reduce_frag_kernel<<<(int)((e4 + 31) / 32), 256, 0, s>>>((const float4*)slab, out, e4, nsplit, d);
+    return 0;
 }
 
 template <int TN, int TC, int TPW>
@@ -287,14 +382,14 @@ DDL_API int ddl_wgrad2_lds(int IMG, int BR, int OW, int Ny, int PH, int PW, int 
 DDL_API int ddl_conv_wgrad2(const void* dy, const void* x, float* slab, long numel, int nsplit, int B, int OH,
                             int OW, int Ny, int H, int W, int Cx, int KH, int KW, int sh, int sw, int dh, int dw,
                             int pt, int pl, int n_lim, int c_lim, long sn, long st, long sc, int IMG, int BR,
-                            int xpitch, int ypitch, int TN, int TC, int TPW, int ngroups, hipStream_t s) {
+                            int xpitch, int ypitch, int TN, int TC, int TPW, int ngroups, int frag, hipStream_t s) {
     if (Ny % 8 || Cx % 8 || nsplit < 1 || IMG < 1 || BR < 1 || ngroups < 1) return -1;
     if ((long)B * OH * OW * Ny >= (1L << 31) || (long)B * H * W * Cx >= (1L << 31)) return -3;
     Wg2Args a;
     a.dy = (const bf16_t*)dy; a.x = (const bf16_t*)x; a.slab = slab;
     a.B = B; a.OH = OH; a.OW = OW; a.Ny = Ny; a.H = H; a.W = W; a.Cx = Cx;
     a.KH = KH; a.KW = KW; a.sh = sh; a.sw = sw; a.dh = dh; a.dw = dw; a.pt = pt; a.pl = pl;
-    a.n_lim = n_lim; a.c_lim = c_lim; a.sn = sn; a.st = st; a.sc = sc; a.slab_stride = numel;
+    a.n_lim = n_lim; a.c_lim = c_lim; a.sn = sn; a.st = st; a.sc = sc; a.slab_stride = numel; a.frag = frag;
     a.IMG = IMG; a.BR = BR; a.bands = (OH + BR - 1) / BR;
     a.n_units = ((B + IMG - 1) / IMG) * a.bands;
     a.PH = (BR - 1) * sh + (KH - 1) * dh + 1;

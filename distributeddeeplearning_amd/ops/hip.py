@@ -84,7 +84,9 @@ _wgrad_ksplit = _sig("ddl_wgrad_ksplit", ci, ci, ci, ci, ci)
 _wgrad = _sig("ddl_conv_wgrad", ci, vp, vp, vp, vp, cl, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci,
               ci, ci, ci, ci, cl, cl, cl, vp)
 _wgrad2 = _sig("ddl_conv_wgrad2", ci, vp, vp, vp, cl, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci,
-               cl, cl, cl, ci, ci, ci, ci, ci, ci, ci, ci, vp)
+               cl, cl, cl, ci, ci, ci, ci, ci, ci, ci, ci, ci, vp)
+_wgrad2_frag_elems = _sig("ddl_wgrad2_frag_elems", cl, ci, ci, ci, ci, ci, ci)
+_slab_reduce_frag = _sig("ddl_slab_reduce_frag", ci, vp, vp, ci, ci, ci, ci, ci, ci, ci, ci, cl, cl, cl, vp)
 _wgrad2_lds = _sig("ddl_wgrad2_lds", ci, ci, ci, ci, ci, ci, ci, ci, ci, ci)
 _slab_reduce = _sig("ddl_slab_reduce", None, vp, vp, cl, cl, ci, vp)
 _dw_blocks = _sig("ddl_dw_wgrad_blocks", ci, cl, ci)
@@ -1045,6 +1047,7 @@ def _tr_pitch(nbytes: int) -> int:
 
 
 W2_XPITCH_SKEW = os.environ.get("DDL_W2_XPITCH_SKEW", "1") == "1"
+W2_FRAG_SLAB = os.environ.get("DDL_W2_FRAG_SLAB", "1") == "1"
 
 
 def _tr_pitch_x(nbytes: int, sw: int) -> int:
@@ -1175,13 +1178,28 @@ def conv_wgrad(x, dy, g: ConvGeom, layout="A", out=None, box=None):
 
     def run_w2(pl):
         ns = pl["nsplit"]
-        slab = (torch.zeros if box is not None else torch.empty)(ns * numel, dtype=torch.float32, device=dev)
+        if W2_FRAG_SLAB:
+            # slabs in the kernel's fragment order (fully coalesced stores); the reduce scatters the final gradient
+            # and writes the box only, so whatever lies outside a custom box is zeroed here
+            per = _wgrad2_frag_elems(pl["TN"], pl["TC"], pl["TPW"], pl["ngroups"], n_lim, c_lim)
+            slab = torch.empty(ns * per, dtype=torch.float32, device=dev)
+            if box is not None:
+                out.zero_()
+        else:
+            slab = (torch.zeros if box is not None else torch.empty)(ns * numel, dtype=torch.float32, device=dev)
         rc = _wgrad2(dy.data_ptr(), x.data_ptr(), slab.data_ptr(), numel, ns, B, g.OH, g.OW, Op, g.H, g.W, Ip,
                      g.KH, g.KW, g.sh, g.sw, g.dh, g.dw, g.pt, g.pl, n_lim, c_lim, sn, st, sc, pl["IMG"], pl["BR"],
-                     pl["xp"], pl["yp"], pl["TN"], pl["TC"], pl["TPW"], pl["ngroups"], _stream())
+                     pl["xp"], pl["yp"], pl["TN"], pl["TC"], pl["TPW"], pl["ngroups"], 1 if W2_FRAG_SLAB else 0,
+                     _stream())
         if rc:
             raise ValueError(f"conv_wgrad2 rejected its plan (rc={rc}): {g} {pl}")
-        _slab_reduce(slab.data_ptr(), out.data_ptr(), numel, numel, ns, _stream())
+        if W2_FRAG_SLAB:
+            rc = _slab_reduce_frag(slab.data_ptr(), out.data_ptr(), ns, pl["TN"], pl["TC"], pl["TPW"], pl["ngroups"],
+                                   T, n_lim, c_lim, sn, st, sc, _stream())
+            if rc:
+                raise ValueError(f"slab_reduce_frag rejected its arguments (rc={rc})")
+        else:
+            _slab_reduce(slab.data_ptr(), out.data_ptr(), numel, numel, ns, _stream())
 
     def run_w1():
         M = B * g.OH * g.OW
