@@ -44,8 +44,8 @@ __device__ __forceinline__ s16x4 tr_read2(const char* p) {
 template <int TN, int TC, int TPW>
 __global__ __launch_bounds__(256, (TPW * (TN / 16) * (TC / 16) * 4 > 160 ? 1 : 2)) void wgrad2_kernel(const Wg2Args a) {
     constexpr int SN = TN / 16, SC = TC / 16;
-    // the one-block-per-CU variants (512-register budget) whose fragment sets leave room: they prefetch the next
-    // slice's fragments and stage with deeper rounds
+    // the one-block-per-CU variants (512-register budget) whose fragment sets leave room: they stage with deeper
+    // rounds and keep the next unit's first round in flight during the MFMA phase
     constexpr bool PIPE = TPW * SN * SC * 4 > 160 && (SN + TPW * SC) * 8 <= 160;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* sX = smem;
@@ -107,132 +107,138 @@ __global__ __launch_bounds__(256, (TPW * (TN / 16) * (TC / 16) * 4 > 160 ? 1 : 2
         (void*)a.dy, 0, (int)((unsigned)a.B * a.OH * a.OW * a.Ny * 2u), 0x00020000);
     constexpr unsigned OOB_OFF = 0xFFFFFFF0u;
 
-    for (int unit = blockIdx.x; unit < a.n_units; unit += gridDim.x) {
+    // ---- staging: the X patch (zero halo / missing images) and the dY tile (pixel m = (img, il, jl) of the band;
+    // rows past the band / batch are zero) of a unit.  The kernel is bound by this phase, so it runs as one stream
+    // of rounds of NLD 16-byte loads per thread -- X rounds, then dY rounds -- with the loads of round r+1 issued
+    // before the LDS stores of round r (no drain between X and dY), and in the one-block-per-CU variants the first
+    // round of the NEXT unit is issued before the MFMA phase of the current one and waits in registers.
+    const int per_img = a.PH * a.PW * cx8;
+    const int nx = a.IMG * per_img;
+    const int nyu = (a.Mmax + 31) / 32 * 32 * ny8;
+    constexpr int NLD = PIPE ? 6 : 4, RND = 256 * NLD;       // loads per thread per round, units per round
+    const int rx = (nx + RND - 1) / RND, R = rx + (nyu + RND - 1) / RND;
+    auto issue = [&](int unit, int r, u32x4_t (&v)[NLD], int (&dst)[NLD]) {
         const int grp = unit / a.bands, band = unit - grp * a.bands;
         const int b0 = grp * a.IMG, i0 = band * a.BR;
-        const int nrow = min(a.BR, a.OH - i0);
-        __syncthreads();                          // previous unit fully consumed (also orders the tables)
-        // ---- stage the X patch (zero halo / missing images) and the dY tile (pixel m = (img, il, jl) of the band;
-        // rows past the band / batch are zero).  The kernel is bound by this phase, so it runs as one stream of
-        // rounds of NLD 16-byte loads per thread -- X rounds, then dY rounds -- with the loads of round r+1
-        // issued before the LDS stores of round r: 2 * NLD loads per thread in flight, no drain between X and dY.
-        {
+        if (r < rx) {                                  // block-uniform
             const int row0 = i0 * a.sh - a.pt, col0 = -a.pl;
-            const int per_img = a.PH * a.PW * cx8;
-            const int nx = a.IMG * per_img;
-            const int mpad = (a.Mmax + 31) / 32 * 32;
-            const int nyu = mpad * ny8;
-            constexpr int NLD = PIPE ? 6 : 4, RND = 256 * NLD;       // loads per thread per round, units per round
-            const int rx = (nx + RND - 1) / RND, R = rx + (nyu + RND - 1) / RND;
-            auto issue = [&](int r, u32x4_t (&v)[NLD], int (&dst)[NLD]) {
-                if (r < rx) {                                  // block-uniform
-                    const int base = tid + r * RND;
+            const int base = tid + r * RND;
 #pragma unroll
-                    for (int k = 0; k < NLD; ++k) {
-                        int u = base + k * 256;
-                        bool in = u < nx;
-                        int uu = in ? u : 0;
-                        int img = fdiv2(uu, a.inv_xper_img), rr = uu - img * per_img;
-                        int pix = fdiv2(rr, a.inv_cx8), c8 = rr - pix * cx8;
-                        int pr = fdiv2(pix, a.inv_PW), pc = pix - pr * a.PW;
-                        int sr = row0 + pr, sc = col0 + pc, bb = b0 + img;
-                        const bool ok = in & (bb < a.B) & ((unsigned)sr < (unsigned)a.H) & ((unsigned)sc < (unsigned)a.W) &
-                                        (c0 + c8 * 8 < a.Cx);
-                        const unsigned off = ok ? (unsigned)(((bb * a.H + sr) * a.W + sc) * a.Cx + c0 + c8 * 8) * 2u : OOB_OFF;
-                        v[k] = __builtin_amdgcn_raw_buffer_load_b128(rsX, off, 0, 0);
-                        dst[k] = in ? img * a.ximg_bytes + pix * a.xpitch + c8 * 16 : -1;
-                    }
-                } else {
-                    const int base = tid + (r - rx) * RND;
+            for (int k = 0; k < NLD; ++k) {
+                int u = base + k * 256;
+                bool in = u < nx;
+                int uu = in ? u : 0;
+                int img = fdiv2(uu, a.inv_xper_img), rr = uu - img * per_img;
+                int pix = fdiv2(rr, a.inv_cx8), c8 = rr - pix * cx8;
+                int pr = fdiv2(pix, a.inv_PW), pc = pix - pr * a.PW;
+                int sr = row0 + pr, sc = col0 + pc, bb = b0 + img;
+                const bool ok = in & (bb < a.B) & ((unsigned)sr < (unsigned)a.H) & ((unsigned)sc < (unsigned)a.W) &
+                                (c0 + c8 * 8 < a.Cx);
+                const unsigned off = ok ? (unsigned)(((bb * a.H + sr) * a.W + sc) * a.Cx + c0 + c8 * 8) * 2u : OOB_OFF;
+                v[k] = __builtin_amdgcn_raw_buffer_load_b128(rsX, off, 0, 0);
+                dst[k] = in ? img * a.ximg_bytes + pix * a.xpitch + c8 * 16 : -1;
+            }
+        } else {
+            const int nrow = min(a.BR, a.OH - i0);
+            const int base = tid + (r - rx) * RND;
 #pragma unroll
-                    for (int k = 0; k < NLD; ++k) {
-                        int u = base + k * 256;
-                        bool in = u < nyu;
-                        int uu = in ? u : 0;
-                        int m = fdiv2(uu, a.inv_yrow), c8 = uu - m * ny8;
-                        int img = fdiv2(m, a.inv_rows), rem = m - img * (a.BR * a.OW);
-                        int il = fdiv2(rem, a.inv_OW), jl = rem - il * a.OW;
-                        int bb = b0 + img;
-                        const bool ok = in & (m < a.Mmax) & (bb < a.B) & (il < nrow) & (n0 + c8 * 8 < a.Ny);
-                        const unsigned off = ok ? (unsigned)(((bb * a.OH + i0 + il) * a.OW + jl) * a.Ny + n0 + c8 * 8) * 2u : OOB_OFF;
-                        v[k] = __builtin_amdgcn_raw_buffer_load_b128(rsY, off, 0, 0);
-                        dst[k] = in ? a.y_off + m * a.ypitch + c8 * 16 : -1;
-                    }
-                }
-            };
-            auto store = [&](const u32x4_t (&v)[NLD], const int (&dst)[NLD]) {
+            for (int k = 0; k < NLD; ++k) {
+                int u = base + k * 256;
+                bool in = u < nyu;
+                int uu = in ? u : 0;
+                int m = fdiv2(uu, a.inv_yrow), c8 = uu - m * ny8;
+                int img = fdiv2(m, a.inv_rows), rem = m - img * (a.BR * a.OW);
+                int il = fdiv2(rem, a.inv_OW), jl = rem - il * a.OW;
+                int bb = b0 + img;
+                const bool ok = in & (m < a.Mmax) & (bb < a.B) & (il < nrow) & (n0 + c8 * 8 < a.Ny);
+                const unsigned off = ok ? (unsigned)(((bb * a.OH + i0 + il) * a.OW + jl) * a.Ny + n0 + c8 * 8) * 2u : OOB_OFF;
+                v[k] = __builtin_amdgcn_raw_buffer_load_b128(rsY, off, 0, 0);
+                dst[k] = in ? a.y_off + m * a.ypitch + c8 * 16 : -1;
+            }
+        }
+    };
+    auto store = [&](const u32x4_t (&v)[NLD], const int (&dst)[NLD]) {
 #pragma unroll
-                for (int k = 0; k < NLD; ++k)
-                    if (dst[k] >= 0) *(u32x4_t*)(smem + dst[k]) = v[k];
-            };
+        for (int k = 0; k < NLD; ++k)
+            if (dst[k] >= 0) *(u32x4_t*)(smem + dst[k]) = v[k];
+    };
+    // ---- every wave walks all 32-pixel slices; its taps' accumulators stay in registers.  All of a
+    // slice's fragments are fetched first (one burst of transposing LDS reads), then the MFMAs run.
+    auto load = [&](int m0, bf16x8_t (&fy)[SN], bf16x8_t (&fx)[TPW][SC]) {
+        const int plo = m0 + 4 * g + tq, phi = plo + 16;
+        const int xlo = sTbl[plo < a.Mmax ? plo : 0], xhi = sTbl[phi < a.Mmax ? phi : 0];
+#pragma unroll
+        for (int i = 0; i < SN; ++i) {
+            s16x4 lo = tr_read2(sY + plo * a.ypitch + chan_y + i * 32);
+            s16x4 hi = tr_read2(sY + phi * a.ypitch + chan_y + i * 32);
+            s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            fy[i] = __builtin_bit_cast(bf16x8_t, v);
+        }
+#pragma unroll
+        for (int q = 0; q < TPW; ++q)
+#pragma unroll
+            for (int j = 0; j < SC; ++j) {
+                s16x4 lo = tr_read2(sX + xlo + toff[q] + j * 32);
+                s16x4 hi = tr_read2(sX + xhi + toff[q] + j * 32);
+                s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                fx[q][j] = __builtin_bit_cast(bf16x8_t, v);
+            }
+    };
+    // Unconditional MFMAs: a tap slot this wave does not own aliases tap 0 and accumulates values that are
+    // never written.  (Guarding them by `q < ntaps_w` makes the compiler shuffle the accumulator file
+    // through v_accvgpr moves at every slice.)
+    auto mma = [&](const bf16x8_t (&fy)[SN], const bf16x8_t (&fx)[TPW][SC]) {
+#pragma unroll
+        for (int q = 0; q < TPW; ++q)
+#pragma unroll
+            for (int i = 0; i < SN; ++i)
+#pragma unroll
+                for (int j = 0; j < SC; ++j)
+                    acc[q][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fy[i], fx[q][j], acc[q][i][j], 0, 0, 0);
+    };
+
+    u32x4_t vP[PIPE ? NLD : 1];                    // PIPE: round 0 of the unit about to be staged
+    int dP[PIPE ? NLD : 1];
+    if constexpr (PIPE) {
+        if (blockIdx.x < a.n_units) issue(blockIdx.x, 0, vP, dP);
+    }
+    for (int unit = blockIdx.x; unit < a.n_units; unit += gridDim.x) {
+        __syncthreads();                          // previous unit fully consumed (also orders the tables)
+        {
             u32x4_t vA[NLD], vB[NLD];
             int dA[NLD], dB[NLD];
-            issue(0, vA, dA);
-            for (int r = 0; r < R; r += 2) {
-                if (r + 1 < R) issue(r + 1, vB, dB);
-                store(vA, dA);
-                if (r + 1 < R) {
-                    if (r + 2 < R) issue(r + 2, vA, dA);
+            if constexpr (PIPE) {
+                if (R > 1) issue(unit, 1, vB, dB);
+                store(vP, dP);
+                for (int r = 1; r < R; r += 2) {      // vB holds round r
+                    if (r + 1 < R) issue(unit, r + 1, vA, dA);
                     store(vB, dB);
+                    if (r + 1 < R) {
+                        if (r + 2 < R) issue(unit, r + 2, vB, dB);
+                        store(vA, dA);
+                    }
+                }
+            } else {
+                issue(unit, 0, vA, dA);
+                for (int r = 0; r < R; r += 2) {
+                    if (r + 1 < R) issue(unit, r + 1, vB, dB);
+                    store(vA, dA);
+                    if (r + 1 < R) {
+                        if (r + 2 < R) issue(unit, r + 2, vA, dA);
+                        store(vB, dB);
+                    }
                 }
             }
         }
         __syncthreads();
-
-        // ---- every wave walks all 32-pixel slices; its taps' accumulators stay in registers.  All of a
-        // slice's fragments are fetched first (one burst of transposing LDS reads), then the MFMAs run.
-        auto load = [&](int m0, bf16x8_t (&fy)[SN], bf16x8_t (&fx)[TPW][SC]) {
-            const int plo = m0 + 4 * g + tq, phi = plo + 16;
-            const int xlo = sTbl[plo < a.Mmax ? plo : 0], xhi = sTbl[phi < a.Mmax ? phi : 0];
-#pragma unroll
-            for (int i = 0; i < SN; ++i) {
-                s16x4 lo = tr_read2(sY + plo * a.ypitch + chan_y + i * 32);
-                s16x4 hi = tr_read2(sY + phi * a.ypitch + chan_y + i * 32);
-                s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-                fy[i] = __builtin_bit_cast(bf16x8_t, v);
-            }
-#pragma unroll
-            for (int q = 0; q < TPW; ++q)
-#pragma unroll
-                for (int j = 0; j < SC; ++j) {
-                    s16x4 lo = tr_read2(sX + xlo + toff[q] + j * 32);
-                    s16x4 hi = tr_read2(sX + xhi + toff[q] + j * 32);
-                    s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-                    fx[q][j] = __builtin_bit_cast(bf16x8_t, v);
-                }
-        };
-        // Unconditional MFMAs: a tap slot this wave does not own aliases tap 0 and accumulates values that are
-        // never written.  (Guarding them by `q < ntaps_w` makes the compiler shuffle the accumulator file
-        // through v_accvgpr moves at every slice.)
-        auto mma = [&](const bf16x8_t (&fy)[SN], const bf16x8_t (&fx)[TPW][SC]) {
-#pragma unroll
-            for (int q = 0; q < TPW; ++q)
-#pragma unroll
-                for (int i = 0; i < SN; ++i)
-#pragma unroll
-                    for (int j = 0; j < SC; ++j)
-                        acc[q][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fy[i], fx[q][j], acc[q][i][j], 0, 0, 0);
-        };
         if constexpr (PIPE) {
-            // one block (one wave per SIMD) per CU: nothing else hides the LDS latency, so the next slice's
-            // fragments are requested before the current slice's MFMAs (two register sets, 512-VGPR budget)
-            bf16x8_t fyA[SN], fxA[TPW][SC], fyB[SN], fxB[TPW][SC];
-            load(0, fyA, fxA);
-            for (int m0 = 0; m0 < a.Mmax; m0 += 64) {
-                const bool n1 = m0 + 32 < a.Mmax;          // block-uniform
-                if (n1) load(m0 + 32, fyB, fxB);
-                mma(fyA, fxA);
-                if (n1) {
-                    if (m0 + 64 < a.Mmax) load(m0 + 64, fyA, fxA);
-                    mma(fyB, fxB);
-                }
-            }
-        } else {
-            for (int m0 = 0; m0 < a.Mmax; m0 += 32) {
-                bf16x8_t fy[SN], fx[TPW][SC];
-                load(m0, fy, fx);
-                mma(fy, fx);
-            }
+            const int next = unit + gridDim.x;
+            if (next < a.n_units) issue(next, 0, vP, dP);          // in flight during the MFMA phase
+        }
+        for (int m0 = 0; m0 < a.Mmax; m0 += 32) {
+            bf16x8_t fy[SN], fx[TPW][SC];
+            load(m0, fy, fx);
+            mma(fy, fx);
         }
     }
 
