@@ -152,6 +152,30 @@ def test_depthwise(hip, case):
     close(dw[..., :Cc], cpu_ref.conv_wgrad(x, dy, g), rtol=1e-2)
 
 
+@pytest.mark.parametrize("case", [(14, 14, 64, 128, 5, 2), (9, 11, 24, 40, 3, 1)])
+@pytest.mark.parametrize("layout", ["A", "B"])
+def test_wgrad2_slab_orders_agree(hip, case, layout, monkeypatch):
+    """wgrad2's split-K slabs in fragment order (default) and in the gradient's own layout are summed over the
+    splits in the same order: the two paths must agree bit for bit (and with the fp32 oracle to tolerance)."""
+    H, W, I, O, k, s = case
+    g = G.conv2d_geom(H, W, I, O, (k, k), (s, s), (1, 1), "same")
+    B = 96
+    torch.manual_seed(11)
+    x = r16(torch.randn(B, H, W, I))
+    dy = r16(torch.randn(B, g.OH, g.OW, O))
+    xd, dyd = dev(hip, x), dev(hip, dy)
+    monkeypatch.setattr(hip, "WGRAD_IMPL", "wgrad2")
+    monkeypatch.setattr(hip, "AUTOTUNE", False)          # heuristic plan 0 on both calls
+    monkeypatch.setattr(hip, "W2_FRAG_SLAB", True)
+    a = hip.conv_wgrad(xd, dyd, g, layout).cpu()
+    monkeypatch.setattr(hip, "W2_FRAG_SLAB", False)
+    b = hip.conv_wgrad(xd, dyd, g, layout).cpu()
+    assert torch.equal(a, b)
+    ref = cpu_ref.conv_wgrad(x, dy, g)
+    if layout == "A":
+        close(a[..., :I], ref, rtol=1e-2)
+
+
 def test_dense_large_k(hip):
     g = G.dense_geom(86528, 10)           # model0 dense_1
     B = 32
