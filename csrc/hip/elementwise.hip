@@ -151,6 +151,39 @@ __global__ __launch_bounds__(EW_BLOCK) void colreduce_kernel(
             accum(ua, ub, uy);
         }
     }
+    if (cgl <= 64 && (cgl & (cgl - 1)) == 0) {
+        // Lanes l, l + cgl, l + 2 cgl, ... of a wave hold different rows of the same channel group: fold them with
+        // shuffles, then the four waves through LDS, and let every thread combine and store one (group, sum, channel)
+        // element.  (The generic path below -- 40 LDS stores per thread, a barrier per tree level, 8 threads doing
+        // all the scattered partial stores -- was 10-25 % of these 15-30 us kernels.)
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        for (int off = cgl; off < 64; off <<= 1) {
+#pragma unroll
+            for (int k = 0; k < NS; ++k)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) s[k][j] += __shfl_xor(s[k][j], off, 64);
+        }
+        float* fr = &red[0][0];                                   // [4 waves][cgl][NS * 8]
+        if (lane < cgl) {
+#pragma unroll
+            for (int k = 0; k < NS; ++k)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) fr[(wave * cgl + lane) * (NS * 8) + k * 8 + j] = s[k][j];
+        }
+        __syncthreads();
+        const size_t nb = gridDim.x;
+        for (int t = threadIdx.x; t < cgl * NS * 8; t += EW_BLOCK) {
+            const int gl = t / (NS * 8), e = t - gl * (NS * 8);
+            const int gg = blockIdx.y * EW_BLOCK + gl;
+            if (gg >= cg) continue;
+            float v = fr[t];
+#pragma unroll
+            for (int w = 1; w < 4; ++w) v += fr[w * cgl * (NS * 8) + t];
+            const int k = e >> 3, j = e & 7;
+            part[((size_t)k * C + gg * 8 + j) * nb + blockIdx.x] = v;
+        }
+        return;
+    }
 #pragma unroll
     for (int k = 0; k < NS; ++k)
 #pragma unroll
