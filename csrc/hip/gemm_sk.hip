@@ -111,9 +111,12 @@ __global__ __launch_bounds__(256) void gemm_sk_kernel(const GemmSkArgs a) {
             for (int t = 0; t < NT; ++t)
                 *(uint2*)(sE + fr * EROW + (16 * t + 4 * fq) * 2) =
                     make_uint2(pack2bf(acc[t][j][0], acc[t][j][1]), pack2bf(acc[t][j][2], acc[t][j][3]));
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            // The scratch is private to this wave and a wave's LDS operations execute in order, so ordering the
+            // compiler (wavefront-scope fences) is all the transpose needs.  Workgroup-scope fences also drain the
+            // global stores of the previous fragment (vmcnt(0)) and serialised the store latency per fragment.
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 #pragma unroll
             for (int u = lane; u < 16 * (BN / 8); u += 64) {
                 int px = u / (BN / 8), c8 = u - px * (BN / 8);
@@ -121,9 +124,9 @@ __global__ __launch_bounds__(256) void gemm_sk_kernel(const GemmSkArgs a) {
                 if (m < a.M && n0 + c8 * 8 < a.Nd)
                     *(uint4*)(a.y + m * a.Nd + n0 + c8 * 8) = *(const uint4*)(sE + px * EROW + c8 * 16);
             }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         }
     }
 }

@@ -253,6 +253,10 @@ __global__ __launch_bounds__(256, (BN * FR >= 512 ? 1 : 2)) void pconv_kernel(co
                 __syncthreads();
             }
 
+            // The weight pipeline's last loads (past the final stage: zeros, never stored) are still in flight.  Drain
+            // them here, where they are old, so the compiler does not have to protect their destination registers
+            // with a vmcnt(0) in the middle of the epilogue -- that wait would also drain the fragment stores.
+            __builtin_amdgcn_s_waitcnt(0x0F70);         // vmcnt(0) only
             // ---- epilogue.  A lane holds channels 16t + 4fq .. +3 of pixel 16j + fr; written directly
             // that is 8-byte stores in 32-byte runs.  Each 16-pixel fragment is instead transposed
             // through a per-wave LDS scratch and leaves as 16-byte stores covering every pixel's whole
@@ -333,9 +337,12 @@ __global__ __launch_bounds__(256, (BN * FR >= 512 ? 1 : 2)) void pconv_kernel(co
                             }
                         }
                     }
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                    // The scratch is private to this wave and a wave's LDS operations execute in order, so ordering the
+                    // compiler (wavefront-scope fences) is all the transpose needs.  Workgroup-scope fences also drain the
+                    // global stores of the previous fragment (vmcnt(0)) and serialised the store latency per fragment.
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                     __builtin_amdgcn_wave_barrier();
-                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 #pragma unroll
                     for (int u = lane; u < 16 * (BN / 8); u += 64) {
                         int px = u / (BN / 8), c8 = u - px * (BN / 8);
@@ -344,9 +351,9 @@ __global__ __launch_bounds__(256, (BN * FR >= 512 ? 1 : 2)) void pconv_kernel(co
                         if (p >= 0 && n < a.Nd)
                             *(uint4*)(a.dst + (long)p * a.Nd + n) = *(const uint4*)(sE + px * EROW + c8 * 16);
                     }
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                     __builtin_amdgcn_wave_barrier();
-                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
                 }
             }
         }
