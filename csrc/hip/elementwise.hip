@@ -361,6 +361,11 @@ __global__ __launch_bounds__(256) void bn_stats_finalize_wide_kernel(
     }
 }
 
+DDL_API void ddl_bn_stats_from_part(const float* part, int nblocks, long rows, int C, const float* gamma,
+                                    const float* beta, float* mm, float* mv, float momentum, float eps, int bessel,
+                                    int update_moving, float* scale, float* shift, float* mean, float* invstd,
+                                    hipStream_t s);
+
 DDL_API void ddl_bn_batch_stats(const void* x, long rows, int C, float* part, const float* gamma,
                                 const float* beta, float* mm, float* mv, float momentum, float eps, int bessel,
                                 int update_moving, float* scale, float* shift, float* mean, float* invstd,
@@ -369,9 +374,8 @@ DDL_API void ddl_bn_batch_stats(const void* x, long rows, int C, float* part, co
     colreduce_grid(rows, C, &grid);
     colreduce_kernel<0><<<grid, EW_BLOCK, 0, s>>>((const uint4*)x, nullptr, nullptr, nullptr, nullptr, part,
                                                   rows, C, 0, 0.f, 0, 0.f);
-    bn_stats_finalize_kernel<<<FIN_GRID(C), FIN_BLOCK, 0, s>>>(part, grid.x, C, rows, gamma, beta, mm, mv,
-                                                             momentum, eps, bessel, update_moving, scale,
-                                                             shift, mean, invstd);
+    ddl_bn_stats_from_part(part, (int)grid.x, rows, C, gamma, beta, mm, mv, momentum, eps, bessel, update_moving, scale,
+                           shift, mean, invstd, s);
 }
 
 // Batch statistics from partials a producer kernel already wrote (pconv's STATS epilogue): finalize only.
@@ -379,7 +383,10 @@ DDL_API void ddl_bn_stats_from_part(const float* part, int nblocks, long rows, i
                                     const float* beta, float* mm, float* mv, float momentum, float eps, int bessel,
                                     int update_moving, float* scale, float* shift, float* mean, float* invstd,
                                     hipStream_t s) {
-    if (nblocks > 1024)
+    // one block per channel once a 32-lane walk would take more than two trips of four loads: the narrow
+    // kernel's time is its number of dependent round trips (8 of them for 1000 partials)
+    static const int wide_min = getenv("DDL_FIN_WIDE_MIN") ? atoi(getenv("DDL_FIN_WIDE_MIN")) : 256;
+    if (nblocks > wide_min)
         bn_stats_finalize_wide_kernel<<<C, 256, 0, s>>>(part, nblocks, C, rows, gamma, beta, mm, mv, momentum, eps,
                                                         bessel, update_moving, scale, shift, mean, invstd);
     else
