@@ -268,6 +268,11 @@ __device__ __forceinline__ void reduce_partials(const float* __restrict__ part, 
 #define FIN_CHANNEL() (blockIdx.x * FIN_CH + (threadIdx.x >> 5))
 #define FIN_LEADER() ((threadIdx.x & 31) == 0)
 #define FIN_GRID(C) (((C) + FIN_CH - 1) / FIN_CH)
+// partial rows per channel above which the finalize kernels run one block per channel (DDL_FIN_WIDE_MIN)
+static int fin_wide_min() {
+    static const int v = getenv("DDL_FIN_WIDE_MIN") ? atoi(getenv("DDL_FIN_WIDE_MIN")) : 256;
+    return v;
+}
 
 static inline void colreduce_grid(long rows, int C, dim3* grid) {
     int cg = C / 8;
@@ -385,8 +390,7 @@ DDL_API void ddl_bn_stats_from_part(const float* part, int nblocks, long rows, i
                                     hipStream_t s) {
     // one block per channel once a 32-lane walk would take more than two trips of four loads: the narrow
     // kernel's time is its number of dependent round trips (8 of them for 1000 partials)
-    static const int wide_min = getenv("DDL_FIN_WIDE_MIN") ? atoi(getenv("DDL_FIN_WIDE_MIN")) : 256;
-    if (nblocks > wide_min)
+    if (nblocks > fin_wide_min())
         bn_stats_finalize_wide_kernel<<<C, 256, 0, s>>>(part, nblocks, C, rows, gamma, beta, mm, mv, momentum, eps,
                                                         bessel, update_moving, scale, shift, mean, invstd);
     else
@@ -506,15 +510,11 @@ DDL_API void ddl_bn_apply_infer(const void* x, void* y, const float* gamma, cons
 
 // BN backward: reduce -> finalize (dgamma, dbeta, c1 = dbeta/M, c2 = dgamma/M) -> apply.
 template <int NS>
-__global__ void bn_bwd_finalize_kernel(const float* __restrict__ part, int nblocks, int C, long rows,
-                                       int train_stats, float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                       float* __restrict__ c1, float* __restrict__ c2,
-                                       const float* __restrict__ mean, const float* __restrict__ invstd,
-                                       const float* __restrict__ gamma, float* __restrict__ dbias, int c_bias) {
-    int c = FIN_CHANNEL();
-    double o[NS];
-    reduce_partials_n<NS, NS>(part, nblocks, C, c, o);
-    if (c >= C || !FIN_LEADER()) return;
+__device__ __forceinline__ void bn_bwd_emit(int c, const double (&o)[NS], long rows, int train_stats,
+                                            float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                            float* __restrict__ c1, float* __restrict__ c2,
+                                            const float* __restrict__ mean, const float* __restrict__ invstd,
+                                            const float* __restrict__ gamma, float* __restrict__ dbias, int c_bias) {
     if (dbeta) dbeta[c] = (float)o[0];
     if (dgamma) dgamma[c] = (float)o[1];
     const float f1 = train_stats ? (float)(o[0] / (double)rows) : 0.f;
@@ -526,6 +526,65 @@ __global__ void bn_bwd_finalize_kernel(const float* __restrict__ part, int nbloc
         const double is = invstd[c], gi = (double)gamma[c] * is;
         const double k0 = gi, k1 = -gi * is * (double)f2, k2 = -gi * ((double)f1 - (double)mean[c] * is * (double)f2);
         dbias[c] = (float)(k0 * o[NS - 3] + k1 * o[NS - 2] + k2 * o[NS - 1]);
+    }
+}
+
+template <int NS>
+__global__ void bn_bwd_finalize_kernel(const float* __restrict__ part, int nblocks, int C, long rows,
+                                       int train_stats, float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                       float* __restrict__ c1, float* __restrict__ c2,
+                                       const float* __restrict__ mean, const float* __restrict__ invstd,
+                                       const float* __restrict__ gamma, float* __restrict__ dbias, int c_bias) {
+    int c = FIN_CHANNEL();
+    double o[NS];
+    reduce_partials_n<NS, NS>(part, nblocks, C, c, o);
+    if (c >= C || !FIN_LEADER()) return;
+    bn_bwd_emit<NS>(c, o, rows, train_stats, dgamma, dbeta, c1, c2, mean, invstd, gamma, dbias, c_bias);
+}
+
+// More than a few hundred partials per channel: one block per channel, 256 lanes on the channel's contiguous
+// partial rows (the 32-lane walk above is a chain of dependent round trips), fixed-order fp64 tree.
+template <int NS>
+__global__ __launch_bounds__(256) void bn_bwd_finalize_wide_kernel(
+    const float* __restrict__ part, int nblocks, int C, long rows, int train_stats, float* __restrict__ dgamma,
+    float* __restrict__ dbeta, float* __restrict__ c1, float* __restrict__ c2, const float* __restrict__ mean,
+    const float* __restrict__ invstd, const float* __restrict__ gamma, float* __restrict__ dbias, int c_bias) {
+    __shared__ double red[NS][4];
+    const int c = blockIdx.x;
+    double acc[NS];
+#pragma unroll
+    for (int k = 0; k < NS; ++k) acc[k] = 0;
+    int b = threadIdx.x;
+    for (; b + 256 < nblocks; b += 512) {             // two partial rows per trip, NS sums each: 2 NS loads in flight
+        float u[2][NS];
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int k = 0; k < NS; ++k) u[h][k] = part[((size_t)k * C + c) * nblocks + b + 256 * h];
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int k = 0; k < NS; ++k) acc[k] += u[h][k];
+    }
+    for (; b < nblocks; b += 256) {
+#pragma unroll
+        for (int k = 0; k < NS; ++k) acc[k] += part[((size_t)k * C + c) * nblocks + b];
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+#pragma unroll
+        for (int k = 0; k < NS; ++k) acc[k] += __shfl_down(acc[k], o, 64);
+    }
+    if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+        for (int k = 0; k < NS; ++k) red[k][threadIdx.x >> 6] = acc[k];
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double o[NS];
+#pragma unroll
+        for (int k = 0; k < NS; ++k) o[k] = ((red[k][0] + red[k][1]) + red[k][2]) + red[k][3];
+        bn_bwd_emit<NS>(c, o, rows, train_stats, dgamma, dbeta, c1, c2, mean, invstd, gamma, dbias, c_bias);
     }
 }
 
@@ -605,15 +664,23 @@ DDL_API void ddl_bn_bwd(const void* dy, const void* x, const void* y, void* dx, 
     if (dbias) {
         colreduce_kernel<3><<<grid, EW_BLOCK, 0, s>>>((const uint4*)dy, (const uint4*)x, (const uint4*)y, mean,
                                                       invstd, part, rows, C, act, alpha, prev_act, prev_alpha);
-        bn_bwd_finalize_kernel<5><<<FIN_GRID(C), FIN_BLOCK, 0, s>>>(part, grid.x, C, rows, train_stats, dgamma,
-                                                                  dbeta, c1, c2, mean, invstd, gamma, dbias,
-                                                                  c_bias);
+        if ((int)grid.x > fin_wide_min())
+            bn_bwd_finalize_wide_kernel<5><<<C, 256, 0, s>>>(part, grid.x, C, rows, train_stats, dgamma, dbeta, c1, c2,
+                                                              mean, invstd, gamma, dbias, c_bias);
+        else
+            bn_bwd_finalize_kernel<5><<<FIN_GRID(C), FIN_BLOCK, 0, s>>>(part, grid.x, C, rows, train_stats, dgamma,
+                                                                      dbeta, c1, c2, mean, invstd, gamma, dbias,
+                                                                      c_bias);
     } else {
         colreduce_kernel<1><<<grid, EW_BLOCK, 0, s>>>((const uint4*)dy, (const uint4*)x, (const uint4*)y, mean,
                                                       invstd, part, rows, C, act, alpha, 0, 0.f);
-        bn_bwd_finalize_kernel<2><<<FIN_GRID(C), FIN_BLOCK, 0, s>>>(part, grid.x, C, rows, train_stats, dgamma,
-                                                                  dbeta, c1, c2, mean, invstd, gamma, nullptr,
-                                                                  0);
+        if ((int)grid.x > fin_wide_min())
+            bn_bwd_finalize_wide_kernel<2><<<C, 256, 0, s>>>(part, grid.x, C, rows, train_stats, dgamma, dbeta, c1, c2,
+                                                              mean, invstd, gamma, nullptr, 0);
+        else
+            bn_bwd_finalize_kernel<2><<<FIN_GRID(C), FIN_BLOCK, 0, s>>>(part, grid.x, C, rows, train_stats, dgamma,
+                                                                      dbeta, c1, c2, mean, invstd, gamma, nullptr,
+                                                                      0);
     }
     long n8 = rows * (C / 8);
     if (cs_ok(C / 8)) {
