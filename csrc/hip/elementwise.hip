@@ -76,7 +76,14 @@ __global__ __launch_bounds__(EW_BLOCK) void colreduce_kernel(
     long rows, int C, int act, float alpha, int prev_act, float prev_alpha) {
     constexpr int NS = CrSums<MODE>::N;
     __shared__ float red[EW_BLOCK][NS * 8 + 1];
+    // batch groups (blockIdx.z): `rows` rows each, statistics per group (a discriminator batch of
+    // [real ; fake] normalised half by half); partial index = z * gridDim.x + blockIdx.x
     const int cg = C / 8;
+    {
+        const size_t goff = (size_t)blockIdx.z * rows * cg;
+        a += goff;
+        if (MODE == 1 || MODE == 3) { b += goff; if (yv) yv += goff; mean += blockIdx.z * C; invstd += blockIdx.z * C; }
+    }
     const int cgl = cg < EW_BLOCK ? cg : EW_BLOCK;           // channel groups handled by this block column
     const int rpi = EW_BLOCK / cgl;                            // rows per block iteration
     const int g = blockIdx.y * EW_BLOCK + (threadIdx.x % cgl);
@@ -171,7 +178,8 @@ __global__ __launch_bounds__(EW_BLOCK) void colreduce_kernel(
                 for (int j = 0; j < 8; ++j) fr[(wave * cgl + lane) * (NS * 8) + k * 8 + j] = s[k][j];
         }
         __syncthreads();
-        const size_t nb = gridDim.x;
+        const size_t nb = (size_t)gridDim.x * gridDim.z;
+        const size_t bi = (size_t)blockIdx.z * gridDim.x + blockIdx.x;
         for (int t = threadIdx.x; t < cgl * NS * 8; t += EW_BLOCK) {
             const int gl = t / (NS * 8), e = t - gl * (NS * 8);
             const int gg = blockIdx.y * EW_BLOCK + gl;
@@ -180,7 +188,7 @@ __global__ __launch_bounds__(EW_BLOCK) void colreduce_kernel(
 #pragma unroll
             for (int w = 1; w < 4; ++w) v += fr[w * cgl * (NS * 8) + t];
             const int k = e >> 3, j = e & 7;
-            part[((size_t)k * C + gg * 8 + j) * nb + blockIdx.x] = v;
+            part[((size_t)k * C + gg * 8 + j) * nb + bi] = v;
         }
         return;
     }
@@ -202,8 +210,8 @@ __global__ __launch_bounds__(EW_BLOCK) void colreduce_kernel(
     if (rl == 0 && g < cg) {
         // part[k][c][block]: the block index is the fastest dimension, so the finalize kernel's lanes read
         // consecutive floats (with [block][k][c] every lane touched its own 64-byte line: 35 us for 1024 x 5 x 128)
-        float* p = part + blockIdx.x;
-        const size_t nb = gridDim.x;
+        float* p = part + (size_t)blockIdx.z * gridDim.x + blockIdx.x;
+        const size_t nb = (size_t)gridDim.x * gridDim.z;
 #pragma unroll
         for (int k = 0; k < NS; ++k)
 #pragma unroll
@@ -220,7 +228,10 @@ __global__ __launch_bounds__(EW_BLOCK) void colreduce_kernel(
 #define FIN_CH 8
 template <int NS, int NUSE>
 __device__ __forceinline__ void reduce_partials_n(const float* __restrict__ part, int nblocks, int C, int c,
-                                                  double (&out)[NUSE]) {
+                                                  double (&out)[NUSE], int nb_total = 0, int b0 = 0) {
+    // partial row of (k, c): part[(k * C + c) * nb_total + b0 + b], b < nblocks (one batch group's blocks)
+    if (nb_total == 0) nb_total = nblocks;
+    part += b0;
     const int pl = threadIdx.x & 31;
     double acc[NUSE];
 #pragma unroll
@@ -234,7 +245,7 @@ __device__ __forceinline__ void reduce_partials_n(const float* __restrict__ part
 #pragma unroll
             for (int u = 0; u < 4; ++u)
 #pragma unroll
-                for (int k = 0; k < NUSE; ++k) v[u][k] = part[((size_t)k * C + c) * nblocks + b + 32 * u];
+                for (int k = 0; k < NUSE; ++k) v[u][k] = part[((size_t)k * C + c) * nb_total + b + 32 * u];
 #pragma unroll
             for (int u = 0; u < 4; ++u)
 #pragma unroll
@@ -242,7 +253,7 @@ __device__ __forceinline__ void reduce_partials_n(const float* __restrict__ part
         }
         for (; b < nblocks; b += 32) {
 #pragma unroll
-            for (int k = 0; k < NUSE; ++k) acc[k] += part[((size_t)k * C + c) * nblocks + b];
+            for (int k = 0; k < NUSE; ++k) acc[k] += part[((size_t)k * C + c) * nb_total + b];
         }
     }
 #pragma unroll
@@ -254,14 +265,14 @@ __device__ __forceinline__ void reduce_partials_n(const float* __restrict__ part
     for (int k = 0; k < NUSE; ++k) out[k] = acc[k];
 }
 __device__ __forceinline__ void reduce_partials(const float* __restrict__ part, int nblocks, int C, int c,
-                                                bool two, double& s0, double& s1) {
+                                                bool two, double& s0, double& s1, int nb_total = 0, int b0 = 0) {
     if (two) {
         double o[2];
-        reduce_partials_n<2, 2>(part, nblocks, C, c, o);
+        reduce_partials_n<2, 2>(part, nblocks, C, c, o, nb_total, b0);
         s0 = o[0]; s1 = o[1];
     } else {
         double o[1];
-        reduce_partials_n<2, 1>(part, nblocks, C, c, o);
+        reduce_partials_n<2, 1>(part, nblocks, C, c, o, nb_total, b0);
         s0 = o[0]; s1 = 0;
     }
 }
@@ -324,13 +335,17 @@ __global__ void bn_stats_finalize_kernel(const float* __restrict__ part, int nbl
                                          float* __restrict__ mm, float* __restrict__ mv, float momentum,
                                          float eps, int bessel, int update_moving, float* __restrict__ scale,
                                          float* __restrict__ shift, float* __restrict__ mean_out,
-                                         float* __restrict__ invstd_out) {
+                                         float* __restrict__ invstd_out, int groups) {
+    // `nblocks` partials and `rows` rows PER batch group; outputs are [groups][C]; the moving statistics take one
+    // momentum update per group, in group order (as calling the layer once per half would)
     int c = FIN_CHANNEL();
-    double s0, s1;
-    reduce_partials(part, nblocks, C, c, true, s0, s1);
-    if (c >= C || !FIN_LEADER()) return;
-    bn_stats_emit(c, s0, s1, rows, gamma, beta, mm, mv, momentum, eps, bessel, update_moving, scale, shift, mean_out,
-                  invstd_out);
+    for (int z = 0; z < groups; ++z) {
+        double s0, s1;
+        reduce_partials(part, nblocks, C, c, true, s0, s1, nblocks * groups, z * nblocks);
+        if (c < C && FIN_LEADER())
+            bn_stats_emit(c, s0, s1, rows, gamma, beta, mm, mv, momentum, eps, bessel, update_moving, scale + z * C,
+                          shift + z * C, mean_out + z * C, invstd_out + z * C);
+    }
 }
 
 // Many partials per channel (a producer kernel with thousands of blocks): one block per channel, 256 lanes walk
@@ -339,64 +354,70 @@ __global__ __launch_bounds__(256) void bn_stats_finalize_wide_kernel(
     const float* __restrict__ part, int nblocks, int C, long rows, const float* __restrict__ gamma,
     const float* __restrict__ beta, float* __restrict__ mm, float* __restrict__ mv, float momentum, float eps,
     int bessel, int update_moving, float* __restrict__ scale, float* __restrict__ shift,
-    float* __restrict__ mean_out, float* __restrict__ invstd_out) {
+    float* __restrict__ mean_out, float* __restrict__ invstd_out, int groups) {
     __shared__ double red[2][4];
     const int c = blockIdx.x;
-    const float* p0 = part + (size_t)c * nblocks;
-    const float* p1 = part + ((size_t)C + c) * nblocks;
-    double a0 = 0, a1 = 0;
-    int b = threadIdx.x;
-    for (; b + 768 < nblocks; b += 1024) {
-        float u[4], v[4];
+    const size_t nbt = (size_t)nblocks * groups;
+    for (int z = 0; z < groups; ++z) {
+        const float* p0 = part + (size_t)c * nbt + (size_t)z * nblocks;
+        const float* p1 = part + ((size_t)C + c) * nbt + (size_t)z * nblocks;
+        double a0 = 0, a1 = 0;
+        int b = threadIdx.x;
+        for (; b + 768 < nblocks; b += 1024) {
+            float u[4], v[4];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) { u[k] = p0[b + 256 * k]; v[k] = p1[b + 256 * k]; }
+            for (int k = 0; k < 4; ++k) { u[k] = p0[b + 256 * k]; v[k] = p1[b + 256 * k]; }
 #pragma unroll
-        for (int k = 0; k < 4; ++k) { a0 += u[k]; a1 += v[k]; }
-    }
-    for (; b < nblocks; b += 256) { a0 += p0[b]; a1 += p1[b]; }
+            for (int k = 0; k < 4; ++k) { a0 += u[k]; a1 += v[k]; }
+        }
+        for (; b < nblocks; b += 256) { a0 += p0[b]; a1 += p1[b]; }
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { a0 += __shfl_down(a0, o, 64); a1 += __shfl_down(a1, o, 64); }
-    if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = a0; red[1][threadIdx.x >> 6] = a1; }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        const double s0 = ((red[0][0] + red[0][1]) + red[0][2]) + red[0][3];
-        const double s1 = ((red[1][0] + red[1][1]) + red[1][2]) + red[1][3];
-        bn_stats_emit(c, s0, s1, rows, gamma, beta, mm, mv, momentum, eps, bessel, update_moving, scale, shift,
-                      mean_out, invstd_out);
+        for (int o = 32; o > 0; o >>= 1) { a0 += __shfl_down(a0, o, 64); a1 += __shfl_down(a1, o, 64); }
+        if (z) __syncthreads();                      // `red` of the previous group has been consumed
+        if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = a0; red[1][threadIdx.x >> 6] = a1; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const double s0 = ((red[0][0] + red[0][1]) + red[0][2]) + red[0][3];
+            const double s1 = ((red[1][0] + red[1][1]) + red[1][2]) + red[1][3];
+            bn_stats_emit(c, s0, s1, rows, gamma, beta, mm, mv, momentum, eps, bessel, update_moving, scale + z * C,
+                          shift + z * C, mean_out + z * C, invstd_out + z * C);
+        }
     }
 }
 
+// `groups` batch groups of `rows` rows (and `nblocks` partials) EACH; outputs [groups][C].
 DDL_API void ddl_bn_stats_from_part(const float* part, int nblocks, long rows, int C, const float* gamma,
                                     const float* beta, float* mm, float* mv, float momentum, float eps, int bessel,
                                     int update_moving, float* scale, float* shift, float* mean, float* invstd,
-                                    hipStream_t s);
+                                    int groups, hipStream_t s);
 
 DDL_API void ddl_bn_batch_stats(const void* x, long rows, int C, float* part, const float* gamma,
                                 const float* beta, float* mm, float* mv, float momentum, float eps, int bessel,
                                 int update_moving, float* scale, float* shift, float* mean, float* invstd,
-                                hipStream_t s) {
+                                int groups, hipStream_t s) {
     dim3 grid;
     colreduce_grid(rows, C, &grid);
+    grid.z = groups;
     colreduce_kernel<0><<<grid, EW_BLOCK, 0, s>>>((const uint4*)x, nullptr, nullptr, nullptr, nullptr, part,
                                                   rows, C, 0, 0.f, 0, 0.f);
     ddl_bn_stats_from_part(part, (int)grid.x, rows, C, gamma, beta, mm, mv, momentum, eps, bessel, update_moving, scale,
-                           shift, mean, invstd, s);
+                           shift, mean, invstd, groups, s);
 }
 
 // Batch statistics from partials a producer kernel already wrote (pconv's STATS epilogue): finalize only.
 DDL_API void ddl_bn_stats_from_part(const float* part, int nblocks, long rows, int C, const float* gamma,
                                     const float* beta, float* mm, float* mv, float momentum, float eps, int bessel,
                                     int update_moving, float* scale, float* shift, float* mean, float* invstd,
-                                    hipStream_t s) {
+                                    int groups, hipStream_t s) {
     // one block per channel once a 32-lane walk would take more than two trips of four loads: the narrow
     // kernel's time is its number of dependent round trips (8 of them for 1000 partials)
     if (nblocks > fin_wide_min())
         bn_stats_finalize_wide_kernel<<<C, 256, 0, s>>>(part, nblocks, C, rows, gamma, beta, mm, mv, momentum, eps,
-                                                        bessel, update_moving, scale, shift, mean, invstd);
+                                                        bessel, update_moving, scale, shift, mean, invstd, groups);
     else
         bn_stats_finalize_kernel<<<FIN_GRID(C), FIN_BLOCK, 0, s>>>(part, nblocks, C, rows, gamma, beta, mm, mv,
                                                                  momentum, eps, bessel, update_moving, scale, shift,
-                                                                 mean, invstd);
+                                                                 mean, invstd, groups);
 }
 
 // Inference-phase BN: scale/shift from the moving statistics (tiny, one launch).
@@ -441,6 +462,9 @@ __global__ void bn_apply_kernel(const uint4* __restrict__ x, uint4* __restrict__
                                 const float* __restrict__ scale, const float* __restrict__ shift, long n8,
                                 int cg, int c_true, int act, float alpha, const float* __restrict__ mm,
                                 const float* __restrict__ mv, float eps) {
+    // blockIdx.y = batch group: n8 vectors and one (scale, shift) row each
+    x += (size_t)blockIdx.y * n8; y += (size_t)blockIdx.y * n8;
+    scale += blockIdx.y * cg * 8; shift += blockIdx.y * cg * 8;
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n8; i += (long)gridDim.x * blockDim.x) {
         int c0 = (int)(i % cg) * 8;
         float f[8];
@@ -464,6 +488,8 @@ __global__ __launch_bounds__(EW_BLOCK) void bn_apply_cs_kernel(const uint4* __re
                                                                const float* __restrict__ mv, float eps) {
     const int g = threadIdx.x % cg, rl = threadIdx.x / cg, rpi = EW_BLOCK / cg;
     const int c0 = g * 8;
+    x += (size_t)blockIdx.y * rows * cg; y += (size_t)blockIdx.y * rows * cg;      // blockIdx.y = batch group
+    scale += blockIdx.y * cg * 8; shift += blockIdx.y * cg * 8;
     float sc[8], sh[8];
     bn_affine8(scale, shift, mm, mv, eps, c0, sc, sh);
     for (long r = blockIdx.x * (long)rpi + rl; r < rows; r += (long)gridDim.x * rpi) {
@@ -485,48 +511,65 @@ static inline int cs_grid(long rows, int cg) {
 
 static void bn_apply_launch(const void* x, void* y, const float* scale, const float* shift, long rows, int C,
                             int c_true, int act, float alpha, const float* mm, const float* mv, float eps,
-                            hipStream_t s) {
-    long n8 = rows * (C / 8);
+                            int groups, hipStream_t s) {
+    long n8 = rows * (C / 8);                  // `rows` per batch group
     if (cs_ok(C / 8)) {
-        bn_apply_cs_kernel<<<cs_grid(rows, C / 8), EW_BLOCK, 0, s>>>((const uint4*)x, (uint4*)y, scale, shift, rows,
-                                                                   C / 8, c_true, act, alpha, mm, mv, eps);
+        int gx = cs_grid(rows * groups, C / 8) / groups;
+        bn_apply_cs_kernel<<<dim3(gx < 1 ? 1 : gx, groups), EW_BLOCK, 0, s>>>((const uint4*)x, (uint4*)y, scale, shift,
+                                                                              rows, C / 8, c_true, act, alpha, mm, mv,
+                                                                              eps);
         return;
     }
-    bn_apply_kernel<<<ew_grid(n8), EW_BLOCK, 0, s>>>((const uint4*)x, (uint4*)y, scale, shift, n8, C / 8,
-                                                     c_true, act, alpha, mm, mv, eps);
+    int gx = ew_grid(n8 * groups) / groups;
+    bn_apply_kernel<<<dim3(gx < 1 ? 1 : gx, groups), EW_BLOCK, 0, s>>>((const uint4*)x, (uint4*)y, scale, shift, n8,
+                                                                       C / 8, c_true, act, alpha, mm, mv, eps);
 }
 
+// `groups` batch groups of `rows` rows each, scale / shift [groups][C]
 DDL_API void ddl_bn_apply(const void* x, void* y, const float* scale, const float* shift, long rows, int C,
-                          int c_true, int act, float alpha, hipStream_t s) {
-    bn_apply_launch(x, y, scale, shift, rows, C, c_true, act, alpha, nullptr, nullptr, 0.f, s);
+                          int c_true, int act, float alpha, int groups, hipStream_t s) {
+    bn_apply_launch(x, y, scale, shift, rows, C, c_true, act, alpha, nullptr, nullptr, 0.f, groups, s);
 }
 
 // Inference-phase BN in one launch: y = act(gamma * (x - moving_mean) * rsqrt(moving_var + eps) + beta).
 DDL_API void ddl_bn_apply_infer(const void* x, void* y, const float* gamma, const float* beta, const float* mm,
                                 const float* mv, float eps, long rows, int C, int c_true, int act, float alpha,
                                 hipStream_t s) {
-    bn_apply_launch(x, y, gamma, beta, rows, C, c_true, act, alpha, mm, mv, eps, s);
+    bn_apply_launch(x, y, gamma, beta, rows, C, c_true, act, alpha, mm, mv, eps, 1, s);
 }
 
 // BN backward: reduce -> finalize (dgamma, dbeta, c1 = dbeta/M, c2 = dgamma/M) -> apply.
+// Per batch group z: c1 = dbeta_z / M, c2 = dgamma_z / M (M rows per group), rows [z][C].  dgamma / dbeta (and the
+// producing conv's bias gradient for NS == 5) are the sums over the groups, accumulated in fp64 in group order.
 template <int NS>
-__device__ __forceinline__ void bn_bwd_emit(int c, const double (&o)[NS], long rows, int train_stats,
-                                            float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                            float* __restrict__ c1, float* __restrict__ c2,
-                                            const float* __restrict__ mean, const float* __restrict__ invstd,
-                                            const float* __restrict__ gamma, float* __restrict__ dbias, int c_bias) {
-    if (dbeta) dbeta[c] = (float)o[0];
-    if (dgamma) dgamma[c] = (float)o[1];
+struct BnBwdAcc { double dbeta = 0, dgamma = 0, dbias = 0; };
+
+template <int NS>
+__device__ __forceinline__ void bn_bwd_group(int c, int z, int C, const double (&o)[NS], long rows, int train_stats,
+                                             float* __restrict__ c1, float* __restrict__ c2,
+                                             const float* __restrict__ mean, const float* __restrict__ invstd,
+                                             const float* __restrict__ gamma, int c_bias, BnBwdAcc<NS>& acc) {
+    acc.dbeta += o[0];
+    acc.dgamma += o[1];
     const float f1 = train_stats ? (float)(o[0] / (double)rows) : 0.f;
     const float f2 = train_stats ? (float)(o[1] / (double)rows) : 0.f;
-    c1[c] = f1;
-    c2[c] = f2;
+    c1[z * C + c] = f1;
+    c2[z * C + c] = f2;
     if (NS == 5 && c < c_bias) {
         // same k0/k1/k2 as bn_bwd_apply (fp32 there); combined in fp64 here
-        const double is = invstd[c], gi = (double)gamma[c] * is;
-        const double k0 = gi, k1 = -gi * is * (double)f2, k2 = -gi * ((double)f1 - (double)mean[c] * is * (double)f2);
-        dbias[c] = (float)(k0 * o[NS - 3] + k1 * o[NS - 2] + k2 * o[NS - 1]);
+        const double is = invstd[z * C + c], gi = (double)gamma[c] * is;
+        const double k0 = gi, k1 = -gi * is * (double)f2,
+                     k2 = -gi * ((double)f1 - (double)mean[z * C + c] * is * (double)f2);
+        acc.dbias += k0 * o[NS - 3] + k1 * o[NS - 2] + k2 * o[NS - 1];
     }
+}
+
+template <int NS>
+__device__ __forceinline__ void bn_bwd_store(int c, const BnBwdAcc<NS>& acc, float* __restrict__ dgamma,
+                                             float* __restrict__ dbeta, float* __restrict__ dbias, int c_bias) {
+    if (dbeta) dbeta[c] = (float)acc.dbeta;
+    if (dgamma) dgamma[c] = (float)acc.dgamma;
+    if (NS == 5 && c < c_bias) dbias[c] = (float)acc.dbias;
 }
 
 template <int NS>
@@ -534,12 +577,18 @@ __global__ void bn_bwd_finalize_kernel(const float* __restrict__ part, int nbloc
                                        int train_stats, float* __restrict__ dgamma, float* __restrict__ dbeta,
                                        float* __restrict__ c1, float* __restrict__ c2,
                                        const float* __restrict__ mean, const float* __restrict__ invstd,
-                                       const float* __restrict__ gamma, float* __restrict__ dbias, int c_bias) {
+                                       const float* __restrict__ gamma, float* __restrict__ dbias, int c_bias,
+                                       int groups) {
     int c = FIN_CHANNEL();
-    double o[NS];
-    reduce_partials_n<NS, NS>(part, nblocks, C, c, o);
+    BnBwdAcc<NS> acc;
+    for (int z = 0; z < groups; ++z) {
+        double o[NS];
+        reduce_partials_n<NS, NS>(part, nblocks, C, c, o, nblocks * groups, z * nblocks);
+        if (c < C && FIN_LEADER())
+            bn_bwd_group<NS>(c, z, C, o, rows, train_stats, c1, c2, mean, invstd, gamma, c_bias, acc);
+    }
     if (c >= C || !FIN_LEADER()) return;
-    bn_bwd_emit<NS>(c, o, rows, train_stats, dgamma, dbeta, c1, c2, mean, invstd, gamma, dbias, c_bias);
+    bn_bwd_store<NS>(c, acc, dgamma, dbeta, dbias, c_bias);
 }
 
 // More than a few hundred partials per channel: one block per channel, 256 lanes on the channel's contiguous
@@ -548,44 +597,52 @@ template <int NS>
 __global__ __launch_bounds__(256) void bn_bwd_finalize_wide_kernel(
     const float* __restrict__ part, int nblocks, int C, long rows, int train_stats, float* __restrict__ dgamma,
     float* __restrict__ dbeta, float* __restrict__ c1, float* __restrict__ c2, const float* __restrict__ mean,
-    const float* __restrict__ invstd, const float* __restrict__ gamma, float* __restrict__ dbias, int c_bias) {
+    const float* __restrict__ invstd, const float* __restrict__ gamma, float* __restrict__ dbias, int c_bias,
+    int groups) {
     __shared__ double red[NS][4];
     const int c = blockIdx.x;
-    double acc[NS];
+    const size_t nbt = (size_t)nblocks * groups;
+    BnBwdAcc<NS> total;
+    for (int z = 0; z < groups; ++z) {
+        const float* pz = part + (size_t)z * nblocks;
+        double acc[NS];
 #pragma unroll
-    for (int k = 0; k < NS; ++k) acc[k] = 0;
-    int b = threadIdx.x;
-    for (; b + 256 < nblocks; b += 512) {             // two partial rows per trip, NS sums each: 2 NS loads in flight
-        float u[2][NS];
+        for (int k = 0; k < NS; ++k) acc[k] = 0;
+        int b = threadIdx.x;
+        for (; b + 256 < nblocks; b += 512) {         // two partial rows per trip, NS sums each: 2 NS loads in flight
+            float u[2][NS];
 #pragma unroll
-        for (int h = 0; h < 2; ++h)
+            for (int h = 0; h < 2; ++h)
 #pragma unroll
-            for (int k = 0; k < NS; ++k) u[h][k] = part[((size_t)k * C + c) * nblocks + b + 256 * h];
+                for (int k = 0; k < NS; ++k) u[h][k] = pz[((size_t)k * C + c) * nbt + b + 256 * h];
 #pragma unroll
-        for (int h = 0; h < 2; ++h)
+            for (int h = 0; h < 2; ++h)
 #pragma unroll
-            for (int k = 0; k < NS; ++k) acc[k] += u[h][k];
+                for (int k = 0; k < NS; ++k) acc[k] += u[h][k];
+        }
+        for (; b < nblocks; b += 256) {
+#pragma unroll
+            for (int k = 0; k < NS; ++k) acc[k] += pz[((size_t)k * C + c) * nbt + b];
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+#pragma unroll
+            for (int k = 0; k < NS; ++k) acc[k] += __shfl_down(acc[k], o, 64);
+        }
+        if (z) __syncthreads();
+        if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+            for (int k = 0; k < NS; ++k) red[k][threadIdx.x >> 6] = acc[k];
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            double o[NS];
+#pragma unroll
+            for (int k = 0; k < NS; ++k) o[k] = ((red[k][0] + red[k][1]) + red[k][2]) + red[k][3];
+            bn_bwd_group<NS>(c, z, C, o, rows, train_stats, c1, c2, mean, invstd, gamma, c_bias, total);
+        }
     }
-    for (; b < nblocks; b += 256) {
-#pragma unroll
-        for (int k = 0; k < NS; ++k) acc[k] += part[((size_t)k * C + c) * nblocks + b];
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-#pragma unroll
-        for (int k = 0; k < NS; ++k) acc[k] += __shfl_down(acc[k], o, 64);
-    }
-    if ((threadIdx.x & 63) == 0) {
-#pragma unroll
-        for (int k = 0; k < NS; ++k) red[k][threadIdx.x >> 6] = acc[k];
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        double o[NS];
-#pragma unroll
-        for (int k = 0; k < NS; ++k) o[k] = ((red[k][0] + red[k][1]) + red[k][2]) + red[k][3];
-        bn_bwd_emit<NS>(c, o, rows, train_stats, dgamma, dbeta, c1, c2, mean, invstd, gamma, dbias, c_bias);
-    }
+    if (threadIdx.x == 0) bn_bwd_store<NS>(c, total, dgamma, dbeta, dbias, c_bias);
 }
 
 __global__ void bn_bwd_apply_kernel(const uint4* __restrict__ dy, const uint4* __restrict__ x,
@@ -594,6 +651,12 @@ __global__ void bn_bwd_apply_kernel(const uint4* __restrict__ dy, const uint4* _
                                     const float* __restrict__ gamma, const float* __restrict__ c1,
                                     const float* __restrict__ c2, long n8, int cg, int act, float alpha,
                                     int prev_act, float prev_alpha) {
+    {   // blockIdx.y = batch group
+        const size_t go = (size_t)blockIdx.y * n8;
+        dy += go; x += go; dx += go; if (yv) yv += go;
+        const int co = blockIdx.y * cg * 8;
+        mean += co; invstd += co; c1 += co; c2 += co;
+    }
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n8; i += (long)gridDim.x * blockDim.x) {
         int c0 = (int)(i % cg) * 8;
         float g[8], xv[8], yy[8];
@@ -623,6 +686,12 @@ __global__ __launch_bounds__(EW_BLOCK) void bn_bwd_apply_cs_kernel(
     const float* __restrict__ c1, const float* __restrict__ c2, long rows, int cg, int act, float alpha,
     int prev_act, float prev_alpha) {
     const int g = threadIdx.x % cg, rl = threadIdx.x / cg, rpi = EW_BLOCK / cg;
+    {   // blockIdx.y = batch group
+        const size_t go = (size_t)blockIdx.y * rows * cg;
+        dy += go; x += go; dx += go; if (yv) yv += go;
+        const int co = blockIdx.y * cg * 8;
+        mean += co; invstd += co; c1 += co; c2 += co;
+    }
     // dx = k0*g' + k1*x + k2 with  k0 = gamma*is, k1 = -gamma*is*is*c2, k2 = -gamma*is*(c1 - mean*is*c2)
     float k0[8], k1[8], k2[8];
 #pragma unroll
@@ -653,45 +722,49 @@ __global__ __launch_bounds__(EW_BLOCK) void bn_bwd_apply_cs_kernel(
     }
 }
 
+// `groups` batch groups of `rows` rows each: mean / invstd / c1 / c2 are [groups][C]; dgamma, dbeta, dbias sum over groups.
 DDL_API void ddl_bn_bwd(const void* dy, const void* x, const void* y, void* dx, long rows, int C,
                         const float* mean, const float* invstd, const float* gamma, int act, float alpha,
                         int train_stats, int prev_act, float prev_alpha, float* part, float* dgamma,
-                        float* dbeta, float* c1, float* c2, float* dbias, int c_bias, hipStream_t s) {
+                        float* dbeta, float* c1, float* c2, float* dbias, int c_bias, int groups, hipStream_t s) {
     // `dbias` (optional, c_bias entries): bias gradient of the conv feeding this BN, = column sums of dx;
     // `part` then holds 5 (instead of 2) partial rows per block.
     dim3 grid;
     colreduce_grid(rows, C, &grid);
+    grid.z = groups;
     if (dbias) {
         colreduce_kernel<3><<<grid, EW_BLOCK, 0, s>>>((const uint4*)dy, (const uint4*)x, (const uint4*)y, mean,
                                                       invstd, part, rows, C, act, alpha, prev_act, prev_alpha);
         if ((int)grid.x > fin_wide_min())
             bn_bwd_finalize_wide_kernel<5><<<C, 256, 0, s>>>(part, grid.x, C, rows, train_stats, dgamma, dbeta, c1, c2,
-                                                              mean, invstd, gamma, dbias, c_bias);
+                                                              mean, invstd, gamma, dbias, c_bias, groups);
         else
             bn_bwd_finalize_kernel<5><<<FIN_GRID(C), FIN_BLOCK, 0, s>>>(part, grid.x, C, rows, train_stats, dgamma,
                                                                       dbeta, c1, c2, mean, invstd, gamma, dbias,
-                                                                      c_bias);
+                                                                      c_bias, groups);
     } else {
         colreduce_kernel<1><<<grid, EW_BLOCK, 0, s>>>((const uint4*)dy, (const uint4*)x, (const uint4*)y, mean,
                                                       invstd, part, rows, C, act, alpha, 0, 0.f);
         if ((int)grid.x > fin_wide_min())
             bn_bwd_finalize_wide_kernel<2><<<C, 256, 0, s>>>(part, grid.x, C, rows, train_stats, dgamma, dbeta, c1, c2,
-                                                              mean, invstd, gamma, nullptr, 0);
+                                                              mean, invstd, gamma, nullptr, 0, groups);
         else
             bn_bwd_finalize_kernel<2><<<FIN_GRID(C), FIN_BLOCK, 0, s>>>(part, grid.x, C, rows, train_stats, dgamma,
                                                                       dbeta, c1, c2, mean, invstd, gamma, nullptr,
-                                                                      0);
+                                                                      0, groups);
     }
     long n8 = rows * (C / 8);
     if (cs_ok(C / 8)) {
-        bn_bwd_apply_cs_kernel<<<cs_grid(rows, C / 8), EW_BLOCK, 0, s>>>(
+        int gx = cs_grid(rows * groups, C / 8) / groups;
+        bn_bwd_apply_cs_kernel<<<dim3(gx < 1 ? 1 : gx, groups), EW_BLOCK, 0, s>>>(
             (const uint4*)dy, (const uint4*)x, (const uint4*)y, (uint4*)dx, mean, invstd, gamma, c1, c2, rows, C / 8,
             act, alpha, prev_act, prev_alpha);
         return;
     }
-    bn_bwd_apply_kernel<<<ew_grid(n8), EW_BLOCK, 0, s>>>((const uint4*)dy, (const uint4*)x, (const uint4*)y,
-                                                         (uint4*)dx, mean, invstd, gamma, c1, c2, n8, C / 8,
-                                                         act, alpha, prev_act, prev_alpha);
+    int gx = ew_grid(n8 * groups) / groups;
+    bn_bwd_apply_kernel<<<dim3(gx < 1 ? 1 : gx, groups), EW_BLOCK, 0, s>>>(
+        (const uint4*)dy, (const uint4*)x, (const uint4*)y, (uint4*)dx, mean, invstd, gamma, c1, c2, n8, C / 8, act,
+        alpha, prev_act, prev_alpha);
 }
 
 // bias gradient = per-channel column sum of dY

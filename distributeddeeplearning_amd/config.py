@@ -97,6 +97,7 @@ class GANSettings:
     size: int = 28
     reference_exact: bool = False
     seed: int = 0
+    bn_policy: str = "split"      # split | inference | mixed (models/dcgan.py); reference_exact forces inference
 
 
 def _coerce(old, text: str):

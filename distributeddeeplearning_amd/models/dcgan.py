@@ -5,11 +5,21 @@ Graphs: /root/reference/GAN_distributed.py:15-72 (shapes in SURVEY 2.6.1).  Step
 labels [1 ; 0] in ONE pass, then a G-step through the frozen D with labels 1; sigmoid-BCE on
 logits; Adam(2e-4).
 
-Two modes, selectable per trainer:
-  * `reference_exact=True`  : fresh TF-Adam applied twice per phase (== 2*lr*sign(g)), BN in
-    inference phase (moving stats, never updated) -- what the reference script really computes;
-  * `reference_exact=False` : persistent Adam, training-mode BN with batch statistics -- the sane
-    default used for data-parallel benchmarking.
+Optimizer: `reference_exact=True` is the script's literal "fresh TF-Adam applied twice
+per phase" (== 2*lr*sign(g)); the default is one persistent Adam per network.
+
+BatchNorm policy (`bn_policy`).  The batch composition differs between the two phases
+([real ; fake] in the D phase, fake only in the G phase) and `generator.predict` is an inference-phase
+call, so WHICH statistics normalise WHAT decides whether the game is adversarial at all:
+  * "split" (default): batch statistics everywhere, standard DCGAN practice -- the generator runs in
+    training mode for the D-phase fakes too, and the discriminator normalises the real half and the
+    fake half of its batch separately.  A fake batch then looks the same to D in both phases.
+  * "inference": the reference's own semantics -- every BN in inference phase on its (never updated)
+    moving statistics, i.e. a learned per-channel affine.  Forced by `reference_exact`.
+  * "mixed": round-1 behaviour, kept for study only: D normalises [real ; fake] as ONE batch and the
+    D-phase fakes come from inference-phase G.  D separates real from fake through the batch
+    statistics, a fake-only batch then reads as "real", and both losses collapse to ~1e-4 within a
+    few hundred iterations while G learns nothing (docs/GAN_TRAINING.md has the measurements).
 
 No host round trips inside a step: noise comes from a device RNG, the generated batch is written
 next to the real batch on device, the loss stays on device until someone asks for it.
@@ -77,6 +87,13 @@ class GANConfig:
     reference_exact: bool = False
     seed: int = 0
     base: int = 32
+    bn_policy: str = "split"        # split | inference | mixed (module docstring)
+
+    def __post_init__(self):
+        if self.reference_exact:
+            self.bn_policy = "inference"
+        if self.bn_policy not in ("split", "inference", "mixed"):
+            raise ValueError(f"bn_policy {self.bn_policy!r}")
 
 
 class DeviceRNG:
@@ -97,6 +114,17 @@ class DeviceRNG:
             return F.hip_backend().philox_uniform(shape, dtype, self.state, lo, hi)
         return (torch.rand(shape, generator=self.gen) * (hi - lo) + lo).to(dtype)
 
+    def state_dict(self):
+        if self.device.type == "cuda":
+            return {"philox": self.state.detach().cpu()}
+        return {"generator": self.gen.get_state()}
+
+    def load_state_dict(self, sd):
+        if self.device.type == "cuda":
+            self.state.copy_(sd["philox"])
+        else:
+            self.gen.set_state(sd["generator"])
+
 
 class GANTrainer:
     """One rank's DCGAN trainer.  `dp` (parallel.ddp.FlatDataParallel or None) averages the flat
@@ -105,7 +133,8 @@ class GANTrainer:
     def __init__(self, cfg: GANConfig, device="cpu", dp=None, rank: int = 0, shard_optimizer: bool = False):
         self.cfg, self.device, self.dp = cfg, torch.device(device), dp
         self.sharded = bool(shard_optimizer and dp is not None)
-        bn_mode = "inference" if cfg.reference_exact else "batch"
+        bn_mode = "inference" if cfg.bn_policy == "inference" else "batch"
+        self._split = cfg.bn_policy == "split"
         # same seed on every rank -> identical initial replicas (dp.broadcast makes it certain)
         self.G = Network(generator_spec(cfg.size, cfg.base, cfg.noise_dim), device, cfg.seed + 1, bn_mode)
         self.D = Network(discriminator_spec(cfg.size, cfg.base), device, cfg.seed + 2, bn_mode)
@@ -137,16 +166,19 @@ class GANTrainer:
         """Forward/backward of the discriminator phase; leaves averaged grads in D.G."""
         B = real.shape[0]
         z = self.rng.uniform((B, self.cfg.noise_dim), self.G.cdtype)
+        g_train = self._split           # "split": the D-phase fakes see batch statistics like the G-phase ones
         if self.G.can_forward_into() and real.is_contiguous():
             # [real ; fake] assembled in place: the generator's last kernel writes straight into the
             # second half of the discriminator batch (no 2B-image concat copy)
             xs = torch.empty((2 * B,) + tuple(real.shape[1:]), dtype=real.dtype, device=real.device)
             xs[:B].copy_(real)
-            self.G.forward(z, training=False, out=xs[B:])      # generator.predict(noise)
+            self.G.forward(z, training=g_train, out=xs[B:])     # generator.predict(noise)
         else:
-            fake = self.G.forward(z, training=False)
+            fake = self.G.forward(z, training=g_train)
             xs = torch.cat([real, fake], 0)
-        feat = self.D.forward(xs, training=True, stop=-1)
+        if g_train:
+            self.G.release()
+        feat = self.D.forward(xs, training=True, stop=-1, bn_groups=2 if self._split else 1)
         loss, dfeat = self._d_head(feat, B, 1.0, 0.0, True, True)
         self.D.backward(dfeat, need_input_grad=False, start=-1)
         self.d_loss = loss
@@ -211,22 +243,70 @@ class GANTrainer:
         return self.d_loss, self.g_loss
 
     # ---- checkpoint / resume (the reference never checkpoints its GAN) ---------
-    def save_checkpoint(self, path, iteration: int):
+    def sync_bn_stats(self):
+        """Synchronous DP exchanges gradients only, so every rank's BN moving statistics follow its own data
+        shard: average them (one tiny all-reduce per network) before anything rank-dependent reads them --
+        a checkpoint, sample generation, evaluation.  A collective: every rank calls it."""
+        if self.dp is not None and self.dp.world > 1:
+            self.dp.all_reduce_mean_(self.G.S)
+            self.dp.all_reduce_mean_(self.D.S)
+
+    def save_checkpoint(self, path, iteration: int, write: bool = True):
+        """Every rank calls this (BN statistics are averaged, sharded optimizer state is gathered);
+        `write=False` on all ranks but the one that owns the file."""
         from ..utils import ckpt
-        ckpt.save_training_state(str(path) + ".G", self.G, self.optG, {"iteration": iteration})
-        ckpt.save_training_state(str(path) + ".D", self.D, self.optD, {"iteration": iteration})
-        with open(path, "w") as f:
-            f.write(str(iteration))
+        self.sync_bn_stats()
+        extra = {"iteration": iteration, "rng": self.rng.state_dict(), "bn_policy": self.cfg.bn_policy}
+        ckpt.save_training_state(str(path) + ".G", self.G, self.optG, extra, write)
+        ckpt.save_training_state(str(path) + ".D", self.D, self.optD, {"iteration": iteration}, write)
+        if write:
+            with open(path, "w") as f:
+                f.write(str(iteration))
 
     def load_checkpoint(self, path) -> int:
         from ..utils import ckpt
-        it = ckpt.load_training_state(str(path) + ".G", self.G, self.optG)["iteration"]
+        extra = ckpt.load_training_state(str(path) + ".G", self.G, self.optG)
         ckpt.load_training_state(str(path) + ".D", self.D, self.optD)
-        return int(it)
+        if "rng" in extra:
+            self.rng.load_state_dict(extra["rng"])
+        return int(extra["iteration"])
 
-    def generate(self, n: int):
+    def generate(self, n: int, training_bn: Optional[bool] = None):
+        """`generator.predict(noise)` (GAN_distributed.py:119-124).  Inference-phase BN (moving statistics) by
+        default; `training_bn=True` normalises the sample batch with its own statistics instead."""
         z = self.rng.uniform((n, self.cfg.noise_dim), self.G.cdtype)
-        return self.G.to_logical(self.G.forward(z, training=False))
+        y = self.G.forward(z, training=bool(training_bn))
+        if training_bn:
+            self.G.release()
+        return self.G.to_logical(y)
+
+    def diagnose(self, real):
+        """Mean discriminator logits on the three batches a step sees -- the real half and the fake half of
+        the D phase and the fake-only batch of the G phase -- computed exactly as the step computes them
+        (same BN policy).  Leaves weights, BN statistics, RNG and optimizer untouched.  A healthy game has
+        logit_fake ~= logit_gphase; a BN batch-composition leak shows as logit_fake << 0 << logit_gphase."""
+        B = real.shape[0]
+        keepS = (self.G.S.clone(), self.D.S.clone())
+        keepR = self.rng.state_dict()
+        if "philox" in keepR:
+            keepR = {"philox": keepR["philox"].clone()}
+        z = self.rng.uniform((B, self.cfg.noise_dim), self.G.cdtype)
+        fake = self.G.forward(z, training=self._split)
+        xs = torch.cat([real, fake], 0)
+        feat = self.D.forward(xs, training=True, stop=-1, bn_groups=2 if self._split else 1)
+        h = self.head
+        lg = F.dense1_bce_fwd_bwd(feat, h.w_main, h.bias, 1.0, 0.0, B, False, False)[4].float()
+        z = self.rng.uniform((B, self.cfg.noise_dim), self.G.cdtype)
+        feat2 = self.D.forward(self.G.forward(z, training=True), training=True, stop=-1)
+        lg2 = F.dense1_bce_fwd_bwd(feat2, h.w_main, h.bias, 1.0, 1.0, B, False, False)[4].float()
+        out = {"logit_real": float(lg[:B].mean()), "logit_fake": float(lg[B:].mean()),
+               "logit_gphase": float(lg2.mean())}
+        self.G.release()
+        self.D.release()
+        self.G.S.copy_(keepS[0])
+        self.D.S.copy_(keepS[1])
+        self.rng.load_state_dict(keepR)
+        return out
 
 
 class GraphedGANStep:

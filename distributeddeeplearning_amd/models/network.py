@@ -270,7 +270,9 @@ class ConvOp(Op):
         else:
             y = F.conv_fprop(x, self.w_main, self.bias, g, self.act, self.alpha, stats_out=so, bn_infer=bi)
         if so and "part" in so:
-            bn.pre_stats = (so["part"], so["nb"])
+            # per-group statistics need every producer block inside one batch group
+            if bn.groups == 1 or (x.shape[0] % (so["img"] * bn.groups) == 0):
+                bn.pre_stats = (so["part"], so["nb"])
         elif so and so.get("affine"):
             bn.applied_by_producer = True
         if training:
@@ -340,6 +342,8 @@ class BNOp(Op):
         self.bias_grad_for = None      # ConvOp (with a fused activation) whose bias gradient our backward emits
         self.pre_stats = None          # (partials, n_blocks) left by the producing conv kernel for the next fwd
         self.applied_by_producer = False   # inference forward: the producing conv already applied this BN
+        self.groups = 1                # batch groups with their own batch statistics (set per forward pass)
+        self.groups_used = 1
 
     def fwd(self, x, training):
         use_batch = training and self.mode == "batch"
@@ -350,22 +354,24 @@ class BNOp(Op):
             return F.bn_apply_infer(x, self.gamma, self.beta, self.moving_mean, self.moving_var, self.eps,
                                     self.post_act, self.post_alpha, self.C)
         pre, self.pre_stats = self.pre_stats, None
+        groups = self.groups if use_batch else 1
         if use_batch and pre is not None:
             scale, shift, mean, invstd = F.bn_train_affine_from_part(
                 pre[0], pre[1], x.numel() // x.shape[-1], self.gamma, self.beta, self.moving_mean,
-                self.moving_var, self.momentum, self.eps, self.rank4, True)
+                self.moving_var, self.momentum, self.eps, self.rank4, True, groups)
         elif use_batch:
             scale, shift, mean, invstd = F.bn_train_affine(x, self.gamma, self.beta, self.moving_mean,
                                                            self.moving_var, self.momentum, self.eps,
-                                                           self.rank4, True)
+                                                           self.rank4, True, groups)
         else:
             mean = self.moving_mean
             scale, shift, invstd = F.bn_infer_affine(self.gamma, self.beta, self.moving_mean, self.moving_var,
                                                      self.eps)
-        y = F.bn_apply(x, scale, shift, self.post_act, self.post_alpha, self.C)
+        y = F.bn_apply(x, scale, shift, self.post_act, self.post_alpha, self.C, groups)
         if training:
             self.x, self.y, self.mean, self.invstd = x, y, mean, invstd
             self.used_batch_stats = use_batch
+            self.groups_used = groups
         return y
 
     def bwd(self, dy, need_dx=True, need_dw=True):
@@ -373,7 +379,7 @@ class BNOp(Op):
         dx, _, _ = F.bn_bwd(dy, self.x, self.y, self.mean, self.invstd, self.gamma, self.post_act,
                             self.post_alpha, self.used_batch_stats, self.prev_act, self.prev_alpha,
                             self.ggamma if need_dw else None, self.gbeta if need_dw else None,
-                            conv.gbias if (need_dw and conv is not None) else None)
+                            conv.gbias if (need_dw and conv is not None) else None, self.groups_used)
         return dx
 
     def release(self):
@@ -715,10 +721,16 @@ class Network:
             return F.hip_backend().strip_channels(y, c_true)
         return y.float()
 
-    def forward(self, x, training: bool = False, start: int = 0, stop: Optional[int] = None, out=None):
+    def forward(self, x, training: bool = False, start: int = 0, stop: Optional[int] = None, out=None,
+                bn_groups: int = 1):
         """`out`: destination for the network's output when its last op can write in place of
-        allocating (`can_forward_into()`); lets a caller assemble a batch without a concat copy."""
+        allocating (`can_forward_into()`); lets a caller assemble a batch without a concat copy.
+        `bn_groups`: batch-statistics BatchNorm layers normalise that many equal contiguous parts of the
+        batch independently (a discriminator batch [real ; fake] with per-half statistics)."""
         stop = len(self.ops) if stop is None else (stop if stop >= 0 else len(self.ops) + stop)
+        for op in self.ops:
+            if isinstance(op, BNOp):
+                op.groups = bn_groups
         last = self.ops[-1] if self.ops else None
         if out is not None:
             if not (stop == len(self.ops) and self.can_forward_into()):

@@ -74,8 +74,15 @@ class FlatOptimizer:
         else:
             raise ValueError(c.kind)
 
+    def steps_taken(self) -> int:
+        """Optimizer steps actually executed.  On device the truth is the device-side counter: hipGraph
+        replays advance `step_dev` only, and a capture bumps the host mirror without executing anything."""
+        if self.step_dev is not None:
+            self.t = int(self.step_dev[0].item())
+        return self.t
+
     def state_dict(self):
-        return {"t": self.t, "m": self.m, "v": self.v, "cfg": vars(self.cfg)}
+        return {"t": self.steps_taken(), "m": self.m, "v": self.v, "cfg": vars(self.cfg)}
 
     def load_state_dict(self, sd):
         self.t = int(sd["t"])
@@ -111,6 +118,35 @@ class ShardedFlatOptimizer(FlatOptimizer):
         self.m = torch.zeros(self.chunk, dtype=net.P.dtype, device=dev) if cfg.kind == "adam" else None
         self.v = torch.zeros(self.chunk, dtype=net.P.dtype, device=dev) if cfg.kind in ("adam", "rmsprop") else None
         self.step_dev = torch.zeros(2, dtype=torch.int32, device=dev) if net.on_gpu else None
+
+    def sync_from_net(self):
+        """Re-read this rank's parameter shard from `net.P` (after a checkpoint load / broadcast rewrote it)."""
+        self.pshard.zero_()
+        self.pshard[:self.hi - self.lo].copy_(self.net.P[self.lo:self.hi])
+
+    def state_dict(self):
+        """Full-size optimizer state: every rank's m / v shard all-gathered (a collective: all ranks call it)."""
+        n = self.net.P.numel()
+        out = {"t": self.steps_taken(), "cfg": vars(self.cfg), "m": None, "v": None}
+        for k in ("m", "v"):
+            sh = getattr(self, k)
+            if sh is not None:
+                full = torch.empty(self.chunk * self.dp.world, dtype=sh.dtype, device=sh.device)
+                self.dp.all_gather_flat(sh, full)
+                out[k] = full[:n].clone()
+        return out
+
+    def load_state_dict(self, sd):
+        self.t = int(sd["t"])
+        for k in ("m", "v"):
+            sh, full = getattr(self, k), sd.get(k)
+            if sh is not None and full is not None:
+                sh.zero_()
+                sh[:self.hi - self.lo].copy_(full[self.lo:self.hi])
+        if self.step_dev is not None:
+            self.step_dev.zero_()
+            self.step_dev[0] = self.t
+        self.sync_from_net()
 
     def step(self, grad_scale: Optional[float] = None):
         net, c, dp = self.net, self.cfg, self.dp

@@ -105,28 +105,38 @@ def spatial_pad(x, pt, pb, pl, pr):
 
 
 # batch norm --------------------------------------------------------------------------------
-def bn_train_affine(x, gamma, beta, mm, mv, momentum, eps, bessel, update_moving=True):
+def bn_train_affine(x, gamma, beta, mm, mv, momentum, eps, bessel, update_moving=True, groups=1):
     """Batch statistics of x -> (scale, shift, mean, invstd) with y = x*scale + shift, plus the
     Keras moving-average update  moving = moving*momentum + batch*(1-momentum)  (variance
-    Bessel-corrected for 4-D inputs, as TF's fused batch norm does)."""
+    Bessel-corrected for 4-D inputs, as TF's fused batch norm does).
+
+    `groups` > 1: the batch is `groups` equal contiguous parts, each normalised with its own
+    statistics (results are [groups][C]); the moving statistics take one update per part, in order --
+    what calling the layer once per part would do (a GAN discriminator on [real ; fake])."""
     if x.is_cuda:
-        return hip_backend().bn_train_affine(x, gamma, beta, mm, mv, momentum, eps, bessel, update_moving)
-    mean, var = cpu_ref.bn_stats(x)
-    count = x.numel() // x.shape[-1]
-    invstd = torch.rsqrt(var + eps)
-    scale = gamma * invstd
-    shift = beta - mean * scale
-    if update_moving:
-        mm.mul_(momentum).add_(mean, alpha=1 - momentum)
-        v = var * (count / max(count - 1, 1)) if bessel else var
-        mv.mul_(momentum).add_(v, alpha=1 - momentum)
-    return scale, shift, mean, invstd
+        return hip_backend().bn_train_affine(x, gamma, beta, mm, mv, momentum, eps, bessel, update_moving, groups)
+    outs = []
+    for xs in x.chunk(groups, 0):
+        mean, var = cpu_ref.bn_stats(xs)
+        count = xs.numel() // xs.shape[-1]
+        invstd = torch.rsqrt(var + eps)
+        scale = gamma * invstd
+        shift = beta - mean * scale
+        if update_moving:
+            mm.mul_(momentum).add_(mean, alpha=1 - momentum)
+            v = var * (count / max(count - 1, 1)) if bessel else var
+            mv.mul_(momentum).add_(v, alpha=1 - momentum)
+        outs.append((scale, shift, mean, invstd))
+    if groups == 1:
+        return outs[0]
+    return tuple(torch.stack([o[k] for o in outs], 0) for k in range(4))
 
 
-def bn_train_affine_from_part(part, nb, rows, gamma, beta, mm, mv, momentum, eps, bessel, update_moving=True):
+def bn_train_affine_from_part(part, nb, rows, gamma, beta, mm, mv, momentum, eps, bessel, update_moving=True,
+                              groups=1):
     """Device only: batch statistics from partial sums the producing conv kernel already wrote."""
     return hip_backend().bn_train_affine_from_part(part, nb, rows, gamma, beta, mm, mv, momentum, eps, bessel,
-                                                   update_moving)
+                                                   update_moving, groups)
 
 
 def bn_infer_affine(gamma, beta, mm, mv, eps):
@@ -146,21 +156,33 @@ def bn_apply_infer(x, gamma, beta, mm, mv, eps, act=None, alpha=0.3, c_true=None
     return cpu_ref.bn_apply(x, scale, shift, act, alpha)
 
 
-def bn_apply(x, scale, shift, act=None, alpha=0.3, c_true=None):
+def bn_apply(x, scale, shift, act=None, alpha=0.3, c_true=None, groups=1):
+    """`groups` > 1: scale / shift are [groups][C], one row per equal contiguous part of the batch."""
     if x.is_cuda:
-        return hip_backend().bn_apply(x, scale, shift, act, alpha, c_true)
-    return cpu_ref.bn_apply(x, scale, shift, act, alpha)
+        return hip_backend().bn_apply(x, scale, shift, act, alpha, c_true, groups)
+    if groups == 1:
+        return cpu_ref.bn_apply(x, scale, shift, act, alpha)
+    return torch.cat([cpu_ref.bn_apply(xs, scale[i], shift[i], act, alpha)
+                      for i, xs in enumerate(x.chunk(groups, 0))], 0)
 
 
 def bn_bwd(dy, x, y, mean, invstd, gamma, act, alpha, train_stats, prev_act=None, prev_alpha=0.3,
-           out_dgamma=None, out_dbeta=None, out_dbias=None):
+           out_dgamma=None, out_dbeta=None, out_dbias=None, groups=1):
     """`out_dbias`: also write the bias gradient of the conv/dense layer feeding this BN (the column
-    sums of dx) -- on device it comes out of the same reduction pass as dgamma/dbeta."""
+    sums of dx) -- on device it comes out of the same reduction pass as dgamma/dbeta.
+    `groups` > 1: per-part statistics (mean / invstd are [groups][C]); dgamma / dbeta / dbias sum over parts."""
     if dy.is_cuda:
         return hip_backend().bn_bwd(dy, x, y, mean, invstd, gamma, act, alpha, train_stats, prev_act,
-                                    prev_alpha, out_dgamma, out_dbeta, out_dbias)
-    dx, dgamma, dbeta = cpu_ref.bn_bwd(dy, x, y, mean, invstd, gamma, act, alpha, train_stats, prev_act,
-                                       prev_alpha)
+                                    prev_alpha, out_dgamma, out_dbeta, out_dbias, groups)
+    if groups == 1:
+        dx, dgamma, dbeta = cpu_ref.bn_bwd(dy, x, y, mean, invstd, gamma, act, alpha, train_stats, prev_act,
+                                           prev_alpha)
+    else:
+        ys = y.chunk(groups, 0) if y is not None else [None] * groups
+        parts = [cpu_ref.bn_bwd(d, xx, yy, mean[i], invstd[i], gamma, act, alpha, train_stats, prev_act, prev_alpha)
+                 for i, (d, xx, yy) in enumerate(zip(dy.chunk(groups, 0), x.chunk(groups, 0), ys))]
+        dx = torch.cat([p[0] for p in parts], 0)
+        dgamma, dbeta = sum(p[1] for p in parts), sum(p[2] for p in parts)
     if out_dgamma is not None:
         out_dgamma.copy_(dgamma)
         out_dbeta.copy_(dbeta)

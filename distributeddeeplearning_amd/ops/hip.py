@@ -45,13 +45,13 @@ def _sig(name, restype, *argtypes):
 _act_fwd = _sig("ddl_act_fwd", None, vp, vp, cl, ci, ci, ci, cf, vp)
 _act_bwd = _sig("ddl_act_bwd", None, vp, vp, vp, cl, ci, cf, vp)
 _colreduce_blocks = _sig("ddl_colreduce_blocks", ci, cl, ci)
-_bn_batch_stats = _sig("ddl_bn_batch_stats", None, vp, cl, ci, vp, vp, vp, vp, vp, cf, cf, ci, ci, vp, vp, vp, vp, vp)
-_bn_stats_from_part = _sig("ddl_bn_stats_from_part", None, vp, ci, cl, ci, vp, vp, vp, vp, cf, cf, ci, ci, vp, vp, vp, vp, vp)
+_bn_batch_stats = _sig("ddl_bn_batch_stats", None, vp, cl, ci, vp, vp, vp, vp, vp, cf, cf, ci, ci, vp, vp, vp, vp, ci, vp)
+_bn_stats_from_part = _sig("ddl_bn_stats_from_part", None, vp, ci, cl, ci, vp, vp, vp, vp, cf, cf, ci, ci, vp, vp, vp, vp, ci, vp)
 _bn_infer_affine = _sig("ddl_bn_infer_affine", None, vp, vp, vp, vp, cf, ci, vp, vp, vp, vp)
-_bn_apply = _sig("ddl_bn_apply", None, vp, vp, vp, vp, cl, ci, ci, ci, cf, vp)
+_bn_apply = _sig("ddl_bn_apply", None, vp, vp, vp, vp, cl, ci, ci, ci, cf, ci, vp)
 _bn_apply_infer = _sig("ddl_bn_apply_infer", None, vp, vp, vp, vp, vp, vp, cf, cl, ci, ci, ci, cf, vp)
 _bn_bwd = _sig("ddl_bn_bwd", None, vp, vp, vp, vp, cl, ci, vp, vp, vp, ci, cf, ci, ci, cf, vp, vp, vp, vp, vp, vp, ci,
-              vp)
+              ci, vp)
 _bias_grad = _sig("ddl_bias_grad", None, vp, cl, ci, ci, vp, vp, vp)
 _cast = _sig("ddl_cast_f32_bf16", None, vp, vp, cl, vp)
 _relayout = _sig("ddl_relayout_alt", None, vp, vp, vp, ci, cl, vp)
@@ -186,36 +186,56 @@ def spatial_pad(x, pt, pb, pl, pr):
 
 
 # ------------------------------------------------------------------------------ batch norm
-def _part(rows, Cp, device, ns=2):
+def _part(rows, Cp, device, ns=2, groups=1):
     nb = _colreduce_blocks(rows, Cp)
-    return torch.empty(nb * ns * Cp, dtype=torch.float32, device=device)
+    return torch.empty(nb * ns * Cp * groups, dtype=torch.float32, device=device)
 
 
-def bn_train_affine(x, gamma, beta, mm, mv, momentum, eps, bessel, update_moving=True):
-    _chk_act(x, "x")
+def _group_rows(x, groups):
+    """Rows per batch group: the batch (leading) dim splits into `groups` equal contiguous parts."""
     rows, Cp = _rows_c(x)
+    if groups < 1 or x.shape[0] % groups:
+        raise ValueError(f"batch {x.shape[0]} does not split into {groups} equal groups")
+    return rows // groups, Cp
+
+
+def bn_train_affine(x, gamma, beta, mm, mv, momentum, eps, bessel, update_moving=True, groups=1):
+    """-> scale, shift, mean, invstd: [Cp] each, or [groups][Cp] with per-group batch statistics (`groups` > 1:
+    the batch is `groups` equal contiguous parts, each normalised with its own statistics; the moving
+    statistics take one momentum update per group, in order)."""
+    _chk_act(x, "x")
+    rows, Cp = _group_rows(x, groups)
     for t, n in ((gamma, "gamma"), (beta, "beta"), (mm, "moving_mean"), (mv, "moving_var")):
         _chk_f32(t, Cp, n)
-    out = torch.empty(4, Cp, dtype=torch.float32, device=x.device)
-    part = _part(rows, Cp, x.device)
+    out = torch.empty(4, groups, Cp, dtype=torch.float32, device=x.device)
+    part = _part(rows, Cp, x.device, 2, groups)
     _bn_batch_stats(x.data_ptr(), rows, Cp, part.data_ptr(), gamma.data_ptr(), beta.data_ptr(), mm.data_ptr(),
                     mv.data_ptr(), momentum, eps, int(bool(bessel)), int(bool(update_moving)),
-                    out[0].data_ptr(), out[1].data_ptr(), out[2].data_ptr(), out[3].data_ptr(), _stream())
+                    out[0].data_ptr(), out[1].data_ptr(), out[2].data_ptr(), out[3].data_ptr(), groups, _stream())
     _done()
+    if groups == 1:
+        out = out.view(4, Cp)
     return out[0], out[1], out[2], out[3]
 
 
-def bn_train_affine_from_part(part, nb, rows, gamma, beta, mm, mv, momentum, eps, bessel, update_moving=True):
-    """`bn_train_affine` when the producer kernel already left per-block partial sums part[2][Cp][nb]."""
+def bn_train_affine_from_part(part, nb, rows, gamma, beta, mm, mv, momentum, eps, bessel, update_moving=True,
+                              groups=1):
+    """`bn_train_affine` when the producer kernel already left per-block partial sums part[2][Cp][nb].
+    `rows` = rows of the whole batch; with `groups` > 1 both `nb` and `rows` must split evenly (the
+    producer's blocks are batch-major and none straddles a group boundary -- the caller checks that)."""
     Cp = gamma.numel()
     _chk_f32(part, 2 * Cp * nb, "stats partials")
+    if nb % groups or rows % groups:
+        raise ValueError("partials / rows do not split into the batch groups")
     for t, n in ((gamma, "gamma"), (beta, "beta"), (mm, "moving_mean"), (mv, "moving_var")):
         _chk_f32(t, Cp, n)
-    out = torch.empty(4, Cp, dtype=torch.float32, device=gamma.device)
-    _bn_stats_from_part(part.data_ptr(), nb, rows, Cp, gamma.data_ptr(), beta.data_ptr(), mm.data_ptr(), mv.data_ptr(),
-                        momentum, eps, int(bool(bessel)), int(bool(update_moving)), out[0].data_ptr(),
-                        out[1].data_ptr(), out[2].data_ptr(), out[3].data_ptr(), _stream())
+    out = torch.empty(4, groups, Cp, dtype=torch.float32, device=gamma.device)
+    _bn_stats_from_part(part.data_ptr(), nb // groups, rows // groups, Cp, gamma.data_ptr(), beta.data_ptr(),
+                        mm.data_ptr(), mv.data_ptr(), momentum, eps, int(bool(bessel)), int(bool(update_moving)),
+                        out[0].data_ptr(), out[1].data_ptr(), out[2].data_ptr(), out[3].data_ptr(), groups, _stream())
     _done()
+    if groups == 1:
+        out = out.view(4, Cp)
     return out[0], out[1], out[2], out[3]
 
 
@@ -228,14 +248,14 @@ def bn_infer_affine(gamma, beta, mm, mv, eps):
     return out[0], out[1], out[2]
 
 
-def bn_apply(x, scale, shift, act=None, alpha=0.3, c_true=None):
+def bn_apply(x, scale, shift, act=None, alpha=0.3, c_true=None, groups=1):
     _chk_act(x, "x")
-    rows, Cp = _rows_c(x)
-    _chk_f32(scale, Cp, "scale")
-    _chk_f32(shift, Cp, "shift")
+    rows, Cp = _group_rows(x, groups)
+    _chk_f32(scale, Cp * groups, "scale")
+    _chk_f32(shift, Cp * groups, "shift")
     y = torch.empty_like(x)
     _bn_apply(x.data_ptr(), y.data_ptr(), scale.data_ptr(), shift.data_ptr(), rows, Cp,
-              Cp if c_true is None else c_true, ACT_CODE[act], alpha, _stream())
+              Cp if c_true is None else c_true, ACT_CODE[act], alpha, groups, _stream())
     _done()
     return y
 
@@ -254,7 +274,7 @@ def bn_apply_infer(x, gamma, beta, mm, mv, eps, act=None, alpha=0.3, c_true=None
 
 
 def bn_bwd(dy, x, y, mean, invstd, gamma, act, alpha, train_stats, prev_act=None, prev_alpha=0.3,
-           out_dgamma=None, out_dbeta=None, out_dbias=None):
+           out_dgamma=None, out_dbeta=None, out_dbias=None, groups=1):
     """`out_dbias` (fp32, <= C entries): also emit the bias gradient of the conv layer feeding this BN
     (= column sums of dx) from the same reduction pass (colreduce MODE 3)."""
     _chk_act(dy, "dy")
@@ -263,17 +283,18 @@ def bn_bwd(dy, x, y, mean, invstd, gamma, act, alpha, train_stats, prev_act=None
         raise ValueError(f"bn_bwd: dy {tuple(dy.shape)} vs x {tuple(x.shape)}")
     if ACT_CODE[act] != 0:
         _chk_act(y, "y")
-    rows, Cp = _rows_c(x)
-    for t, n in ((mean, "mean"), (invstd, "invstd"), (gamma, "gamma")):
-        _chk_f32(t, Cp, n)
+    rows, Cp = _group_rows(x, groups)
+    for t, n in ((mean, "mean"), (invstd, "invstd")):
+        _chk_f32(t, Cp * groups, n)
+    _chk_f32(gamma, Cp, "gamma")
     dev = x.device
     dx = torch.empty_like(x)
     if out_dbias is not None:
         _chk_f32(out_dbias, None, "dbias")
         if out_dbias.numel() > Cp:
             raise ValueError("bn_bwd: bias gradient longer than the channel dim")
-    part = _part(rows, Cp, dev, 5 if out_dbias is not None else 2)
-    coef = torch.empty(2, Cp, dtype=torch.float32, device=dev)
+    part = _part(rows, Cp, dev, 5 if out_dbias is not None else 2, groups)
+    coef = torch.empty(2, groups * Cp, dtype=torch.float32, device=dev)
     if out_dgamma is None:
         out_dgamma = torch.empty(Cp, dtype=torch.float32, device=dev)
         out_dbeta = torch.empty(Cp, dtype=torch.float32, device=dev)
@@ -283,7 +304,7 @@ def bn_bwd(dy, x, y, mean, invstd, gamma, act, alpha, train_stats, prev_act=None
     _bn_bwd(dy.data_ptr(), x.data_ptr(), _p(y), dx.data_ptr(), rows, Cp, mean.data_ptr(), invstd.data_ptr(),
             gamma.data_ptr(), ACT_CODE[act], alpha, int(bool(train_stats)), ACT_CODE[prev_act], prev_alpha,
             part.data_ptr(), out_dgamma.data_ptr(), out_dbeta.data_ptr(), coef[0].data_ptr(),
-            coef[1].data_ptr(), _p(out_dbias), 0 if out_dbias is None else out_dbias.numel(), _stream())
+            coef[1].data_ptr(), _p(out_dbias), 0 if out_dbias is None else out_dbias.numel(), groups, _stream())
     _done()
     return dx, out_dgamma, out_dbeta
 
@@ -935,7 +956,7 @@ def _igemm_call(src, wgt, bias, dst, g, mode, B, Hs, Ws, Cs, Hd, Wd, Nd, Nw, ss,
         elif stats_out is not None and PCONV_STATS and mul is None:
             nb = _pconv_units(choice[1], B)
             stats = torch.empty(2 * Nd * nb, dtype=torch.float32, device=src.device)
-            stats_out["part"], stats_out["nb"] = stats, nb
+            stats_out["part"], stats_out["nb"], stats_out["img"] = stats, nb, choice[1]["IMG"]
         _run_pconv(choice[1], *args, *tail, mul=mul, stats=stats, bn_infer=bn_infer)
     else:
         _run_igemm(src, wgt, bias, dst, g, mode, *tail, tile=choice[1])

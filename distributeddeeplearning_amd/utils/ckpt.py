@@ -42,13 +42,18 @@ def load_model(directory, device="cpu", keras224_compat: bool = True, bn_mode: s
     return net
 
 
-def save_training_state(path, net: Network, opt=None, extra: Optional[dict] = None):
+def save_training_state(path, net: Network, opt=None, extra: Optional[dict] = None, write: bool = True):
     sd = {"logical": net.logical_state(), "arch": net.spec.to_keras_json(), "extra": extra or {}}
     if opt is not None:
-        sd["opt"] = {"t": opt.t, "cfg": vars(opt.cfg),
-                     "m": None if opt.m is None else opt.m.detach().cpu(),
-                     "v": None if opt.v is None else opt.v.detach().cpu(),
+        # state_dict() reads the DEVICE step counter (graph replays never touch the host mirror) and, for a
+        # sharded optimizer, all-gathers the shards: every rank calls this, `write=False` on all but one
+        o = opt.state_dict()
+        sd["opt"] = {"t": o["t"], "cfg": o["cfg"],
+                     "m": None if o["m"] is None else o["m"].detach().cpu(),
+                     "v": None if o["v"] is None else o["v"].detach().cpu(),
                      "padded_layout": net.cpad}
+    if not write:
+        return
     tmp = str(path) + ".tmp"
     torch.save(sd, tmp)
     os.replace(tmp, path)             # atomic: a crash never leaves a torn checkpoint

@@ -248,6 +248,70 @@ def test_batchnorm(hip, shape, post, prev, train):
         close(dbias.cpu(), ref, rtol=2e-2, atol=2e-3 * float(dx_ref.abs().sum(tuple(range(dx_ref.dim() - 1))).max()))
 
 
+@pytest.mark.parametrize("shape", [(2000, 7, 7, 64), (2000, 4, 4, 128), (66, 5, 5, 19), (48, 24)])
+@pytest.mark.parametrize("post,prev", [("leaky", None), (None, "relu")])
+def test_batchnorm_batch_groups(hip, shape, post, prev):
+    """Per-half batch statistics (the DCGAN discriminator on [real ; fake], models/dcgan.py "split"): one grouped
+    launch == the layer applied to each half on its own (bitwise), and both match the fp32 oracle."""
+    Cc, Cp = shape[-1], hip.pad8(shape[-1])
+    torch.manual_seed(11)
+    x = r16(torch.randn(*shape) * 2 + 1)
+    x[shape[0] // 2:] = r16(x[shape[0] // 2:] * 0.3 - 2.0)          # the halves differ in distribution
+    if prev:
+        x = r16(cpu_ref.act_fwd(x, prev))
+    gamma, beta = torch.rand(Cc) + 0.5, torch.randn(Cc)
+
+    def p(t, fill=0.0):
+        o = torch.full((Cp,), fill)
+        o[:Cc] = t
+        return o.cuda()
+
+    gd, bd = p(gamma, 1.0), p(beta)
+    xd = dev(hip, x)
+    bessel = len(shape) == 4
+    mm2, mv2 = p(torch.zeros(Cc)), p(torch.ones(Cc), 1.0)
+    sc2, sh2, mean2, is2 = hip.bn_train_affine(xd, gd, bd, mm2, mv2, 0.99, 1e-3, bessel, True, groups=2)
+    assert sc2.shape == (2, Cp)
+    y2 = hip.bn_apply(xd, sc2, sh2, post, 0.3, Cc, groups=2)
+    dy = r16(torch.randn(*shape))
+    dyd = dev(hip, dy)
+    dbias = torch.zeros(Cc, device="cuda") if prev else None
+    dx2, dg2, db2 = hip.bn_bwd(dyd, xd, y2, mean2, is2, gd, post, 0.3, True, prev, out_dbias=dbias, groups=2)
+    # the same thing one half at a time
+    mm1, mv1 = p(torch.zeros(Cc)), p(torch.ones(Cc), 1.0)
+    h = shape[0] // 2
+    ys, dxs, dgs, dbs, dbi = [], [], [], [], []
+    y_ref, dx_ref, dg_ref, db_ref = [], [], 0, 0
+    for k in range(2):
+        xs, ds = xd[k * h:(k + 1) * h], dyd[k * h:(k + 1) * h]
+        sc, sh, mean, inv = hip.bn_train_affine(xs, gd, bd, mm1, mv1, 0.99, 1e-3, bessel, True)
+        assert torch.equal(sc, sc2[k]) and torch.equal(sh, sh2[k]) and torch.equal(mean, mean2[k])
+        y = hip.bn_apply(xs, sc, sh, post, 0.3, Cc)
+        ys.append(y)
+        b1 = torch.zeros(Cc, device="cuda") if prev else None
+        dx, dg, db = hip.bn_bwd(ds, xs, y, mean, inv, gd, post, 0.3, True, prev, out_dbias=b1)
+        dxs.append(dx), dgs.append(dg.double()), dbs.append(db.double()), dbi.append(b1)
+        xc, dc = x[k * h:(k + 1) * h], dy[k * h:(k + 1) * h]
+        m_, v_ = cpu_ref.bn_stats(xc)
+        i_ = torch.rsqrt(v_ + 1e-3)
+        yr = cpu_ref.bn_apply(xc, gamma * i_, beta - m_ * gamma * i_, post)
+        y_ref.append(yr)
+        a, b, c = cpu_ref.bn_bwd(dc, xc, r16(yr), m_, i_, gamma, post, 0.3, True, prev)
+        dx_ref.append(a)
+        dg_ref, db_ref = dg_ref + b, db_ref + c
+    assert torch.equal(y2, torch.cat(ys, 0)) and torch.equal(dx2, torch.cat(dxs, 0))
+    assert torch.equal(mm2, mm1) and torch.equal(mv2, mv1)          # two momentum updates, in group order
+    close(dg2.cpu().double(), (dgs[0] + dgs[1]).cpu(), rtol=1e-5, atol=1e-4 * float(dg2.abs().max()) + 1e-6)
+    close(db2.cpu().double(), (dbs[0] + dbs[1]).cpu(), rtol=1e-5, atol=1e-4 * float(db2.abs().max()) + 1e-6)
+    close(host(hip, y2, Cc), torch.cat(y_ref, 0))
+    close(host(hip, dx2, Cc), torch.cat(dx_ref, 0), rtol=3e-2)
+    close(dg2[:Cc].cpu(), dg_ref, rtol=2e-2)
+    close(db2[:Cc].cpu(), db_ref, rtol=2e-2)
+    if prev:
+        close(dbias.cpu().double(), (dbi[0] + dbi[1]).cpu().double(), rtol=1e-4,
+              atol=1e-4 * float(dbias.abs().max()) + 1e-5)
+
+
 @pytest.mark.parametrize("kind", ["relu", "sigmoid", "softplus", "tanh", "softsign", "leaky", "tanh01"])
 def test_activations(hip, kind):
     torch.manual_seed(6)

@@ -123,11 +123,13 @@ def test_gan_reference_exact_step_is_sign_sgd():
     assert torch.equal(t.D.S, S0)
 
 
-def test_gan_proper_mode_learns_and_generates_in_unit_range(tmp_path):
+def test_gan_default_mode_steps_and_generates_in_unit_range(tmp_path):
+    """Plumbing of one trainer (phases touch the right networks, outputs in range, checkpoint round trip).
+    Whether the game is actually adversarial is pinned in tests/test_gan_learning.py."""
     t = GANTrainer(GANConfig(batch=16, seed=0), "cpu")
     real = (torch.rand(16, 28, 28, 1, generator=torch.Generator().manual_seed(0)) > 0.7).float()
     losses = [tuple(float(v) for v in t.train_step(real)) for _ in range(6)]
-    assert all(np.isfinite(l).all() for l in losses) and losses[-1][0] < losses[0][0]
+    assert all(np.isfinite(l).all() for l in losses)
     img = t.generate(3)
     assert img.shape == (3, 28, 28, 1) and float(img.min()) >= 0 and float(img.max()) <= 1
     # G phase must not touch D's weights, D phase must not touch G's
@@ -142,6 +144,10 @@ def test_gan_proper_mode_learns_and_generates_in_unit_range(tmp_path):
     t2 = GANTrainer(GANConfig(batch=16, seed=0), "cpu")
     assert t2.load_checkpoint(tmp_path / "gan.ck") == 7
     assert all(torch.equal(a, b) for a, b in zip(t.G.logical_state().values(), t2.G.logical_state().values()))
+    # ... including the noise stream and the optimizer step: the next steps are identical
+    la, lb = t.train_step(real), t2.train_step(real)
+    assert float(la[0]) == float(lb[0]) and float(la[1]) == float(lb[1])
+    assert torch.equal(t.G.P, t2.G.P) and torch.equal(t.D.P, t2.D.P)
 
 
 def test_fused_activation_backward_matches_separate_pass_cpu(monkeypatch):

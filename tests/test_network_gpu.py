@@ -74,16 +74,17 @@ def test_generator_fwd_bwd():
     _cmp_grads(c, g)
 
 
-def test_gan_trainer_runs_and_learns():
-    t = GANTrainer(GANConfig(batch=256), "cuda")
+@pytest.mark.parametrize("policy", ["split", "inference", "mixed"])
+def test_gan_trainer_steps_in_every_bn_policy(policy):
+    """Plumbing only (finite losses, output range); learning is pinned in tests/test_gan_learning.py."""
+    t = GANTrainer(GANConfig(batch=256, bn_policy=policy), "cuda")
     torch.manual_seed(0)
     real = (torch.rand(256, 28, 28, 1) > 0.7).float()
     losses = []
-    for i in range(20):
+    for i in range(8):
         dl, gl = t.train_step(real)
         losses.append((float(dl), float(gl)))
     assert all(torch.isfinite(torch.tensor(l)).all() for l in losses)
-    assert losses[-1][0] < losses[0][0]          # D learns to separate real from fake
     img = t.generate(4)
     assert img.shape == (4, 28, 28, 1) and float(img.min()) >= 0 and float(img.max()) <= 1
 
