@@ -31,8 +31,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--config", default="dcgan28", choices=["dcgan28", "dcgan64", "classifier", "localsgd"])
     ap.add_argument("--batch", type=int, default=0, help="per-GPU real images per step (0 = config default)")
-    ap.add_argument("--graph", default="on", choices=["on", "off", "full"],
-                    help="hipGraph capture: on = segments around collectives, full = capture RCCL too")
+    ap.add_argument("--graph", default="auto", choices=["auto", "on", "off", "full"],
+                    help="hipGraph capture: on = graph segments around eagerly issued collectives, full = the "
+                         "collectives are captured too (one graph per step), auto = full if the start-up self-test "
+                         "of a captured all-reduce passes on every rank (parallel/selfcheck.py), else on")
     ap.add_argument("--comm-dtype", default="fp32", choices=["fp32", "bf16"])
     ap.add_argument("--comm", default="torch", choices=["torch", "rccl"],
                     help="collectives through torch.distributed (nccl == RCCL) or the native C++ RCCL communicator")
@@ -73,6 +75,23 @@ def main():
             dp = ddp.FlatDataParallel(comm_dtype=cd)
 
     from distributeddeeplearning_amd import benchmarks
+    from distributeddeeplearning_amd.parallel import selfcheck
+
+    # N > 1: prove the communicator spans N ranks, then let the captured-collective self-test pick the graph mode
+    seen = selfcheck.ranks_seen(dp, device)
+    captured_ok = None
+    if a.graph == "auto":
+        if dp is None or not on_gpu:
+            a.graph = "on" if on_gpu else "off"
+        else:
+            captured_ok = selfcheck.captured_collective_ok(dp, device, verbose=True)
+            a.graph = "full" if captured_ok else "on"
+    if dp is None:
+        backend = "none"
+    elif a.comm == "rccl" and on_gpu:
+        backend = "rccl-native"
+    else:
+        backend = "torch.distributed/" + torch.distributed.get_backend()
 
     def build_runner():
         r = benchmarks.make(a.config, device, dp, rank, a)
@@ -80,26 +99,31 @@ def main():
         return r
 
     # hipGraph capture next to a live RCCL group is the one step of setup that can fail for reasons
-    # outside the model code; if it does on ANY rank, every rank falls back to eager launches together
-    # (the measurement stays valid, only slower) instead of the job dying or ranks diverging.
-    runner, err = None, None
-    try:
-        runner = build_runner()
-    except Exception as e:          # noqa: BLE001 - re-raised below unless the eager fallback applies
-        err = e
-    failed = err is not None
-    if world > 1:
-        f = torch.tensor([1.0 if failed else 0.0], device=device)
-        torch.distributed.all_reduce(f, op=torch.distributed.ReduceOp.MAX)
-        failed = bool(f.item() > 0)
-    if failed:
-        if a.graph == "off" or not on_gpu:
-            raise err if err is not None else RuntimeError("setup failed on another rank")
-        print(f"[rank {rank}] graph setup failed ({err!r}); falling back to --graph off", file=sys.stderr, flush=True)
-        a.graph = "off"
+    # outside the model code; if it does on ANY rank, every rank steps down together (full -> on -> off:
+    # the measurement stays valid, only slower) instead of the job dying or ranks diverging.
+    chain = {"full": ["full", "on", "off"], "on": ["on", "off"], "off": ["off"]}[a.graph] if on_gpu else [a.graph]
+    runner = None
+    for k, mode in enumerate(chain):
+        a.graph = mode
+        err = None
+        try:
+            runner = build_runner()
+        except Exception as e:          # noqa: BLE001 - re-raised below unless a fallback applies
+            err = e
+        failed = err is not None
+        if world > 1:
+            f = torch.tensor([1.0 if failed else 0.0], device=device)
+            torch.distributed.all_reduce(f, op=torch.distributed.ReduceOp.MAX)
+            failed = bool(f.item() > 0)
+        if not failed:
+            break
         runner = None
-        torch.cuda.synchronize()
-        runner = build_runner()
+        if k + 1 == len(chain):
+            raise err if err is not None else RuntimeError("setup failed on another rank")
+        print(f"[rank {rank}] setup with --graph {mode} failed ({err!r}); falling back to --graph {chain[k + 1]}",
+              file=sys.stderr, flush=True)
+        if on_gpu:
+            torch.cuda.synchronize()
 
     def sync():
         if world > 1:
@@ -128,6 +152,11 @@ def main():
                "dtype": "bf16" if on_gpu else "fp32", "data": "synthetic", "config": info["config"]}
         out["config"]["parallelism"] = f"dp{world}"
         out["config"]["global_batch"] = info["images_per_step_per_rank"] * world
+        out["config"]["graph"] = a.graph
+        out["rccl_ranks_seen"] = seen
+        out["graph_mode_used"] = a.graph
+        out["captured_collective_selftest"] = captured_ok
+        out["comm_backend"] = backend
         out.update(info.get("extra", {}))
         print(json.dumps(out), flush=True)
     if torch.distributed.is_initialized():

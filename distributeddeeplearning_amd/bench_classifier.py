@@ -17,7 +17,7 @@ import numpy as np
 import torch
 
 from .config import get_space
-from .models.classifier import RandomModel
+from .models.classifier import RandomModel, ReplicaGroupStep
 from .models.ir import ModelSpec
 from .models.optim import OptimConfig
 from .models.search import CompiledSpec
@@ -60,10 +60,18 @@ class ClassifierBench:
         self.idx = [torch.randint(0, n_pool, (self.batch,), generator=g).to(self.device) for _ in range(8)]
         self.t = 0
         self.loss = None
+        # synchronous DP: the five networks' all-reduces overlap the next network's compute (ReplicaGroupStep)
+        self.group = None
+        if self.dp is not None and not self.local_sgd:
+            mode = "eager" if not use_graph else ("full" if self.args.graph == "full" else "segments")
+            self.group = ReplicaGroupStep(self.members, self.dp, self.idx[0], mode)
 
     def step(self):
         idx = self.idx[self.t % len(self.idx)]
         self.t += 1
+        if self.group is not None:
+            self.loss = self.group.step(idx)
+            return self.loss
         for m in self.members:
             self.loss = m.train_step(idx)
         return self.loss
@@ -74,7 +82,7 @@ class ClassifierBench:
                "per_gpu_batch": self.batch, "seq_len": None, "networks_per_step": 5,
                "step": "fwd + softmax-CE + bwd + Adam on each of the 5 replicas",
                "sync": (f"weight average every {self.args.avg_every} steps, overlapped" if self.local_sgd
-                        else "flat gradient all-reduce per network per step"),
+                        else "flat gradient all-reduce per network per step, overlapped with the next network"),
                "graph": self.args.graph}
         return {"metric": f"{name}_train_images_per_sec", "images_per_step_per_rank": self.batch * 5,
                 "config": cfg, "extra": {"loss": float(self.loss)}}

@@ -30,7 +30,8 @@ class _DCGAN:
                 "images_per_step_per_rank": self.batch,
                 "config": {"model": f"DCGAN {self.size}x{self.size} (GAN_distributed generator+discriminator)",
                            "per_gpu_batch": self.batch, "seq_len": None,
-                           "step": "D update on [B real; B fake] + G update on B noise, Adam 2e-4, BN batch stats",
+                           "step": "D update on [B real; B fake] + G update on B noise, Adam 2e-4, "
+                                   f"BN policy {self.t.cfg.bn_policy} (batch statistics, per half in D)",
                            "graph": self.args.graph},
                 "extra": {"d_loss": float(self.t.d_loss), "g_loss": float(self.t.g_loss)}}
 

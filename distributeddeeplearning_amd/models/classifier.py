@@ -147,8 +147,14 @@ class RandomModel:
                 idx = perm[i:i + B]
                 loss = self.train_step(idx)
                 acc = acc + loss.detach() * idx.numel()      # Keras: sample-weighted epoch mean
-            losses.append(float(acc) / n)
-        return losses
+            losses.append(acc / n)
+        if self.dp is not None and self.dp.world > 1:
+            # every rank must take the same early-stop decision or the ones that stay would wait forever in
+            # their next collective: the decision is made on the rank-averaged epoch losses
+            t = torch.stack(losses).float()
+            self.dp.all_reduce_mean_(t)
+            return [float(v) for v in t]
+        return [float(v) for v in losses]
 
     def train(self):
         sp = self.space
@@ -157,12 +163,17 @@ class RandomModel:
             self.history.append(hist)
             if self.verbose:
                 print(i, hist, flush=True)
-            if not all(math.isfinite(h) for h in hist):
-                break
-            if 1 - (hist[-1] / hist[0]) < sp.early_stop_rate:
+            # the reference's test, literally (DDL.py:95): with a NaN loss `1 - nan < rate` is False and it trains on
+            if hist[0] == 0 or 1 - (hist[-1] / hist[0]) < sp.early_stop_rate:
                 break
         if self.averager is not None:
             self.averager.finish()
+
+    def sync_bn_stats(self):
+        """Synchronous DP exchanges gradients only: average the BN moving statistics over the ranks before they
+        are read by anything rank-dependent (evaluation, export).  A collective: every rank calls it."""
+        if self.dp is not None and self.dp.world > 1 and self.averager is None:
+            self.dp.all_reduce_mean_(self.net.S)
 
     # ------------------------------------------------------------------ inference
     def predict(self, x=None, index: Optional[torch.Tensor] = None, batch_size: int = 4096) -> torch.Tensor:
@@ -181,6 +192,7 @@ class RandomModel:
         return torch.cat(outs, 0)
 
     def get_accuracy(self, validation_data: Optional[Tuple[torch.Tensor, torch.Tensor]] = None) -> float:
+        self.sync_bn_stats()
         if validation_data is None:
             idx = self.sample.val_idx
             if idx.numel() == 0:
@@ -198,5 +210,96 @@ class RandomModel:
 
     def save(self, directory: Optional[str] = None):
         from ..utils import ckpt
+        self.sync_bn_stats()
         d = directory or self.space.model_save_directory
         return ckpt.save_model(self.net, f"{d}/model{self.number}")
+
+
+class ReplicaGroupStep:
+    """One synchronous data-parallel step of SEVERAL networks (BASELINE config 2: the five replicas) with the
+    flat gradient all-reduces taken off the critical path.
+
+    Issued one network at a time, a step is fwd/bwd_0, AR_0, update_0, fwd/bwd_1, AR_1, ...: five exposed
+    collectives, each a latency-bound 0.2-3.5 MB message on xGMI.  Here network i's all-reduce runs on a
+    communication stream while network i+1 computes, and the optimizer updates follow once at the end:
+
+        main:  A_0 | A_1 | A_2 | A_3 | A_4 |        wait | U_0 U_1 U_2 U_3 U_4
+        comm:        AR_0  AR_1  AR_2  AR_3  AR_4 ---^
+
+    so only the last collective is exposed.  `mode`:
+      * "full"     -- the whole picture above is ONE hipGraph (collectives captured, the fork/join become graph
+                      branches); chosen when `parallel.selfcheck.captured_collective_ok` passed on every rank;
+      * "segments" -- five captured A_i graphs, eager collectives on the comm stream, one captured update graph;
+      * "eager"    -- no graphs (CPU / gloo plumbing, debugging).
+    All three produce identical parameters (tests/test_dist_gloo.py compares against the serial order).
+    """
+
+    def __init__(self, members: List[RandomModel], dp, idx: torch.Tensor, mode: str = "eager"):
+        if mode not in ("eager", "segments", "full"):
+            raise ValueError(mode)
+        self.members, self.dp, self.mode = members, dp, mode
+        self.idx = idx.clone()
+        self.on_gpu = idx.is_cuda
+        self.comm = torch.cuda.Stream() if self.on_gpu else None
+        self.losses = None
+        self.graphs = None
+        if mode == "eager" or not self.on_gpu:
+            self.mode = "eager"
+            return
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):                    # warm-up (really trains): autotuning, allocator, tables
+            self._body()
+        torch.cuda.current_stream().wait_stream(side)
+        hipgraph.quiesce()
+        pool = torch.cuda.graph_pool_handle()
+        if mode == "full":
+            g, self.losses = hipgraph.capture(self._body, pool)
+            self.graphs = [g]
+        else:
+            self.graphs, self.losses = [], []
+            for m in members:
+                g, loss = hipgraph.capture(lambda m=m: m._fwd_bwd(self.idx), pool)
+                self.graphs.append(g)
+                self.losses.append(loss)
+            g, _ = hipgraph.capture(self._updates, pool)
+            self.graphs.append(g)
+
+    def _fork_allreduce(self, m):
+        if self.comm is None:
+            self.dp.all_reduce_sum_(m.net.G)
+            return
+        self.comm.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(self.comm):
+            self.dp.all_reduce_sum_(m.net.G)
+
+    def _join(self):
+        if self.comm is not None:
+            torch.cuda.current_stream().wait_stream(self.comm)
+
+    def _updates(self):
+        for m in self.members:
+            m._update()
+
+    def _body(self):
+        losses = []
+        for m in self.members:
+            losses.append(m._fwd_bwd(self.idx))
+            self._fork_allreduce(m)
+        self._join()
+        self._updates()
+        return losses
+
+    def step(self, idx: torch.Tensor):
+        self.idx.copy_(idx)
+        if self.mode == "eager":
+            self.losses = self._body()
+        elif self.mode == "full":
+            self.graphs[0].replay()
+        else:
+            for g, m in zip(self.graphs[:-1], self.members):
+                g.replay()
+                self._fork_allreduce(m)
+            self._join()
+            self.graphs[-1].replay()
+        return self.losses[-1]

@@ -119,10 +119,15 @@ class DeviceRNG:
             return {"philox": self.state.detach().cpu()}
         return {"generator": self.gen.get_state()}
 
-    def load_state_dict(self, sd):
+    def load_state_dict(self, sd, keep_seed: bool = False):
+        """`keep_seed`: restore the stream position only (a state saved by ANOTHER rank: this rank keeps its own
+        seed so the ranks' noise stays different)."""
         if self.device.type == "cuda":
+            seed = self.state[0].clone()
             self.state.copy_(sd["philox"])
-        else:
+            if keep_seed:
+                self.state[0] = seed
+        elif not keep_seed:
             self.gen.set_state(sd["generator"])
 
 
@@ -259,6 +264,8 @@ class GANTrainer:
         extra = {"iteration": iteration, "rng": self.rng.state_dict(), "bn_policy": self.cfg.bn_policy}
         ckpt.save_training_state(str(path) + ".G", self.G, self.optG, extra, write)
         ckpt.save_training_state(str(path) + ".D", self.D, self.optD, {"iteration": iteration}, write)
+        if self.dp is not None and self.dp.world > 1:       # every rank has its own noise stream: one small file each
+            torch.save(self.rng.state_dict(), f"{path}.rng{self.dp.rank}")
         if write:
             with open(path, "w") as f:
                 f.write(str(iteration))
@@ -267,8 +274,12 @@ class GANTrainer:
         from ..utils import ckpt
         extra = ckpt.load_training_state(str(path) + ".G", self.G, self.optG)
         ckpt.load_training_state(str(path) + ".D", self.D, self.optD)
-        if "rng" in extra:
-            self.rng.load_state_dict(extra["rng"])
+        import os
+        own = f"{path}.rng{self.dp.rank}" if (self.dp is not None and self.dp.world > 1) else None
+        if own and os.path.exists(own):
+            self.rng.load_state_dict(torch.load(own, map_location="cpu", weights_only=True))
+        elif "rng" in extra:
+            self.rng.load_state_dict(extra["rng"], keep_seed=own is not None)
         return int(extra["iteration"])
 
     def generate(self, n: int, training_bn: Optional[bool] = None):

@@ -166,3 +166,92 @@ def sharded_adam(rank, world, port, out):
         res.append(float((a.P - b.P).abs().max()))
     np.save(f"{out}/zero{rank}.npy", np.array(res))
     dist.destroy_process_group()
+
+
+def _members(dp, rank, n_members=3, lr=0.05):
+    """Small MLP ensemble members on a shared synthetic pool (each rank its own data)."""
+    from distributeddeeplearning_amd import config
+    from distributeddeeplearning_amd.models.classifier import RandomModel
+    from distributeddeeplearning_amd.models.optim import OptimConfig
+    from distributeddeeplearning_amd.models.search import CompiledSpec
+    from distributeddeeplearning_amd.models import ir
+    from distributeddeeplearning_amd.utils.data import Data
+    data = Data("cpu", channels=1, n_train=96, n_test=16, synthetic=True, seed=rank)
+    space = config.get_space("ddl_normal4", ["data_train_size=64", "batch_size=16", "epochs=6", "early_stop_rate=0.05"])
+    members = []
+    for i in range(n_members):
+        spec = ir.ModelSpec(f"m{i}", [ir.Input("in", (28, 28, 1))])
+        for l in (ir.Flatten("f"), ir.Dense("d1", 8 + 4 * i, "tanh"), ir.BatchNorm("bn"), ir.Dense("o", 10, "softmax")):
+            spec.append(l)
+        comp = CompiledSpec(spec, OptimConfig.keras("sgd", lr), "categorical_crossentropy")
+        m = RandomModel(data, data.get_random_sample(64, seed=5 + rank), space, comp, "cpu", number=i, seed=i,
+                        dp=dp, use_graph=False, verbose=False)
+        dp.broadcast_(m.net.P, m.net.S)
+        members.append(m)
+    return data, members
+
+
+def replica_group_step(rank, world, port, out):
+    """ReplicaGroupStep (all-reduces forked while the next network computes, updates at the end) ==
+    the serial order fwd/bwd, all-reduce, update per network."""
+    dp = _init(rank, world, port)
+    from distributeddeeplearning_amd.models.classifier import ReplicaGroupStep
+    _, a = _members(dp, rank)
+    _, b = _members(dp, rank)
+    gen = torch.Generator().manual_seed(50 + rank)
+    group = ReplicaGroupStep(a, dp, torch.zeros(16, dtype=torch.int64), "eager")
+    for _ in range(3):
+        idx = torch.randint(0, 96, (16,), generator=gen)
+        group.step(idx)
+        for m in b:
+            m._step_body(idx)
+    diff = max(float((x.net.P - y.net.P).abs().max()) for x, y in zip(a, b))
+    np.save(f"{out}/rg{rank}.npy", np.concatenate([np.array([diff]), torch.cat([m.net.P for m in a]).numpy()]))
+    dist.destroy_process_group()
+
+
+def dp_early_stop(rank, world, port, out):
+    """Ranks whose LOCAL losses would stop at different rounds must still leave `train()` together."""
+    dp = _init(rank, world, port)
+    _, ms = _members(dp, rank, n_members=1, lr=0.2 if rank == 0 else 0.2)
+    m = ms[0]
+    # make the ranks' data differ in difficulty: rank 1 trains on shuffled labels (its local loss plateaus at once)
+    if rank == 1:
+        perm = torch.randperm(m.data.train_y.shape[0], generator=torch.Generator().manual_seed(1))
+        m.data.train_y = m.data.train_y[perm]
+    m.train()
+    m.sync_bn_stats()
+    np.save(f"{out}/es{rank}.npy", np.array([len(m.history)] + [h for r in m.history for h in r]))
+    np.save(f"{out}/esS{rank}.npy", m.net.S.numpy())
+    dist.destroy_process_group()
+
+
+def sharded_checkpoint(rank, world, port, out):
+    """ZeRO-1 optimizer: save (all ranks, shards gathered) -> load into a fresh trainer -> same continuation."""
+    dp = _init(rank, world, port)
+    from distributeddeeplearning_amd.models.dcgan import GANConfig, GANTrainer
+    real = torch.rand(4, 28, 28, 1, generator=torch.Generator().manual_seed(rank))
+    a = GANTrainer(GANConfig(batch=4, seed=3, base=8), "cpu", dp, rank, shard_optimizer=True)
+    for _ in range(2):
+        a.train_step(real)
+    path = f"{out}/gan.ckpt"
+    a.save_checkpoint(path, 2, write=rank == 0)
+    dp.barrier()
+    b = GANTrainer(GANConfig(batch=4, seed=77, base=8), "cpu", dp, rank, shard_optimizer=True)
+    assert b.load_checkpoint(path) == 2
+    for _ in range(2):
+        a.train_step(real)
+        b.train_step(real)
+    d = max(float((a.G.P - b.G.P).abs().max()), float((a.D.P - b.D.P).abs().max()),
+            float((a.G.S - b.G.S).abs().max()))
+    np.save(f"{out}/sck{rank}.npy", np.array([d]))
+    dist.destroy_process_group()
+
+
+def selfcheck_cpu(rank, world, port, out):
+    dp = _init(rank, world, port)
+    from distributeddeeplearning_amd.parallel import selfcheck
+    seen = selfcheck.ranks_seen(dp, "cpu")
+    ok = selfcheck.captured_collective_ok(dp, "cpu")           # no device: the verdict is "no", without any collective
+    np.save(f"{out}/sc{rank}.npy", np.array(seen + [int(ok)]))
+    dist.destroy_process_group()

@@ -48,6 +48,19 @@ def test_bench_two_ranks_gloo():
     assert d["n_gpus"] == 2 and d["config"]["parallelism"] == "dp2" and d["config"]["global_batch"] == 80
 
 
+def test_bench_two_ranks_gloo_classifier_reports_comm_fields():
+    """Sync-DP classifier (ReplicaGroupStep) on 2 gloo ranks; the record proves what the run really used."""
+    env = dict(os.environ, OMP_NUM_THREADS="2")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", "29633", "bench.py", "--gpus", "2",
+                        "--device", "cpu", "--steps", "2", "--warmup", "1", "--batch", "8", "--config", "classifier"],
+                       cwd=ROOT, capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["n_gpus"] == 2 and d["rccl_ranks_seen"] == [0, 1] and d["graph_mode_used"] == "off"
+    assert d["comm_backend"] == "torch.distributed/gloo" and d["captured_collective_selftest"] is None
+
+
 def test_graft_entry_build():
     r = _run(["-c", "import __graft_entry__ as g; g.build()"])
     assert r.returncode == 0, r.stderr[-2000:]

@@ -75,3 +75,29 @@ def test_gan_data_parallel_replicas_stay_identical(tmp_path, sharded):
     a, b = np.load(tmp_path / "gan0.npy"), np.load(tmp_path / "gan1.npy")
     assert np.array_equal(a[:-2], b[:-2])                      # weights identical after 2 DP steps
     assert np.isfinite(a).all() and not np.array_equal(a[-2:], b[-2:])     # local losses differ (own shard)
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_replica_group_step_equals_serial_order(tmp_path, world):
+    _spawn(W.replica_group_step, tmp_path, world=world)
+    rs = [np.load(tmp_path / f"rg{r}.npy") for r in range(world)]
+    assert all(r[0] == 0.0 for r in rs)                        # overlapped schedule == serial schedule, exactly
+    assert all(np.array_equal(rs[0][1:], r[1:]) for r in rs)   # replicas identical across ranks
+
+
+def test_dp_early_stop_is_a_collective_decision(tmp_path):
+    _spawn(W.dp_early_stop, tmp_path)
+    a, b = np.load(tmp_path / "es0.npy"), np.load(tmp_path / "es1.npy")
+    assert np.array_equal(a, b) and a[0] >= 1                  # same rounds, same (rank-averaged) loss history
+    assert np.array_equal(np.load(tmp_path / "esS0.npy"), np.load(tmp_path / "esS1.npy"))   # BN stats averaged
+
+
+def test_sharded_optimizer_checkpoint_round_trip(tmp_path):
+    _spawn(W.sharded_checkpoint, tmp_path)
+    assert all(float(np.load(tmp_path / f"sck{r}.npy")[0]) == 0.0 for r in range(2))
+
+
+def test_selfcheck_ranks_seen_gloo(tmp_path):
+    _spawn(W.selfcheck_cpu, tmp_path, world=4)
+    for r in range(4):
+        assert np.load(tmp_path / f"sc{r}.npy").tolist() == [0, 1, 2, 3, 0]

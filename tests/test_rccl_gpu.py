@@ -83,3 +83,53 @@ def test_graphed_dp_step_with_one_rank_group(sharded):
         assert abs(float(la[1]) - float(lb[1])) < 2e-2 * max(1.0, abs(float(lb[1])))
     finally:
         dist.destroy_process_group()
+
+
+def test_captured_collective_selftest_and_replica_group_modes():
+    """The start-up self-test that picks `--graph full` (parallel/selfcheck.py) on a 1-rank RCCL group, for both
+    communicator back-ends, and the three ReplicaGroupStep modes producing identical parameters."""
+    import os
+    import torch.distributed as dist
+    from distributeddeeplearning_amd.models.classifier import ReplicaGroupStep
+    from distributeddeeplearning_amd.parallel import ddp, selfcheck
+    from distributeddeeplearning_amd.parallel.rccl import RcclCommunicator
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29678")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda:0"))
+    try:
+        dp = ddp.FlatDataParallel()
+        assert selfcheck.ranks_seen(dp, "cuda:0") == [0]
+        assert selfcheck.captured_collective_ok(dp, "cuda:0", verbose=True) is True
+        native = RcclCommunicator.from_env("cuda:0")
+        assert selfcheck.captured_collective_ok(native, "cuda:0", verbose=True) is True
+        native.close()
+
+        class Broken:                       # a communicator whose captured replay silently does nothing
+            rank, world = 0, 1
+
+            def all_reduce_sum_(self, t):
+                if torch.cuda.is_current_stream_capturing():
+                    return
+                t.mul_(2.0)
+        assert selfcheck.captured_collective_ok(Broken(), "cuda:0") is False
+
+        from bench_helpers import small_members
+        results = {}
+        for mode in ("eager", "segments", "full"):
+            members, idxs = small_members(dp)
+            group = ReplicaGroupStep(members, dp, idxs[0], mode)
+            for i in range(4):
+                group.step(idxs[i % len(idxs)])
+            torch.cuda.synchronize()
+            results[mode] = torch.cat([m.net.P for m in members]).clone()
+        # graph modes run one warm-up step more than eager: compare them with each other, eager after 5 steps
+        members, idxs = small_members(dp)
+        group = ReplicaGroupStep(members, dp, idxs[0], "eager")
+        group.step(idxs[0])
+        for i in range(4):
+            group.step(idxs[i % len(idxs)])
+        torch.cuda.synchronize()
+        eager5 = torch.cat([m.net.P for m in members])
+        assert torch.equal(results["segments"], results["full"])
+        assert torch.equal(results["full"], eager5)
+    finally:
+        dist.destroy_process_group()
