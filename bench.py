@@ -36,8 +36,10 @@ def main():
                          "collectives are captured too (one graph per step), auto = full if the start-up self-test "
                          "of a captured all-reduce passes on every rank (parallel/selfcheck.py), else on")
     ap.add_argument("--comm-dtype", default="fp32", choices=["fp32", "bf16"])
-    ap.add_argument("--comm", default="torch", choices=["torch", "rccl"],
-                    help="collectives through torch.distributed (nccl == RCCL) or the native C++ RCCL communicator")
+    ap.add_argument("--comm", default="torch", choices=["torch", "rccl", "p2p"],
+                    help="gradient all-reduce through torch.distributed (nccl == RCCL), the native C++ RCCL "
+                         "communicator, or the xGMI direct all-reduce kernel with the optimizer fused into its "
+                         "epilogue (csrc/comm/p2p_allreduce.hip; validated against RCCL at start-up, RCCL if it fails)")
     ap.add_argument("--avg-every", type=int, default=8, help="local-SGD averaging period (config localsgd)")
     ap.add_argument("--zero", action="store_true",
                     help="dcgan configs, N>1: reduce-scatter + sharded update + all-gather instead of all-reduce")
@@ -73,6 +75,23 @@ def main():
             dp = RcclCommunicator.from_env(device, comm_dtype=cd)
         else:
             dp = ddp.FlatDataParallel(comm_dtype=cd)
+        if a.comm == "p2p" and on_gpu:
+            from distributeddeeplearning_amd.parallel.p2p import P2PAllReduce
+            p2p, p2p_ok = None, False
+            try:
+                p2p = P2PAllReduce(dp, device, 1 << 22)          # 16 MB of fp32: the largest flat gradient is 4.3 MB
+            except Exception as e:      # noqa: BLE001 - fall back below, on every rank together
+                print(f"[rank {rank}] xGMI all-reduce unavailable: {e!r}", file=sys.stderr, flush=True)
+            f = torch.tensor([0.0 if p2p is not None else 1.0], device=device)
+            torch.distributed.all_reduce(f, op=torch.distributed.ReduceOp.MAX)
+            if float(f.item()) == 0.0:
+                p2p_ok = p2p.validate(1 << 20)
+            if p2p_ok:
+                dp = p2p
+            else:
+                a.comm = "torch"
+                if rank == 0:
+                    print("xGMI all-reduce failed its validation against RCCL: using RCCL", file=sys.stderr, flush=True)
 
     from distributeddeeplearning_amd import benchmarks
     from distributeddeeplearning_amd.parallel import selfcheck
@@ -83,6 +102,8 @@ def main():
     if a.graph == "auto":
         if dp is None or not on_gpu:
             a.graph = "on" if on_gpu else "off"
+        elif getattr(dp, "captures_safely", False):
+            a.graph = "full"             # the xGMI kernel is an ordinary launch: nothing of RCCL inside the graph
         else:
             captured_ok = selfcheck.captured_collective_ok(dp, device, verbose=True)
             a.graph = "full" if captured_ok else "on"
@@ -90,6 +111,8 @@ def main():
         backend = "none"
     elif a.comm == "rccl" and on_gpu:
         backend = "rccl-native"
+    elif a.comm == "p2p" and on_gpu:
+        backend = "xgmi-p2p all-reduce + fused optimizer (bootstrap torch.distributed/" + torch.distributed.get_backend() + ")"
     else:
         backend = "torch.distributed/" + torch.distributed.get_backend()
 

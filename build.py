@@ -73,7 +73,7 @@ def build_comm(force=False):
     srcs = sorted((CSRC / "comm").glob("*.cpp")) + sorted((CSRC / "comm").glob("*.hip"))
     if not srcs:
         return None
-    hdrs = sorted((CSRC / "comm").glob("*.h"))
+    hdrs = sorted((CSRC / "comm").glob("*.h")) + sorted((CSRC / "hip").glob("*.h"))     # p2p shares optim_update.h
     lib = OUT / "libddl_comm.so"
     if force or any(_newer(s, lib, hdrs) for s in srcs):
         _run([HIPCC, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-shared", "-fvisibility=hidden",

@@ -1,6 +1,7 @@
 // Fused loss kernels (softmax-CE / softmax-MSE / sigmoid-BCE / Dense(K->1)+BCE forward+backward),
 // metrics, the flat multi-tensor optimizers and the Philox noise generator.
 #include "common.h"
+#include "optim_update.h"
 
 #define LB 256
 
@@ -294,59 +295,16 @@ __global__ void optim_kernel(float4* __restrict__ P, const float4* __restrict__ 
                              float4* __restrict__ Vo, uint2* __restrict__ Pc, int* __restrict__ step,
                              long n4, int kind, float lr, float b1, float b2, float eps, float rho,
                              float gscale, const float4* __restrict__ avg, float avg_w) {
-    float lr_t = lr, lr_2 = lr;
-    if (kind == 0) {
-        float t = (float)step[0];
-        lr_t = lr * sqrtf(1.f - powf(b2, t)) / (1.f - powf(b1, t));
-    } else if (kind == 3) {
-        lr_t = lr * sqrtf(1.f - b2) / (1.f - b1);
-        lr_2 = lr * sqrtf(1.f - b2 * b2) / (1.f - b1 * b1);
-    }
+    const OptimHyper h = optim_prepare(kind, lr, b1, b2, eps, rho, step);
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
-        float4 p4 = P[i], g4 = G[i];
-        float p[4] = {p4.x, p4.y, p4.z, p4.w};
-        float g[4] = {g4.x * gscale, g4.y * gscale, g4.z * gscale, g4.w * gscale};
-        if (kind == 0) {
-            float4 m4 = Mo[i], v4 = Vo[i];
-            float m[4] = {m4.x, m4.y, m4.z, m4.w}, v[4] = {v4.x, v4.y, v4.z, v4.w};
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                m[j] = b1 * m[j] + (1.f - b1) * g[j];
-                v[j] = b2 * v[j] + (1.f - b2) * g[j] * g[j];
-                p[j] -= lr_t * m[j] / (sqrtf(v[j]) + eps);
-            }
-            Mo[i] = make_float4(m[0], m[1], m[2], m[3]);
-            Vo[i] = make_float4(v[0], v[1], v[2], v[3]);
-        } else if (kind == 1) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) p[j] -= lr * g[j];
-        } else if (kind == 2) {
-            float4 v4 = Vo[i];
-            float v[4] = {v4.x, v4.y, v4.z, v4.w};
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                v[j] = rho * v[j] + (1.f - rho) * g[j] * g[j];
-                p[j] -= lr * g[j] / (sqrtf(v[j]) + eps);
-            }
-            Vo[i] = make_float4(v[0], v[1], v[2], v[3]);
-        } else {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                float m1 = (1.f - b1) * g[j], v1 = (1.f - b2) * g[j] * g[j];
-                p[j] -= lr_t * m1 / (sqrtf(v1) + eps);
-                float m2 = b1 * m1 + (1.f - b1) * g[j], v2 = b2 * v1 + (1.f - b2) * g[j] * g[j];
-                p[j] -= lr_2 * m2 / (sqrtf(v2) + eps);
-            }
-        }
-        if (avg) {
-            float4 a = avg[i];
-            p[0] = (1.f - avg_w) * p[0] + avg_w * a.x; p[1] = (1.f - avg_w) * p[1] + avg_w * a.y;
-            p[2] = (1.f - avg_w) * p[2] + avg_w * a.z; p[3] = (1.f - avg_w) * p[3] + avg_w * a.w;
-        }
-        P[i] = make_float4(p[0], p[1], p[2], p[3]);
-        if (Pc) Pc[i] = make_uint2(pack2bf(p[0], p[1]), pack2bf(p[2], p[3]));
+        float4 g4 = G[i];
+        g4.x *= gscale; g4.y *= gscale; g4.z *= gscale; g4.w *= gscale;
+        optim_update4(h, P, Mo, Vo, Pc, i, g4, avg, avg_w);
     }
 }
+
+// Advance a device-side step counter by itself (the fused all-reduce + update kernel of csrc/comm reads it).
+DDL_API void ddl_step_inc(int* step, hipStream_t s) { step_inc_kernel<<<1, 1, 0, s>>>(step); }
 
 DDL_API void ddl_optim_step(float* P, const float* G, float* M, float* V, void* Pc, int* step, long n, int kind,
                             float lr, float b1, float b2, float eps, float rho, float gscale, const float* avg,

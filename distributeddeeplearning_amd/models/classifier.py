@@ -74,11 +74,25 @@ class RandomModel:
         return loss
 
     def _update(self):
-        if self._sync_dp:
+        if self._fused_dp:
+            pass                                          # done by the fused all-reduce kernel (_reduce)
+        elif self._sync_dp:
             self.opt.step(self.dp.grad_scale)
         else:
             self.opt.step()
         self.net.release()
+
+    def _reduce(self):
+        """Synchronous DP: ONE flat collective per step -- or one fused all-reduce + update kernel (parallel/p2p.py)."""
+        if self._fused_dp:
+            self.opt.step_allreduce_fused(self.dp)
+        else:
+            self.dp.all_reduce_sum_(self.net.G)
+
+    @property
+    def _fused_dp(self):
+        return (self.dp is not None and self.averager is None and self.net.on_gpu
+                and getattr(self.dp, "supports_fused_update", False))
 
     @property
     def _sync_dp(self):
@@ -86,8 +100,8 @@ class RandomModel:
 
     def _step_body(self, idx):
         loss = self._fwd_bwd(idx)
-        if self._sync_dp:
-            self.dp.all_reduce_sum_(self.net.G)          # ONE flat collective per step
+        if self._sync_dp or self._fused_dp:
+            self._reduce()
         self._update()
         return loss
 
@@ -104,7 +118,7 @@ class RandomModel:
             torch.cuda.current_stream().wait_stream(side)
             hipgraph.quiesce()
             pool = torch.cuda.graph_pool_handle()
-            if self._sync_dp:
+            if self._sync_dp and not getattr(self.dp, "captures_safely", False):
                 ga, self._static_loss = hipgraph.capture(lambda: self._fwd_bwd(self._idx), pool)
                 gb, _ = hipgraph.capture(self._update, pool)
                 self._graph = (ga, gb)
@@ -267,11 +281,11 @@ class ReplicaGroupStep:
 
     def _fork_allreduce(self, m):
         if self.comm is None:
-            self.dp.all_reduce_sum_(m.net.G)
+            m._reduce()
             return
         self.comm.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(self.comm):
-            self.dp.all_reduce_sum_(m.net.G)
+            m._reduce()
 
     def _join(self):
         if self.comm is not None:

@@ -157,6 +157,11 @@ class GANTrainer:
         if self.sharded:        # reduce-scatter / shard update / all-gather instead of all-reduce (ZeRO-1)
             self.optG = ShardedFlatOptimizer(self.G, ocfg, dp)
             self.optD = ShardedFlatOptimizer(self.D, ocfg, dp)
+        # xGMI direct all-reduce with the optimizer in its epilogue (parallel/p2p.py): reduce + 1/world + update
+        # of a network are ONE kernel, so the separate optimizer launches disappear from the step
+        self.fused = bool(dp is not None and not self.sharded and self.G.on_gpu
+                          and getattr(dp, "supports_fused_update", False))
+        self._comm_stream = torch.cuda.Stream() if (dp is not None and self.G.on_gpu) else None
 
     # ---- the two phases -------------------------------------------------------------------
     def _d_head(self, feat, n_first, label_first, label_second, want_dx, want_dw):
@@ -215,7 +220,8 @@ class GANTrainer:
 
     def phase_b(self, B):
         """D update, then G forward / D dgrad / G backward (local gradients in G.G)."""
-        self.optD.step(self._gscale)
+        if not self.fused:
+            self.optD.step(self._gscale)
         return self.g_backward(B)
 
     def phase_b1(self, B):
@@ -223,27 +229,58 @@ class GANTrainer:
         return self.g_forward(B)
 
     def phase_b2(self, B):
-        self.optD.step(self._gscale)
+        if not self.fused:
+            self.optD.step(self._gscale)
         return self.g_backward(B, self._fake)
 
     def phase_c(self):
-        self.optG.step(self._gscale)
+        if not self.fused:
+            self.optG.step(self._gscale)
         self.D.release()
         self.G.release()
+
+    def reduce_D(self):
+        """Average D's gradients over the ranks (and, fused, update D): one collective / one kernel."""
+        if self.dp is None or self.sharded:
+            return
+        if self.fused:
+            self.optD.step_allreduce_fused(self.dp)
+        else:
+            self.dp.all_reduce_sum_(self.D.G)
+
+    def reduce_G(self):
+        if self.dp is None or self.sharded:
+            return
+        if self.fused:
+            self.optG.step_allreduce_fused(self.dp)
+        else:
+            self.dp.all_reduce_sum_(self.G.G)
 
     @property
     def _gscale(self):
         return 1.0 if self.dp is None else self.dp.grad_scale
 
     def train_step(self, real, prepared: bool = False):
+        """One iteration.  Data parallel on device: D's gradient exchange runs on a communication stream while
+        the generator's forward of the G phase (which does not depend on D) runs on the main one -- captured
+        into a hipGraph the fork / join become two branches."""
         if not prepared:
             real = self.D.prepare_input(real)
+        B = real.shape[0]
         self.phase_a(real)
-        if self.dp is not None and not self.sharded:
-            self.dp.all_reduce_sum_(self.D.G)
-        self.phase_b(real.shape[0])
-        if self.dp is not None and not self.sharded:
-            self.dp.all_reduce_sum_(self.G.G)
+        cs = self._comm_stream if not self.sharded else None
+        if cs is not None:
+            main = torch.cuda.current_stream()
+            cs.wait_stream(main)
+            with torch.cuda.stream(cs):
+                self.reduce_D()
+            self.phase_b1(B)
+            main.wait_stream(cs)
+            self.phase_b2(B)
+        else:
+            self.reduce_D()
+            self.phase_b(B)
+        self.reduce_G()
         self.phase_c()
         return self.d_loss, self.g_loss
 
@@ -334,7 +371,8 @@ class GraphedGANStep:
                  capture_collectives: bool = False):
         self.t, self.real = trainer, real_prepared
         self.B = real_prepared.shape[0]
-        self.full = trainer.dp is None or capture_collectives or trainer.sharded
+        self.full = (trainer.dp is None or capture_collectives or trainer.sharded
+                     or getattr(trainer.dp, "captures_safely", False))
         t = trainer
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
@@ -364,10 +402,10 @@ class GraphedGANStep:
             self.graphs[0].replay()
             self.comm_stream.wait_stream(main)
             with torch.cuda.stream(self.comm_stream):      # D's 1 MB all-reduce hides behind G's forward
-                t.dp.all_reduce_sum_(t.D.G)
+                t.reduce_D()
             self.graphs[1].replay()
             main.wait_stream(self.comm_stream)
             self.graphs[2].replay()
-            t.dp.all_reduce_sum_(t.G.G)
+            t.reduce_G()
             self.graphs[3].replay()
         return t.d_loss, t.g_loss

@@ -65,6 +65,7 @@ _dense1_blocks = _sig("ddl_dense1_bce_blocks", ci, ci)
 _dense1_bce = _sig("ddl_dense1_bce", ci, vp, vp, vp, cf, cf, ci, ci, ci, vp, vp, vp, vp, vp, vp, vp, vp, ci, ci, vp)
 _argmax_match = _sig("ddl_argmax_match", None, vp, vp, ci, ci, vp, vp)
 _optim_step = _sig("ddl_optim_step", None, vp, vp, vp, vp, vp, vp, cl, ci, cf, cf, cf, cf, cf, cf, vp, cf, vp)
+_step_inc = _sig("ddl_step_inc", None, vp, vp)
 _scale_emit = _sig("ddl_scale_emit", None, vp, vp, cl, cf, vp)
 _avg_delta = _sig("ddl_avg_delta", None, vp, vp, vp, vp, cl, cf, vp)
 _im2col = _sig("ddl_im2col_1ch", ci, vp, vp, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, vp)
@@ -603,6 +604,11 @@ def optimizer_step(opt, grad_scale=1.0, avg_with=None, avg_weight=0.0):
                 opt.step_dev.data_ptr(), n, _OPT_KIND[c.kind], c.lr, c.beta1, c.beta2, c.eps, c.rho, grad_scale,
                 _p(avg_with), avg_weight, _stream())
     _done()
+
+
+def step_inc(step_dev):
+    """Advance a device-side optimizer step counter (one-thread kernel on the current stream)."""
+    _step_inc(step_dev.data_ptr(), _stream())
 
 
 def optimizer_step_flat(P, G, m, v, Pc, step_dev, c, grad_scale=1.0):
