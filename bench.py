@@ -29,7 +29,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--config", default="dcgan28", choices=["dcgan28", "dcgan64", "classifier", "localsgd"])
+    ap.add_argument("--config", default="dcgan28", choices=["dcgan28", "dcgan64", "classifier", "localsgd", "ensemble32"])
+    ap.add_argument("--members", type=int, default=10, help="ensemble32: members per GPU")
+    ap.add_argument("--preset", default="ddl", help="ensemble32: search-space preset (ddl, ddl_ray, ddl_normal3, ...)")
     ap.add_argument("--batch", type=int, default=0, help="per-GPU real images per step (0 = config default)")
     ap.add_argument("--graph", default="auto", choices=["auto", "on", "off", "full"],
                     help="hipGraph capture: on = graph segments around eagerly issued collectives, full = the "

@@ -90,3 +90,86 @@ class ClassifierBench:
 
 class LocalSGDBench(ClassifierBench):
     local_sgd = True
+
+
+class EnsembleBench:
+    """`--config ensemble32`: the reference's real regime -- an ensemble generation of random architectures trained
+    at batch 32 (Keras fit() default, /root/reference/DDL.py:92) -- on ONE GPU per rank.
+
+    One bench step = `RandomModel.CHUNK` (32) optimizer steps of EVERY member: each member replays its multi-step
+    graph on its own HIP stream, so the members' tiny kernels share the GPU (models/classifier.py).  With N ranks
+    every rank trains its own N-member generation (ensemble-member parallelism has no gradient exchange).
+    `DDL_SERIAL_MEMBERS=1` issues the members on one stream, `DDL_CHUNK=1` falls back to one graph per step:
+    the two knobs price the two optimisations separately."""
+
+    def __init__(self, device, dp, rank, args):
+        self.device, self.rank, self.args = device, rank, args
+        self.batch = args.batch or 32
+        self.n_members = getattr(args, "members", 10)
+        self.preset = getattr(args, "preset", "ddl")
+
+    def setup(self):
+        import os
+        from .models import search
+        self.serial = os.environ.get("DDL_SERIAL_MEMBERS", "0") == "1"
+        chunk = max(RandomModel.CHUNK, 1)
+        n_pool = max(8192, self.batch * chunk * 2)
+        space = get_space(self.preset, [f"data_train_size={n_pool}", f"batch_size={self.batch}", "seed=0"])
+        self.data = Data(self.device, channels=space.channels, n_train=n_pool, n_test=256, synthetic=True,
+                         seed=self.rank)
+        rng = np.random.default_rng(space.seed)
+        self.members = []
+        use_graph = self.device.type == "cuda" and self.args.graph != "off"
+        for i in range(self.n_members):
+            compiled = search.make_new_model(space, rng, self.data.input_shape, 10)
+            sample = self.data.get_random_sample(n_pool, seed=100 + i)
+            m = RandomModel(self.data, sample, space, compiled, self.device, number=i, seed=i, use_graph=use_graph,
+                            verbose=False)
+            m.prepare(self.batch)
+            self.members.append(m)
+        self.chunk = getattr(self.members[0], "_chunk_S", 0) if use_graph else 0
+        self.steps_per_call = self.chunk if self.chunk else 1
+        on_gpu = self.device.type == "cuda"
+        self.streams = [torch.cuda.Stream() for _ in self.members] if (on_gpu and not self.serial) else None
+        g = torch.Generator().manual_seed(7 + self.rank)
+        self.idx = [torch.randint(0, n_pool, (self.steps_per_call, self.batch), generator=g).to(self.device)
+                    for _ in range(4)]
+        self.t = 0
+        self.params = [m.net.num_params(True) for m in self.members]
+        if on_gpu:
+            torch.cuda.synchronize()
+
+    def _one(self, m, idx):
+        if self.chunk:
+            m._idx_chunk.copy_(idx)
+            m._chunk_graph.replay()
+        else:
+            for k in range(idx.shape[0]):
+                m.train_step(idx[k])
+
+    def step(self):
+        idx = self.idx[self.t % len(self.idx)]
+        self.t += 1
+        if self.streams is None:
+            for m in self.members:
+                self._one(m, idx)
+            return
+        main = torch.cuda.current_stream()
+        for m, st in zip(self.members, self.streams):
+            st.wait_stream(main)
+            with torch.cuda.stream(st):
+                self._one(m, idx)
+        for st in self.streams:              # the step ends when every member's chunk has: bench timing stays honest
+            main.wait_stream(st)
+
+    def describe(self):
+        cfg = {"model": f"{self.n_members} random members of preset {self.preset} (DDL.py search space), batch {self.batch}",
+               "per_gpu_batch": self.batch, "seq_len": None, "members": self.n_members,
+               "optimizer_steps_per_member_per_bench_step": self.steps_per_call,
+               "member_params": self.params,
+               "step": "fwd + softmax-CE + bwd + optimizer, every member, "
+                       + ("members one after another" if self.streams is None else "members concurrent on their own streams"),
+               "graph": self.args.graph}
+        return {"metric": "ensemble32_train_images_per_sec",
+                "images_per_step_per_rank": self.batch * self.steps_per_call * self.n_members,
+                "config": cfg, "extra": {}}

@@ -47,4 +47,7 @@ def make(name, device, dp, rank, args):
     if name == "localsgd":
         from .bench_classifier import LocalSGDBench
         return LocalSGDBench(device, dp, rank, args)
+    if name == "ensemble32":
+        from .bench_classifier import EnsembleBench
+        return EnsembleBench(device, dp, rank, args)
     raise ValueError(name)

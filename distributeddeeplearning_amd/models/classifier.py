@@ -18,6 +18,7 @@ periodic weight averaging (local SGD) through `averager`.
 from __future__ import annotations
 
 import math
+import os
 from typing import Dict, List, Optional, Tuple
 
 import torch
@@ -42,7 +43,10 @@ class RandomModel:
         self.verbose = verbose
         self.dp, self.averager = dp, averager
         self.net = Network(compiled.spec, device, seed)
-        self.net.branch_wgrad = True     # measured +2 % on the 5-replica step (network.SideBranch)
+        # wgrad chain as a parallel graph branch (network.SideBranch): +2 % on the 5-replica step at batch 512, but at
+        # the reference's batch 32 the fork / join edges cost more than they hide (10 MLP members: 66.9 -> 44.4 ms
+        # per 32 steps without it) and they keep members on different streams from overlapping (-> 22.3 ms)
+        self.net.branch_wgrad = space.batch_size >= 128
         if parent_state is not None:
             # clone_model + set_weights(get_weights()): inherited layers start from the parent's
             # weights (BN moving statistics included); the new head keeps its fresh init.
@@ -148,32 +152,106 @@ class RandomModel:
             self.averager.after_step()
         return loss
 
+    # ------------------------------------------------------------------ multi-step graphs
+    # At the reference's batch of 32 (Keras fit() default, /root/reference/DDL.py:92) one optimizer step is tens of
+    # microseconds of tiny kernels; replaying one graph PER step leaves the host (slice the permutation, copy the
+    # index batch, launch, accumulate the loss) as the bottleneck.  `chunk` steps are therefore captured into ONE
+    # graph that reads its index batches from a static [chunk, B] tensor and adds `loss * B` into a device-side
+    # accumulator: an epoch of 1563 steps is ~49 graph launches and no per-step host work at all.
+    CHUNK = int(os.environ.get("DDL_CHUNK", "32"))        # 0 / 1: one graph per step (round-1 behaviour)
+
+    def _chunk_ok(self):
+        return self.use_graph and self.dp is None and self.averager is None and self.device.type == "cuda"
+
+    def prepare(self, batch_size: Optional[int] = None):
+        """Autotune + capture the step graphs WITHOUT training: one eager step on the first indices, the captures,
+        then parameters, optimizer state and BN statistics are restored.  Lets a scheduler prepare many members one
+        after another (plan autotuning times kernels on an otherwise idle GPU) and train them concurrently."""
+        if not self._chunk_ok() or self._graph is not None:
+            return
+        B = batch_size or self.space.batch_size
+        n = self.sample.train_idx.numel()
+        if n < B:
+            return
+        net, opt = self.net, self.opt
+        keep = [t.clone() for t in (net.P, net.S)] + [None if t is None else t.clone() for t in (opt.m, opt.v)]
+        keep_step, keep_t = opt.step_dev.clone(), opt.t
+        idx = self.sample.train_idx[:B].contiguous()
+        self._graphed_step(idx)                                      # eager warm-up step + single-step capture
+        S = min(self.CHUNK, n // B)
+        if S >= 2:
+            self._idx_chunk = torch.zeros(S, B, dtype=torch.int64, device=self.device)
+            self._idx_chunk.copy_(self.sample.train_idx[:S * B].view(S, B))
+            self._loss_acc = torch.zeros((), dtype=torch.float32, device=self.device)
+
+            def body():
+                for k in range(S):
+                    loss = self._step_body(self._idx_chunk[k])
+                    self._loss_acc.add_(loss.detach().float() * B)
+            hipgraph.quiesce()
+            self._chunk_graph, _ = hipgraph.capture(body, torch.cuda.graph_pool_handle())
+            self._chunk_S = S
+        net.P.copy_(keep[0])
+        net.S.copy_(keep[1])
+        for t, k in ((opt.m, keep[2]), (opt.v, keep[3])):
+            if t is not None:
+                t.copy_(k)
+        opt.step_dev.copy_(keep_step)
+        opt.t = keep_t
+        net.refresh_working_copies()
+        torch.cuda.current_stream().synchronize()
+
     # ------------------------------------------------------------------ fit / train
-    def fit(self, epochs: int, batch_size: Optional[int] = None) -> List[float]:
+    # fit / train are written as generators: they yield after every batch of launches they issue (None) and, when
+    # they need a value back from the device, a recorded event -- `train()` simply waits on it, while
+    # `train_concurrently` keeps issuing other members' work on their own streams and comes back once it is done.
+    def _fit_gen(self, epochs: int, batch_size: Optional[int] = None):
         B = batch_size or self.space.batch_size
         tr = self.sample.train_idx
         n = tr.numel()
+        on_gpu = self.device.type == "cuda"
+        if self._chunk_ok():
+            self.prepare(B)
+        S = getattr(self, "_chunk_S", 0) if (self._chunk_ok() and getattr(self, "_gB", None) == B) else 0
         losses = []
         for _ in range(epochs):
             perm = tr[torch.randperm(n, generator=self.gen).to(tr.device)]
             acc = torch.zeros((), dtype=torch.float32, device=self.device)
-            for i in range(0, n, B):
+            i = 0
+            if S:
+                self._loss_acc.zero_()
+                while i + S * B <= n:
+                    self._idx_chunk.copy_(perm[i:i + S * B].view(S, B))
+                    self._chunk_graph.replay()
+                    i += S * B
+                    yield None
+                acc = acc + self._loss_acc
+            k = 0
+            while i < n:
                 idx = perm[i:i + B]
                 loss = self.train_step(idx)
                 acc = acc + loss.detach() * idx.numel()      # Keras: sample-weighted epoch mean
+                i += B
+                k += 1
+                if k % 16 == 0:
+                    yield None
             losses.append(acc / n)
         if self.dp is not None and self.dp.world > 1:
             # every rank must take the same early-stop decision or the ones that stay would wait forever in
             # their next collective: the decision is made on the rank-averaged epoch losses
             t = torch.stack(losses).float()
             self.dp.all_reduce_mean_(t)
-            return [float(v) for v in t]
+            losses = list(t)
+        if on_gpu:
+            ev = torch.cuda.Event()
+            ev.record()
+            yield ev
         return [float(v) for v in losses]
 
-    def train(self):
+    def _train_gen(self):
         sp = self.space
         for i in range(int(sp.epochs / sp.mini_epochs)):
-            hist = self.fit(sp.mini_epochs)
+            hist = yield from self._fit_gen(sp.mini_epochs)
             self.history.append(hist)
             if self.verbose:
                 print(i, hist, flush=True)
@@ -182,6 +260,22 @@ class RandomModel:
                 break
         if self.averager is not None:
             self.averager.finish()
+
+    @staticmethod
+    def _drive(gen):
+        try:
+            while True:
+                ev = next(gen)
+                if ev is not None:
+                    ev.synchronize()
+        except StopIteration as stop:
+            return stop.value
+
+    def fit(self, epochs: int, batch_size: Optional[int] = None) -> List[float]:
+        return self._drive(self._fit_gen(epochs, batch_size))
+
+    def train(self):
+        self._drive(self._train_gen())
 
     def sync_bn_stats(self):
         """Synchronous DP exchanges gradients only: average the BN moving statistics over the ranks before they
@@ -317,3 +411,51 @@ class ReplicaGroupStep:
             self._join()
             self.graphs[-1].replay()
         return self.losses[-1]
+
+
+def train_concurrently(models: List[RandomModel], verbose: bool = False) -> None:
+    """Train several ensemble members of ONE GPU at the same time (the reference trains its members one after
+    another in a single process, /root/reference/DDL.py:142-144, or one per Ray actor).
+
+    A batch-32 step of these small networks cannot fill 256 CUs, so each member gets its own HIP stream and the
+    members' step graphs are issued round-robin from this one host thread; the hardware queues run them side by
+    side.  Members are prepared (autotuned + captured) one at a time first, so plan timing is never disturbed by a
+    neighbour.  A member that needs a value from the device (the epoch losses for its early-stop test) parks on an
+    event; the others keep being issued meanwhile.  Each member's random stream, data split and arithmetic are its
+    own: the result is identical to training the members serially."""
+    import time
+    if not models:
+        return
+    on_gpu = models[0].device.type == "cuda"
+    if not on_gpu:
+        for m in models:
+            m.train()
+        return
+    for m in models:
+        m.prepare()
+    torch.cuda.synchronize()
+    if os.environ.get("DDL_SERIAL_MEMBERS", "0") == "1":      # measurement knob: same graphs, one member at a time
+        for m in models:
+            m.train()
+        return
+    streams = [torch.cuda.Stream(device=m.device) for m in models]
+    gens = [m._train_gen() for m in models]
+    waiting = [None] * len(models)
+    active = list(range(len(models)))
+    while active:
+        progressed = False
+        for i in list(active):
+            ev = waiting[i]
+            if ev is not None and not ev.query():
+                continue
+            progressed = True
+            with torch.cuda.stream(streams[i]):
+                try:
+                    waiting[i] = next(gens[i])
+                except StopIteration:
+                    active.remove(i)
+                    if verbose:
+                        print(f"member {models[i].number} finished after {len(models[i].history)} rounds", flush=True)
+        if not progressed:
+            time.sleep(20e-6)
+    torch.cuda.synchronize()

@@ -32,7 +32,7 @@ import torch
 
 from ..config import SearchSpace
 from ..models import search
-from ..models.classifier import RandomModel
+from ..models.classifier import RandomModel, train_concurrently
 from ..models.search import CompiledSpec
 from ..ops import functional as F
 from ..utils.data import Data
@@ -169,12 +169,17 @@ class EnsembleModel:
             for (h, c), a in zip(members, accs):
                 self.accuracy_with_models.append([a, h, c])
             self._settle()
-        else:                                           # local (serial) / async (queued futures)
+        elif self.mode == "local":
+            # one process, one device: the members of a generation train side by side on their own HIP streams
+            # (serially on the CPU); same results as one after another (models/classifier.py train_concurrently)
+            train_concurrently([h._a.model for h, _ in members])
+            for h, c in members:
+                self.accuracy_with_models.append([h.call("get_accuracy"), h, c])
+            self._settle()
+        else:                                           # async: fire-and-forget train, queued accuracy futures
             for h, c in members:
                 h.call("train")
                 self.accuracy_with_models.append([h.call("get_accuracy"), h, c])
-            if self.mode == "local":
-                self._settle()
 
     def make_and_train_new_models(self, n: Optional[int] = None):
         n = self.space.random_model_size if n is None else n
@@ -268,6 +273,19 @@ class EnsembleModel:
 
 
 # ------------------------------------------------------------------------------------ SPMD (torchrun)
+class _CommOps:
+    """The three collectives an SPMD ensemble needs, expressed on the communicator facade."""
+
+    def __init__(self, comm):
+        self.comm = comm
+
+    def all_reduce(self, t):
+        self.comm.all_reduce_sum_(t)
+
+    def broadcast(self, t, src=0):
+        self.comm.broadcast_(t, src=src)
+
+
 class SpmdEnsemble:
     """The same generations under `torchrun`: one process per GPU, member i lives on rank
     i % world, every rank draws the same architectures from the same seeded RNG, and the only
@@ -275,11 +293,17 @@ class SpmdEnsemble:
 
     def __init__(self, space: SearchSpace, device, comm=None, data_kw: Optional[dict] = None,
                  verbose: bool = False):
+        """`comm`: a communicator facade (parallel.ddp.FlatDataParallel, parallel.rccl.RcclCommunicator,
+        parallel.p2p.P2PAllReduce); default: FlatDataParallel over the initialised torch.distributed group."""
         import torch.distributed as dist
         self.space, self.device, self.verbose = space, torch.device(device), verbose
-        self.dist = dist if (dist.is_available() and dist.is_initialized()) else None
-        self.rank = self.dist.get_rank() if self.dist else 0
-        self.world = self.dist.get_world_size() if self.dist else 1
+        if comm is None and dist.is_available() and dist.is_initialized():
+            from .ddp import FlatDataParallel
+            comm = FlatDataParallel()
+        self.comm = comm
+        self.dist = _CommOps(comm) if comm is not None else None
+        self.rank = comm.rank if comm is not None else 0
+        self.world = comm.world if comm is not None else 1
         self.rng = np.random.default_rng(space.seed)
         self.data = shared_data(device, space.channels, data_kw)
         self.data_kw = data_kw
@@ -298,9 +322,9 @@ class SpmdEnsemble:
 
     def _train_and_gather(self, new: List[dict]):
         accs = torch.zeros(len(new), dtype=torch.float32, device=self.device)
+        train_concurrently([m["actor"].model for m in new if m["actor"] is not None])     # this rank's members
         for i, m in enumerate(new):
             if m["actor"] is not None:
-                m["actor"].train()
                 a = m["actor"].get_accuracy()
                 accs[i] = a if not math.isnan(a) else -1.0
         if self.dist:

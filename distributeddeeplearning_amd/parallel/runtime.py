@@ -26,7 +26,7 @@ import sys
 import tempfile
 import threading
 import time
-from typing import Any, Dict, List, Optional, Sequence
+from typing import Any, Dict, List, Optional, Sequence, Tuple
 
 try:
     import cloudpickle as _cp
@@ -137,7 +137,7 @@ class Runtime:
         self._refs: Dict[int, ObjectRef] = {}
         self._ids = itertools.count(1)
         self._actor_ids = itertools.count(1)
-        self._rr = itertools.count(0)
+        self._actors_on: Dict[int, int] = {}    # worker index -> actors placed there
         self._conn_of: Dict[int, int] = {}      # worker index -> connection id
         self._worker_of: Dict[int, int] = {}    # connection id -> worker index
         self._dead: set = set()
@@ -202,13 +202,31 @@ class Runtime:
 
     # ------------------------------------------------------------------ submission
     def _pick_worker(self, num_gpus=0) -> int:
+        """Resource-aware placement (Ray places an actor where its `num_gpus` request fits,
+        /root/reference/DDL_Ray3.py:67): the live worker with the fewest unfinished requests, then the fewest
+        actors, wins.  With early stopping (DDL.py:95) members finish at very different times, so a blind
+        round-robin would keep stacking new actors behind a busy worker while another GPU idles."""
         alive = [i for i in range(len(self.devices)) if i not in self._dead
                  and (not num_gpus or self.devices[i].startswith("cuda"))]
         if not alive:
             alive = [i for i in range(len(self.devices)) if i not in self._dead]
         if not alive:
             raise WorkerDiedError("no live workers")
-        return alive[next(self._rr) % len(alive)]
+        with self._lock:
+            pending = {i: 0 for i in alive}
+            for r in self._refs.values():
+                if r.worker in pending:
+                    pending[r.worker] += 1
+        return min(alive, key=lambda i: (pending[i], self._actors_on.get(i, 0), i))
+
+    def worker_load(self) -> Dict[int, Tuple[int, int]]:
+        """{worker: (unfinished requests, actors placed)} -- what `_pick_worker` ranks by."""
+        with self._lock:
+            out = {i: [0, self._actors_on.get(i, 0)] for i in range(len(self.devices)) if i not in self._dead}
+            for r in self._refs.values():
+                if r.worker in out:
+                    out[r.worker][0] += 1
+        return {k: tuple(v) for k, v in out.items()}
 
     def _resolve(self, obj):
         if isinstance(obj, ObjectRef):
@@ -237,6 +255,7 @@ class Runtime:
 
     def _create_actor(self, cls, args, kwargs, num_gpus) -> ActorHandle:
         w = self._pick_worker(num_gpus)
+        self._actors_on[w] = self._actors_on.get(w, 0) + 1
         aid = next(self._actor_ids)
         created = self._submit(w, TAG_CREATE, (aid, cls, args, kwargs))
         return ActorHandle(self, aid, w, created)
@@ -270,6 +289,7 @@ class Runtime:
             time.sleep(0.002)
 
     def release(self, handle: ActorHandle):
+        self._actors_on[handle._worker] = max(0, self._actors_on.get(handle._worker, 0) - 1)
         self._submit(handle._worker, TAG_RELEASE, (handle._actor_id,))
 
     def alive_workers(self) -> List[int]:

@@ -53,3 +53,38 @@ def test_cnn_member_step_matches_oracle_direction():
         m = RandomModel(data, data.get_random_sample(256, seed=k), sp, cs, "cuda", number=k, seed=k, verbose=False)
         m.train()
         assert all(np.isfinite(h).all() for h in m.history), cs.spec.summary()
+
+
+def test_concurrent_chunked_training_equals_serial_single_step_graphs(monkeypatch):
+    """Batch-32 regime (DDL.py:92): members trained side by side on their own streams with 32-step graphs must end
+    with exactly the bits of members trained one after another with one graph per step."""
+    import numpy as np
+    from distributeddeeplearning_amd import config
+    from distributeddeeplearning_amd.models import classifier, search
+    from distributeddeeplearning_amd.utils.data import Data
+    sp = config.get_space("ddl_normal3", ["data_train_size=1100", "epochs=4", "early_stop_rate=0.05", "seed=3",
+                                          "kernel_size=2,6", "conv2d_size=0,3"])
+    data = Data("cuda", channels=1, n_train=1300, n_test=64, synthetic=True, seed=1)
+
+    def build():
+        rng = np.random.default_rng(5)
+        ms = []
+        for i in range(4):
+            c = search.make_new_model(sp, rng, data.input_shape, 10)
+            ms.append(classifier.RandomModel(data, data.get_random_sample(1100, seed=10 + i), sp, c, "cuda", i, i,
+                                             verbose=False))
+        return ms
+
+    a = build()
+    classifier.train_concurrently(a)
+    assert any(getattr(m, "_chunk_S", 0) >= 2 for m in a)
+    monkeypatch.setattr(classifier.RandomModel, "CHUNK", 0)
+    b = build()
+    for m in b:
+        m.train()
+    torch.cuda.synchronize()
+    for x, y in zip(a, b):
+        assert x.history == y.history
+        assert torch.equal(x.net.P, y.net.P) and torch.equal(x.net.S, y.net.S)
+    accs = [m.get_accuracy() for m in a]
+    assert max(accs) > 0.5          # the synthetic digits are learnable in a few epochs

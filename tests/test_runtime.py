@@ -102,3 +102,23 @@ def test_worker_death_fails_futures_and_pool_survives():
         assert r.get(a.add.remote(5)) == 5
         c = C.remote(1)                                              # new actors avoid the dead worker
         assert c._worker == a._worker and r.get(c.add.remote(1)) == 2
+
+
+def test_placement_prefers_the_least_loaded_worker():
+    """Actors go where the fewest requests are pending (Ray places by free resources, DDL_Ray3.py:67), not round-robin."""
+    r = runtime.Runtime(3, ["cpu"] * 3)
+    try:
+        C = r.remote(Counter)
+        first = [C.remote(0) for _ in range(3)]
+        assert sorted(a._worker for a in first) == [0, 1, 2]            # empty pool: spread by actor count
+        busy = [a for a in first if a._worker in (0, 1)]
+        slow = [a.add.remote(1, 1.5) for a in busy]                     # workers 0 and 1 are busy for a while
+        time.sleep(0.2)
+        idle = next(a._worker for a in first if a._worker == 2)
+        load = r.worker_load()
+        assert load[0][0] >= 1 and load[1][0] >= 1 and load[2][0] == 0
+        late = [C.remote(0) for _ in range(2)]
+        assert late[0]._worker == idle                                  # round-robin would have picked worker 0
+        r.get([a._created for a in late] + slow)
+    finally:
+        r.shutdown()
