@@ -431,17 +431,27 @@ def train_concurrently(models: List[RandomModel], verbose: bool = False) -> None
         for m in models:
             m.train()
         return
-    for m in models:
+    # MLP members (the DDL_Ray* search spaces) go to the persistent whole-network kernel as ONE group: one launch
+    # per epoch trains all of them, a workgroup each (models/mlp_fast.py); everything else runs its step graphs
+    from . import mlp_fast
+    group = []
+    if os.environ.get("DDL_MLP_PERSISTENT", "1") == "1":
+        group = [m for m in models if mlp_fast.eligible(m)]
+    rest = [m for m in models if all(m is not g for g in group)]
+    for m in rest:
         m.prepare()
     torch.cuda.synchronize()
     if os.environ.get("DDL_SERIAL_MEMBERS", "0") == "1":      # measurement knob: same graphs, one member at a time
-        for m in models:
+        if group:
+            mlp_fast.train_group(group, verbose)
+        for m in rest:
             m.train()
         return
-    streams = [torch.cuda.Stream(device=m.device) for m in models]
-    gens = [m._train_gen() for m in models]
-    waiting = [None] * len(models)
-    active = list(range(len(models)))
+    gens = [m._train_gen() for m in rest] + ([mlp_fast.train_group_gen(group, verbose)] if group else [])
+    names = [f"member {m.number}" for m in rest] + ([f"MLP group of {len(group)}"] if group else [])
+    streams = [torch.cuda.Stream(device=models[0].device) for _ in gens]
+    waiting = [None] * len(gens)
+    active = list(range(len(gens)))
     while active:
         progressed = False
         for i in list(active):
@@ -455,7 +465,7 @@ def train_concurrently(models: List[RandomModel], verbose: bool = False) -> None
                 except StopIteration:
                     active.remove(i)
                     if verbose:
-                        print(f"member {models[i].number} finished after {len(models[i].history)} rounds", flush=True)
+                        print(f"{names[i]} finished", flush=True)
         if not progressed:
             time.sleep(20e-6)
     torch.cuda.synchronize()

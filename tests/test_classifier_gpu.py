@@ -62,6 +62,7 @@ def test_concurrent_chunked_training_equals_serial_single_step_graphs(monkeypatc
     from distributeddeeplearning_amd import config
     from distributeddeeplearning_amd.models import classifier, search
     from distributeddeeplearning_amd.utils.data import Data
+    monkeypatch.setenv("DDL_MLP_PERSISTENT", "0")        # this test is about the step-graph path (bf16, multi-kernel)
     sp = config.get_space("ddl_normal3", ["data_train_size=1100", "epochs=4", "early_stop_rate=0.05", "seed=3",
                                           "kernel_size=2,6", "conv2d_size=0,3"])
     data = Data("cuda", channels=1, n_train=1300, n_test=64, synthetic=True, seed=1)
@@ -88,3 +89,56 @@ def test_concurrent_chunked_training_equals_serial_single_step_graphs(monkeypatc
         assert torch.equal(x.net.P, y.net.P) and torch.equal(x.net.S, y.net.S)
     accs = [m.get_accuracy() for m in a]
     assert max(accs) > 0.5          # the synthetic digits are learnable in a few epochs
+
+
+@pytest.mark.parametrize("opt_name,n_train", [("SGD", 80), ("Adam", 80), ("RMSprop", 80)])
+def test_persistent_mlp_kernel_matches_cpu_oracle(opt_name, n_train):
+    """Whole-network persistent kernel (one workgroup per member, an epoch per launch, csrc/hip/mlp_persistent.hip)
+    vs the fp32 CPU oracle executor: same init, same shuffles, ragged last batch (80 = 2 x 32 + 16 samples), 12
+    optimizer steps.  (Measured: after 2 steps the two agree to 1e-7; on raw 0..255 pixels most sigmoid / tanh units
+    saturate and BatchNorm divides by the tiny spread that is left, so rounding differences between two correct fp32
+    implementations grow step after step -- 44 steps already differ by 2 % in the epoch loss.  Hence the short run.)"""
+    import numpy as np
+    from distributeddeeplearning_amd import config
+    from distributeddeeplearning_amd.models import classifier, mlp_fast, search
+    sp = config.get_space("ddl_ray3", [f"data_train_size={n_train}", "epochs=4", "early_stop_rate=-1.0", "seed=2",
+                                       f"optimizers={opt_name}", "lr_exponent=-3,-2"])
+    dg = Data("cuda", channels=3, n_train=400, n_test=64, synthetic=True, seed=4)
+    dc = Data("cpu", channels=3, n_train=400, n_test=64, synthetic=True, seed=4)
+    rng = np.random.default_rng(8)
+    specs = [search.make_new_model(sp, rng, dg.input_shape, 10) for _ in range(4)]
+    assert len({len(c.spec.layers) for c in specs}) > 1           # different depths in one launch
+    gm = [classifier.RandomModel(dg, dg.get_random_sample(n_train, seed=20 + i), sp, c, "cuda", i, i, verbose=False)
+          for i, c in enumerate(specs)]
+    cm = [classifier.RandomModel(dc, dc.get_random_sample(n_train, seed=20 + i), sp, c, "cpu", i, i, verbose=False)
+          for i, c in enumerate(specs)]
+    assert all(mlp_fast.eligible(m) for m in gm)
+    classifier.train_concurrently(gm)            # -> mlp_fast group: 4 members, one launch per epoch
+    # the oracle's own sensitivity: the same run from parameters perturbed by 1e-6 (relative).  Deep members on raw
+    # 0..255 pixels are chaotic (saturated units behind BatchNorm): 1e-7 already moves the epoch losses by 0.1 after
+    # 12 steps, so agreement is demanded to the extent the oracle agrees with itself.
+    sens = []
+    for i, (c, m) in enumerate(zip(specs, cm)):
+        p = classifier.RandomModel(dc, dc.get_random_sample(n_train, seed=20 + i), sp, c, "cpu", i, i, verbose=False)
+        p.net.P.mul_(1.0 + 1e-6)
+        p.train()
+        m.train()
+        sens.append(float(np.abs(np.array(p.history) - np.array(m.history)).max()))
+    assert min(sens) < 1e-4                        # at least one well-conditioned member pins the kernel tightly
+    for g, c, sn in zip(gm, cm, sens):
+        assert len(g.history) == len(c.history) == 2
+        hg, hc = np.array(g.history), np.array(c.history)
+        if sn > 1e-4:           # chaotic member: comparable only up to the oracle's own spread; must stay sane
+            assert np.isfinite(hg).all() and np.abs(hg - hc).max() < 0.05 + 5 * sn, (hg, hc, sn)
+            continue
+        assert np.allclose(hg, hc, rtol=2e-3, atol=2e-3), (hg, hc, sn)
+        sg, sc = g.net.logical_state(), c.net.logical_state()
+        for k in sc:
+            ref = sc[k].float()
+            err = (sg[k].float() - ref).abs().max().item()
+            assert err <= 2e-3 * max(1.0, ref.abs().max().item()), (k, err)
+        assert g.opt.steps_taken() == c.opt.t == 4 * (-(-n_train // 32))
+        # the framework sees an ordinary trained member: bf16 working copies refreshed, predict works
+        pg = g.predict(dg.test_x).cpu()
+        pc = c.predict(dc.test_x)
+        assert (pg - pc).abs().max().item() < 5e-2
