@@ -5,6 +5,8 @@ Produces, under distributeddeeplearning_amd/_C/ :
   libddl_hip.so   every gfx950 kernel in csrc/hip/*.hip           (hipcc --offload-arch=gfx950)
   libddl_host.so  CPU-only runtime: HDF5 subset, actor transport   (g++)
   libddl_comm.so  RCCL communicator + xGMI peer all-reduce         (hipcc, links librccl)
+`python build.py --sanitize asan|ubsan|tsan` builds the host C++ with a CPU sanitizer into
+build/sanitize/host_sanitize.<kind> (HDF5 mutation fuzzer + transport stress; tests/test_sanitizers.py runs them).
 
 hipcc cross-compiles without a GPU, so this runs in the CPU build container; the .so files are
 git-ignored but travel to the GPU box with the tree.  Objects are cached by source mtime.
@@ -81,6 +83,25 @@ def build_comm(force=False):
     return lib
 
 
+SANITIZERS = {"asan": ["-fsanitize=address", "-fno-omit-frame-pointer"],
+              "ubsan": ["-fsanitize=undefined", "-fno-sanitize-recover=undefined"],
+              "tsan": ["-fsanitize=thread"]}
+
+
+def build_sanitized(kind: str) -> Path:
+    """CPU-only sanitizer build of the host runtime (HDF5 subset + actor transport) linked with its native test
+    driver csrc/host/tests/host_sanitize.cpp -> build/sanitize/host_sanitize.<kind>.  Never touches the GPU code."""
+    if kind not in SANITIZERS:
+        raise ValueError(f"unknown sanitizer {kind!r}; choose from {sorted(SANITIZERS)}")
+    out_dir = ROOT / "build" / "sanitize"
+    out_dir.mkdir(parents=True, exist_ok=True)
+    exe = out_dir / f"host_sanitize.{kind}"
+    srcs = sorted((CSRC / "host").glob("*.cpp")) + [CSRC / "host" / "tests" / "host_sanitize.cpp"]
+    if any(_newer(s, exe) for s in srcs):
+        _run(["g++", "-O1", "-g", "-std=c++17", "-pthread", *SANITIZERS[kind], "-o", exe, *srcs])
+    return exe
+
+
 def build_all(force=False, only=None):
     OUT.mkdir(parents=True, exist_ok=True)
     libs = []
@@ -97,6 +118,11 @@ if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--force", action="store_true")
     ap.add_argument("--only", choices=["hip", "host", "comm"])
+    ap.add_argument("--sanitize", choices=sorted(SANITIZERS),
+                    help="build the host C++ (h5_min, actor_transport) with a CPU sanitizer plus its test driver")
     a = ap.parse_args()
+    if a.sanitize:
+        print("built", build_sanitized(a.sanitize))
+        sys.exit(0)
     for l in build_all(a.force, a.only):
         print("built", l)

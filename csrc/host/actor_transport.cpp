@@ -314,7 +314,11 @@ EP_API int ddl_ep_send(void* h, int conn, uint64_t tag, const void* buf, uint64_
 EP_API int ddl_ep_next(void* h, int timeout_ms, int* conn, uint64_t* tag, uint64_t* size) {
     auto* ep = (Endpoint*)h;
     std::unique_lock<std::mutex> g(ep->mu);
-    if (!ep->cv.wait_for(g, std::chrono::milliseconds(timeout_ms), [&] { return !ep->queue.empty(); }))
+    // wait_until on the system clock = pthread_cond_timedwait, which ThreadSanitizer intercepts; wait_for uses
+    // pthread_cond_clockwait, which gcc 11's libtsan does not (it then believes the mutex stays held across the wait
+    // and reports a "double lock" plus a false race on every queue access)
+    if (!ep->cv.wait_until(g, std::chrono::system_clock::now() + std::chrono::milliseconds(timeout_ms),
+                           [&] { return !ep->queue.empty(); }))
         return EV_TIMEOUT;
     ep->current = std::move(ep->queue.front());
     ep->queue.pop_front();

@@ -13,6 +13,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <exception>
 #include <map>
 #include <memory>
 #include <string>
@@ -47,48 +48,73 @@ struct Node {
     std::vector<uint8_t> compact;
 };
 
+// Every byte of the file is untrusted (`load_model` is fed external checkpoints): all reads go through the checked
+// accessors below, which throw ParseError; the C entry points catch it (and std::bad_alloc) and return an error.
+struct ParseError { std::string msg; };
+[[noreturn]] void bad(const std::string& m) { throw ParseError{m}; }
+
 struct File {
     std::vector<uint8_t> buf;
     std::unique_ptr<Node> root;
     int so = 8, sl = 8;
+    size_t objects = 0;                      // objects loaded so far (bounded: a crafted file cannot make us spin)
+    std::vector<uint64_t> tree_path;         // B-tree nodes on the current descent (cycle guard)
 
     bool ok(uint64_t off, uint64_t n) const { return off <= buf.size() && n <= buf.size() - off; }
+    void need(uint64_t off, uint64_t n, const char* what) const {
+        if (!ok(off, n)) bad(std::string("truncated or corrupt file: ") + what);
+    }
+    uint8_t at(uint64_t off) const { need(off, 1, "byte"); return buf[off]; }
+    const uint8_t* ptr(uint64_t off, uint64_t n, const char* what = "range") const { need(off, n, what); return buf.data() + off; }
     uint64_t rd(uint64_t off, int n) const {
+        need(off, (uint64_t)n, "field");
         uint64_t v = 0;
         for (int i = 0; i < n; ++i) v |= (uint64_t)buf[off + i] << (8 * i);
         return v;
     }
 };
 
+const size_t MAX_OBJECTS = 1 << 20;
+const int MAX_RANK = 8;
+
 struct Msg { uint16_t type; uint64_t off; uint16_t size; };
 
 bool read_messages(const File& f, uint64_t addr, std::vector<Msg>& out) {
-    if (!f.ok(addr, 16)) return false;
-    int version = f.buf[addr];
-    if (version != 1) { g_err = "only v1 object headers are supported"; return false; }
+    f.need(addr, 16, "object header");
+    int version = f.at(addr);
+    if (version != 1) bad("only v1 object headers are supported");
     int nmsg = (int)f.rd(addr + 2, 2);
     uint64_t hsize = f.rd(addr + 8, 4);
     std::vector<std::pair<uint64_t, uint64_t>> blocks{{addr + 16, hsize}};
     for (size_t b = 0; b < blocks.size() && (int)out.size() < nmsg; ++b) {
-        uint64_t p = blocks[b].first, end = p + blocks[b].second;
-        if (!f.ok(p, blocks[b].second)) return false;
+        if (b > 4096) bad("too many object header continuation blocks");
+        uint64_t p = blocks[b].first;
+        f.need(p, blocks[b].second, "object header block");
+        uint64_t end = p + blocks[b].second;
         while (p + 8 <= end && (int)out.size() < nmsg) {
             uint16_t type = (uint16_t)f.rd(p, 2), size = (uint16_t)f.rd(p + 2, 2);
-            if (!f.ok(p + 8, size)) return false;
+            f.need(p + 8, size, "header message");
             out.push_back({type, p + 8, size});
-            if (type == 0x10) blocks.push_back({f.rd(p + 8, f.so), f.rd(p + 8 + f.so, f.sl)});
-            p += 8 + size;
+            if (type == 0x10) {
+                if (size < f.so + f.sl) bad("short continuation message");
+                blocks.push_back({f.rd(p + 8, f.so), f.rd(p + 8 + f.so, f.sl)});
+            }
+            p += 8 + (uint64_t)size;
         }
     }
     return true;
 }
 
 std::string heap_string(const File& f, uint64_t heap_addr, uint64_t off) {
-    if (!f.ok(heap_addr, 32) || memcmp(&f.buf[heap_addr], "HEAP", 4)) return "";
+    if (memcmp(f.ptr(heap_addr, 32, "local heap"), "HEAP", 4)) bad("bad local heap signature");
     uint64_t seg = f.rd(heap_addr + 8 + 2 * f.sl, f.so);
+    if (seg > f.buf.size() || off > f.buf.size() - seg) bad("heap string offset outside the file");
     uint64_t p = seg + off;
     std::string s;
-    while (p < f.buf.size() && f.buf[p]) s.push_back((char)f.buf[p++]);
+    while (p < f.buf.size() && f.buf[p]) {
+        if (s.size() >= 4096) bad("unterminated heap string");
+        s.push_back((char)f.buf[p++]);
+    }
     return s;
 }
 
@@ -96,55 +122,80 @@ struct TypeInfo { int cls = -1, size = 0; bool vlen_string = false; };
 
 TypeInfo parse_type(const File& f, uint64_t off) {
     TypeInfo t;
-    t.cls = f.buf[off] & 0x0f;
+    f.need(off, 8, "datatype message");
+    t.cls = f.at(off) & 0x0f;
     t.size = (int)f.rd(off + 4, 4);
-    if (t.cls == 9) t.vlen_string = (f.buf[off + 1] & 0x0f) == 1;
+    if (t.size < 0) bad("datatype size out of range");
+    if (t.cls == 9) t.vlen_string = (f.at(off + 1) & 0x0f) == 1;
     return t;
 }
 
 void parse_space(const File& f, uint64_t off, std::vector<uint64_t>& dims) {
-    int version = f.buf[off], rank = f.buf[off + 1];
+    int version = f.at(off), rank = f.at(off + 1);
+    if (rank > MAX_RANK) bad("dataspace rank > 8");
     uint64_t p = off + (version == 1 ? 8 : 4);
     dims.clear();
-    for (int i = 0; i < rank; ++i) dims.push_back(f.rd(p + 8 * i, f.sl));
+    for (int i = 0; i < rank; ++i) dims.push_back(f.rd(p + 8 * (uint64_t)i, f.sl));
+}
+
+// product of dims, refusing anything that could not possibly be stored in a file of this size
+uint64_t checked_count(const File& f, const std::vector<uint64_t>& dims, uint64_t elem_size) {
+    uint64_t count = 1;
+    const uint64_t limit = f.buf.size() / (elem_size ? elem_size : 1) + 1;
+    for (auto d : dims) {
+        if (d != 0 && count > limit / d + 1) bad("dataspace larger than the file");
+        count *= d;
+        if (count > limit && d != 0) bad("dataspace larger than the file");
+    }
+    return count;
 }
 
 uint64_t pad8(uint64_t n) { return (n + 7) & ~7ull; }
 
 bool parse_attr(const File& f, const Msg& m, std::string& name, Attr& a) {
     uint64_t p = m.off;
-    int version = f.buf[p];
+    int version = f.at(p);
     uint64_t nsz = f.rd(p + 2, 2), tsz = f.rd(p + 4, 2), ssz = f.rd(p + 6, 2);
     p += 8;
     if (version == 3) p += 1;
     auto adv = [&](uint64_t n) { return version == 1 ? pad8(n) : n; };
-    name.assign((const char*)&f.buf[p], strnlen((const char*)&f.buf[p], nsz));
+    const char* np = (const char*)f.ptr(p, nsz, "attribute name");
+    name.assign(np, strnlen(np, nsz));
     p += adv(nsz);
     TypeInfo t = parse_type(f, p);
     p += adv(tsz);
     parse_space(f, p, a.dims);
     p += adv(ssz);
-    uint64_t count = 1;
-    for (auto d : a.dims) count *= d;
+    uint64_t elem = t.cls == 9 ? (uint64_t)(4 + f.so + 4) : (uint64_t)(t.size > 0 ? t.size : 1);
+    uint64_t count = checked_count(f, a.dims, elem);
     if (count == 0) {
         a.is_string = true;           // Keras writes `weight_names = []` as an empty (float) array
     } else if (t.cls == 3) {
         a.is_string = true;
+        if (t.size <= 0) bad("zero-sized string type");
+        const char* base = (const char*)f.ptr(p, count * (uint64_t)t.size, "string attribute data");
         for (uint64_t i = 0; i < count; ++i) {
-            const char* s = (const char*)&f.buf[p + i * t.size];
+            const char* s = base + i * t.size;
             a.strings.emplace_back(s, strnlen(s, t.size));
         }
     } else if (t.cls == 9 && t.vlen_string) {
         a.is_string = true;
+        f.need(p, count * elem, "vlen attribute data");
         for (uint64_t i = 0; i < count; ++i) {
-            uint64_t q = p + i * (4 + f.so + 4);
+            uint64_t q = p + i * elem;
             uint64_t len = f.rd(q, 4), col = f.rd(q + 4, f.so), idx = f.rd(q + 4 + f.so, 4);
             std::string s;
             if (f.ok(col, 16) && !memcmp(&f.buf[col], "GCOL", 4)) {
                 uint64_t csize = f.rd(col + 8, f.sl), o = col + 16;
+                if (!f.ok(col, csize)) bad("global heap collection outside the file");
                 while (o + 16 <= col + csize) {
                     uint64_t oi = f.rd(o, 2), osz = f.rd(o + 8, f.sl);
-                    if (oi == idx) { s.assign((const char*)&f.buf[o + 16], (size_t)std::min(len, osz)); break; }
+                    if (osz > csize) bad("global heap object larger than its collection");
+                    if (oi == idx) {
+                        uint64_t n = std::min(len, osz);
+                        s.assign((const char*)f.ptr(o + 16, n, "global heap object"), (size_t)n);
+                        break;
+                    }
                     if (oi == 0) break;
                     o += 16 + pad8(osz);
                 }
@@ -152,26 +203,30 @@ bool parse_attr(const File& f, const Msg& m, std::string& name, Attr& a) {
             a.strings.push_back(s);
         }
     } else if (t.cls == 1 && t.size == 4) {
+        const uint8_t* src = f.ptr(p, count * 4, "float attribute data");
         a.floats.resize(count);
-        memcpy(a.floats.data(), &f.buf[p], count * 4);
+        memcpy(a.floats.data(), src, count * 4);
     }
     return true;
 }
 
-bool load_object(const File& f, uint64_t addr, Node& node, int depth);
+bool load_object(File& f, uint64_t addr, Node& node, int depth);
 
-bool walk_btree(const File& f, uint64_t tree, uint64_t heap, Node& group, int depth) {
-    if (!f.ok(tree, 24) || memcmp(&f.buf[tree], "TREE", 4)) { g_err = "bad B-tree node"; return false; }
-    int level = f.buf[tree + 5];
+bool walk_btree(File& f, uint64_t tree, uint64_t heap, Node& group, int depth) {
+    if (memcmp(f.ptr(tree, 24, "B-tree node"), "TREE", 4)) bad("bad B-tree node");
+    if (f.tree_path.size() > 64 || std::find(f.tree_path.begin(), f.tree_path.end(), tree) != f.tree_path.end())
+        bad("B-tree too deep or cyclic");
+    f.tree_path.push_back(tree);
+    int level = f.at(tree + 5);
     int used = (int)f.rd(tree + 6, 2);
-    uint64_t p = tree + 8 + 2 * f.so;
+    uint64_t p = tree + 8 + 2 * (uint64_t)f.so;
     for (int i = 0; i < used; ++i) {
         uint64_t child = f.rd(p + f.sl + (uint64_t)i * (f.sl + f.so), f.so);
         if (level > 0) {
             if (!walk_btree(f, child, heap, group, depth)) return false;
             continue;
         }
-        if (!f.ok(child, 8) || memcmp(&f.buf[child], "SNOD", 4)) { g_err = "bad symbol node"; return false; }
+        if (memcmp(f.ptr(child, 8, "symbol node"), "SNOD", 4)) bad("bad symbol node");
         int n = (int)f.rd(child + 6, 2);
         for (int e = 0; e < n; ++e) {
             uint64_t q = child + 8 + (uint64_t)e * (2 * f.so + 24);
@@ -179,20 +234,23 @@ bool walk_btree(const File& f, uint64_t tree, uint64_t heap, Node& group, int de
             uint64_t oh = f.rd(q + f.so, f.so);
             auto c = std::make_unique<Node>();
             if (!load_object(f, oh, *c, depth + 1)) return false;
-            group.order.push_back(name);
+            if (!group.children.count(name)) group.order.push_back(name);
             group.children[name] = std::move(c);
         }
     }
+    f.tree_path.pop_back();
     return true;
 }
 
-bool load_object(const File& f, uint64_t addr, Node& node, int depth) {
-    if (depth > 64) { g_err = "group nesting too deep"; return false; }
+bool load_object(File& f, uint64_t addr, Node& node, int depth) {
+    if (depth > 64) bad("group nesting too deep");
+    if (++f.objects > MAX_OBJECTS) bad("too many objects (cyclic or hostile file)");
     std::vector<Msg> msgs;
-    if (!read_messages(f, addr, msgs)) { if (g_err.empty()) g_err = "truncated object header"; return false; }
+    read_messages(f, addr, msgs);
     for (auto& m : msgs) {
         if (m.type == 0x11) {
             node.is_group = true;
+            if (m.size < 2 * f.so) bad("short symbol table message");
             if (!walk_btree(f, f.rd(m.off, f.so), f.rd(m.off + f.so, f.so), node, depth)) return false;
         } else if (m.type == 0x01) {
             parse_space(f, m.off, node.dims);
@@ -201,17 +259,18 @@ bool load_object(const File& f, uint64_t addr, Node& node, int depth) {
             node.dtype_class = t.cls;
             node.dtype_size = t.size;
         } else if (m.type == 0x08) {
-            int version = f.buf[m.off];
-            if (version != 3) { g_err = "only v3 data layout messages are supported"; return false; }
-            int cls = f.buf[m.off + 1];
+            int version = f.at(m.off);
+            if (version != 3) bad("only v3 data layout messages are supported");
+            int cls = f.at(m.off + 1);
             if (cls == 1) {
                 node.data_addr = f.rd(m.off + 2, f.so);
                 node.data_size = f.rd(m.off + 2 + f.so, f.sl);
             } else if (cls == 0) {
                 uint64_t n = f.rd(m.off + 2, 2);
-                node.compact.assign(&f.buf[m.off + 4], &f.buf[m.off + 4 + n]);
+                const uint8_t* src = f.ptr(m.off + 4, n, "compact dataset");
+                node.compact.assign(src, src + n);
                 node.data_size = n;
-            } else { g_err = "chunked datasets are not supported"; return false; }
+            } else bad("chunked datasets are not supported");
         } else if (m.type == 0x0c) {
             std::string name;
             Attr a;
@@ -440,25 +499,32 @@ H5_API const char* h5min_last_error() { return g_err.c_str(); }
 
 H5_API void* h5min_open(const char* path) {
     g_err.clear();
-    FILE* fp = fopen(path, "rb");
-    if (!fp) { fail(std::string("cannot open ") + path); return nullptr; }
-    auto f = std::make_unique<File>();
-    fseek(fp, 0, SEEK_END);
-    long n = ftell(fp);
-    fseek(fp, 0, SEEK_SET);
-    f->buf.resize(n > 0 ? n : 0);
-    size_t got = fread(f->buf.data(), 1, f->buf.size(), fp);
-    fclose(fp);
-    static const uint8_t sig[8] = {0x89, 'H', 'D', 'F', '\r', '\n', 0x1a, '\n'};
-    if (got != f->buf.size() || f->buf.size() < 96 || memcmp(f->buf.data(), sig, 8)) { fail("not an HDF5 file"); return nullptr; }
-    if (f->buf[8] != 0) { fail("only superblock version 0 is supported"); return nullptr; }
-    f->so = f->buf[13];
-    f->sl = f->buf[14];
-    if (f->so != 8 || f->sl != 8) { fail("only 8-byte offsets/lengths are supported"); return nullptr; }
-    uint64_t root_ohdr = f->rd(56 + 8, 8);
-    f->root = std::make_unique<Node>();
-    if (!load_object(*f, root_ohdr, *f->root, 0)) return nullptr;
-    return f.release();
+    try {
+        FILE* fp = fopen(path, "rb");
+        if (!fp) { fail(std::string("cannot open ") + path); return nullptr; }
+        auto f = std::make_unique<File>();
+        fseek(fp, 0, SEEK_END);
+        long n = ftell(fp);
+        fseek(fp, 0, SEEK_SET);
+        f->buf.resize(n > 0 ? n : 0);
+        size_t got = fread(f->buf.data(), 1, f->buf.size(), fp);
+        fclose(fp);
+        static const uint8_t sig[8] = {0x89, 'H', 'D', 'F', '\r', '\n', 0x1a, '\n'};
+        if (got != f->buf.size() || f->buf.size() < 96 || memcmp(f->buf.data(), sig, 8)) { fail("not an HDF5 file"); return nullptr; }
+        if (f->buf[8] != 0) { fail("only superblock version 0 is supported"); return nullptr; }
+        f->so = f->buf[13];
+        f->sl = f->buf[14];
+        if (f->so != 8 || f->sl != 8) { fail("only 8-byte offsets/lengths are supported"); return nullptr; }
+        uint64_t root_ohdr = f->rd(56 + 8, 8);
+        f->root = std::make_unique<Node>();
+        if (!load_object(*f, root_ohdr, *f->root, 0)) { if (g_err.empty()) fail("corrupt file"); return nullptr; }
+        return f.release();
+    } catch (const ParseError& e) {
+        fail(e.msg);
+    } catch (const std::exception& e) {       // bad_alloc / length_error from a hostile size field
+        fail(std::string("corrupt file: ") + e.what());
+    }
+    return nullptr;
 }
 
 H5_API void h5min_close(void* h) { delete (File*)h; }
@@ -514,9 +580,13 @@ H5_API int h5min_read_f32(void* h, const char* path, float* out, uint64_t count)
     if (!n || n->is_group) return fail("no such dataset");
     if (!(n->dtype_class == 1 && n->dtype_size == 4)) return fail("dataset is not float32");
     uint64_t total = 1;
-    for (auto d : n->dims) total *= d;
+    for (auto d : n->dims) {
+        if (d != 0 && total > (f.buf.size() / 4 + 1) / d + 1) return fail("dataset larger than the file");
+        total *= d;
+    }
     if (total != count) return fail("element count mismatch");
     if (total == 0) return 0;
+    if (total > f.buf.size() / 4 + 1) return fail("dataset larger than the file");
     if (!n->compact.empty()) {
         if (n->compact.size() < total * 4) return fail("compact data truncated");
         memcpy(out, n->compact.data(), total * 4);
