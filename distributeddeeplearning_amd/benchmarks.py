@@ -7,7 +7,7 @@ import torch
 class _DCGAN:
     def __init__(self, size, device, dp, rank, args):
         self.size, self.device, self.dp, self.rank, self.args = size, device, dp, rank, args
-        self.batch = args.batch or (1000 if size == 28 else 4096)
+        self.batch = args.batch or (1000 if size == 28 else 32768)     # 64x64: ~59 GB of HBM per GPU (65536 -> 118 GB)
 
     def setup(self):
         from .models.dcgan import GANConfig, GANTrainer, GraphedGANStep
@@ -33,7 +33,9 @@ class _DCGAN:
                            "step": "D update on [B real; B fake] + G update on B noise, Adam 2e-4, "
                                    f"BN policy {self.t.cfg.bn_policy} (batch statistics, per half in D)",
                            "graph": self.args.graph},
-                "extra": {"d_loss": float(self.t.d_loss), "g_loss": float(self.t.g_loss)}}
+                "extra": {"d_loss": float(self.t.d_loss), "g_loss": float(self.t.g_loss),
+                          "hbm_high_water_gb": (round(torch.cuda.max_memory_allocated(self.device) / 2 ** 30, 2)
+                                                if self.device.type == "cuda" else None)}}
 
 
 def make(name, device, dp, rank, args):

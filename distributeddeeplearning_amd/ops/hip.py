@@ -369,14 +369,19 @@ def relayout_gather(net):
     _done()
 
 
-def im2col_1ch(img, g: ConvGeom):
+def im2col_1ch(img, g: ConvGeom, out=None):
     """[B][g.H][g.W][Ci] (channel 0 is the image) -> taps-as-channels [B][g.OH][g.OW][pad8(KH*KW)]."""
     _chk_act(img, "img")
     B = img.shape[0]
     if tuple(img.shape[1:3]) != (g.H, g.W):
         raise ValueError(f"im2col_1ch: image {tuple(img.shape)} vs geometry {g}")
     Tp = pad8(g.KH * g.KW)
-    col = torch.empty(B, g.OH, g.OW, Tp, dtype=torch.bfloat16, device=img.device)
+    col = out if out is not None else torch.empty(B, g.OH, g.OW, Tp, dtype=torch.bfloat16, device=img.device)
+    ranges = _batch_ranges(B, max(g.OH * g.OW * Tp, g.H * g.W * img.shape[-1]))
+    if ranges is not None:
+        for b0, b1 in ranges:
+            im2col_1ch(img[b0:b1], g, col[b0:b1])
+        return col
     rc = _im2col(img.data_ptr(), col.data_ptr(), B, g.H, g.W, img.shape[-1], g.OH, g.OW, g.KH, g.KW, g.sh, g.sw,
                  g.dh, g.dw, g.pt, g.pl, Tp, _stream())
     if rc:
@@ -420,6 +425,11 @@ def col2im_1ch(col, g: ConvGeom, bias=None, act=None, alpha=0.3, out=None, mul=N
         img = out
     else:
         img = torch.empty(B, g.H, g.W, 8, dtype=torch.bfloat16, device=col.device)
+    ranges = _batch_ranges(B, max(g.OH * g.OW * Tp, g.H * g.W * 8))
+    if ranges is not None:
+        for b0, b1 in ranges:
+            col2im_1ch(col[b0:b1], g, bias, act, alpha, img[b0:b1], _mul_slice(mul, b0, b1))
+        return img
     my, ma, mal = _mul_args(mul, img)
     rc = _col2im(col.data_ptr(), img.data_ptr(), _p(bias), B, g.H, g.W, g.OH, g.OW, g.KH, g.KW, g.sh, g.sw, g.dh,
                  g.dw, g.pt, g.pl, Tp, ACT_CODE[act], alpha, my, ma, mal, _stream())
@@ -456,6 +466,12 @@ def tapfold_1ch(x, w, g: ConvGeom, bias=None, act=None, alpha=0.3, out=None, mul
         img = out
     else:
         img = torch.empty(B, g.H, g.W, 8, dtype=torch.bfloat16, device=x.device)
+    ranges = _batch_ranges(B, max(g.OH * g.OW * Cp, g.H * g.W * 8))
+    if ranges is not None:
+        for b0, b1 in ranges:
+            if tapfold_1ch(x[b0:b1], w, g, bias, act, alpha, img[b0:b1], _mul_slice(mul, b0, b1)) is None:
+                return None
+        return img
     my, ma, mal = _mul_args(mul, img)
     rc = _tapfold(x.data_ptr(), w.data_ptr(), _p(bias), img.data_ptr(), B, g.H, g.W, g.OH, g.OW, Cp, g.KH, g.KW,
                   g.sh, g.sw, g.dh, g.dw, g.pt, g.pl, ACT_CODE[act], alpha, my, ma, mal, _stream())
@@ -986,9 +1002,31 @@ def _is_1x1(g: ConvGeom) -> bool:
             and not g.depthwise)
 
 
-def conv_fprop(x, wA, bias, g: ConvGeom, act=None, alpha=0.3, mul=None, stats_out=None, bn_infer=None):
+# The conv kernels address their operands through 32-bit buffer descriptors / element offsets: one launch handles
+# tensors below 2^31 elements.  Larger batches (BASELINE config 4: "per-GPU batch sized to 288 GB HBM") are split
+# along the batch dimension into several launches on contiguous slices -- fprop / dgrad write their slice of the
+# output, wgrad sums the per-slice gradients in fp32.
+ELEM_LIMIT = int(os.environ.get("DDL_CONV_ELEM_LIMIT", str((1 << 31) - 1)))
+
+
+def _batch_ranges(B: int, per_image: int):
+    """[(b0, b1)] so that no slice has more than ELEM_LIMIT elements in its largest operand (None: no split)."""
+    if B * per_image <= ELEM_LIMIT:
+        return None
+    step = max(1, ELEM_LIMIT // per_image)
+    if step >= 8:
+        step -= step % 8
+    return [(b, min(b + step, B)) for b in range(0, B, step)]
+
+
+def _mul_slice(mul, b0, b1):
+    return None if mul is None else (mul[0][b0:b1], mul[1], mul[2])
+
+
+def conv_fprop(x, wA, bias, g: ConvGeom, act=None, alpha=0.3, mul=None, stats_out=None, bn_infer=None, out=None):
     """`mul` = (y, act, alpha): multiply the (bf16) result by act'(y) -- the activation backward of the layer
-    below, fused into the epilogue when this runs as a transposed conv's input gradient."""
+    below, fused into the epilogue when this runs as a transposed conv's input gradient.
+    `out`: write into this contiguous [B, OH, OW, Op] tensor (a batch slice of a larger one)."""
     _chk_act(x, "x")
     B = x.shape[0]
     Ip, Op = pad8(g.I), pad8(g.O)
@@ -996,7 +1034,16 @@ def conv_fprop(x, wA, bias, g: ConvGeom, act=None, alpha=0.3, mul=None, stats_ou
         raise ValueError(f"conv_fprop: x {tuple(x.shape)} does not match geometry {g} (padded I={Ip})")
     if bias is not None:
         _chk_f32(bias, g.O, "bias")
-    y = torch.empty(B, g.OH, g.OW, Op, dtype=torch.bfloat16, device=x.device)
+    if out is not None:
+        _chk_act(out, "out")
+        if tuple(out.shape) != (B, g.OH, g.OW, Op):
+            raise ValueError(f"conv_fprop: out {tuple(out.shape)} != {(B, g.OH, g.OW, Op)}")
+    y = out if out is not None else torch.empty(B, g.OH, g.OW, Op, dtype=torch.bfloat16, device=x.device)
+    ranges = _batch_ranges(B, max(g.H * g.W * Ip, g.OH * g.OW * Op))
+    if ranges is not None:
+        for b0, b1 in ranges:           # no BN statistics / folded BN across slices: the caller runs its own pass
+            conv_fprop(x[b0:b1], wA, bias, g, act, alpha, _mul_slice(mul, b0, b1), None, None, y[b0:b1])
+        return y
     if g.depthwise:
         _chk_w(wA, (g.KH, g.KW, Ip), "depthwise kernel")
         rc = _depthwise(0, x.data_ptr(), wA.data_ptr(), _p(bias), y.data_ptr(), None, B, g.H, g.W, Ip, g.OH, g.OW,
@@ -1023,7 +1070,8 @@ def conv_fprop(x, wA, bias, g: ConvGeom, act=None, alpha=0.3, mul=None, stats_ou
     return y
 
 
-def conv_dgrad(dy, wB, g: ConvGeom, bias=None, act=None, alpha=0.3, mul=None, stats_out=None, bn_infer=None):
+def conv_dgrad(dy, wB, g: ConvGeom, bias=None, act=None, alpha=0.3, mul=None, stats_out=None, bn_infer=None,
+               out=None):
     _chk_act(dy, "dy")
     B = dy.shape[0]
     Ip, Op = pad8(g.I), pad8(g.O)
@@ -1031,7 +1079,16 @@ def conv_dgrad(dy, wB, g: ConvGeom, bias=None, act=None, alpha=0.3, mul=None, st
         raise ValueError(f"conv_dgrad: dy {tuple(dy.shape)} does not match geometry {g} (padded O={Op})")
     if bias is not None:
         _chk_f32(bias, g.I, "bias")
-    dx = torch.empty(B, g.H, g.W, Ip, dtype=torch.bfloat16, device=dy.device)
+    if out is not None:
+        _chk_act(out, "out")
+        if tuple(out.shape) != (B, g.H, g.W, Ip):
+            raise ValueError(f"conv_dgrad: out {tuple(out.shape)} != {(B, g.H, g.W, Ip)}")
+    dx = out if out is not None else torch.empty(B, g.H, g.W, Ip, dtype=torch.bfloat16, device=dy.device)
+    ranges = _batch_ranges(B, max(g.H * g.W * Ip, g.OH * g.OW * Op))
+    if ranges is not None:
+        for b0, b1 in ranges:
+            conv_dgrad(dy[b0:b1], wB, g, bias, act, alpha, _mul_slice(mul, b0, b1), None, None, dx[b0:b1])
+        return dx
     if g.depthwise:
         _chk_w(wB, (g.KH, g.KW, Ip), "depthwise kernel")
         if bias is not None or act not in (None, "linear"):
@@ -1171,6 +1228,16 @@ def conv_wgrad(x, dy, g: ConvGeom, layout="A", out=None, box=None):
     Ip, Op = pad8(g.I), pad8(g.O)
     if tuple(x.shape) != (B, g.H, g.W, Ip) or tuple(dy.shape) != (B, g.OH, g.OW, Op):
         raise ValueError(f"conv_wgrad: x {tuple(x.shape)} / dy {tuple(dy.shape)} vs geometry {g}")
+    ranges = _batch_ranges(B, max(g.H * g.W * Ip, g.OH * g.OW * Op))
+    if ranges is not None:                      # sum of the per-slice gradients (fp32)
+        total = None
+        for b0, b1 in ranges:
+            if total is None:
+                total = conv_wgrad(x[b0:b1], dy[b0:b1], g, layout, out, box)
+            else:
+                total.add_(conv_wgrad(x[b0:b1], dy[b0:b1], g, layout, torch.empty_like(total) if box is None
+                                      else torch.zeros_like(total), box))
+        return total
     dev = x.device
     T = g.KH * g.KW
     if g.depthwise:

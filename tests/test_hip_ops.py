@@ -550,3 +550,33 @@ def test_pconv_emits_batchnorm_statistics(hip, shape, B):
     for u, v in zip(a, b):
         assert torch.allclose(u, v, rtol=1e-4, atol=1e-5)
     assert torch.allclose(mm1, mm2, rtol=1e-4, atol=1e-6) and torch.allclose(mv1, mv2, rtol=1e-4, atol=1e-6)
+
+
+def test_batch_split_launches_for_tensors_beyond_32bit_addressing(hip, monkeypatch):
+    """Tensors of >= 2^31 elements are split along the batch into several launches (BASELINE config 4: batch sized to
+    HBM).  Exercised here with an artificially small limit: fprop / dgrad / one-channel ops give the same bits as one
+    launch, wgrad the same sums up to fp32 addition order."""
+    torch.manual_seed(2)
+    g = G.conv2d_geom(14, 14, 32, 64, (5, 5), (2, 2), (1, 1), "same")
+    B = 48
+    x = dev(hip, r16(torch.randn(B, 14, 14, 32)))
+    w = r16(torch.randn(64, 5, 5, 32) * 0.05)
+    wA = padw(hip, w)
+    wB = padw(hip, w.permute(3, 1, 2, 0).contiguous())
+    bias = torch.randn(64).cuda()
+    dy = dev(hip, r16(torch.randn(B, 7, 7, 64)))
+    ref_y = hip.conv_fprop(x, wA, bias, g, "leaky", 0.3)
+    ref_dx = hip.conv_dgrad(dy, wB, g)
+    ref_dw = hip.conv_wgrad(x, dy, g, "A")
+    g1 = G.conv2d_geom(28, 28, 1, 32, (5, 5), (2, 2), (1, 1), "same")
+    img = dev(hip, r16(torch.rand(B, 28, 28, 1)))
+    ref_col = hip.im2col_1ch(img, g1)
+    ref_img = hip.col2im_1ch(ref_col, g1, None, "tanh01", 0.3)
+    monkeypatch.setattr(hip, "ELEM_LIMIT", 11 * 14 * 14 * 32)          # 11 images per launch -> 8-image slices
+    assert len(hip._batch_ranges(B, 14 * 14 * 32)) == 6
+    assert torch.equal(hip.conv_fprop(x, wA, bias, g, "leaky", 0.3), ref_y)
+    assert torch.equal(hip.conv_dgrad(dy, wB, g), ref_dx)
+    dw = hip.conv_wgrad(x, dy, g, "A")
+    close(dw.cpu(), ref_dw.cpu(), rtol=1e-4, atol=1e-4 * float(ref_dw.abs().max()))
+    assert torch.equal(hip.im2col_1ch(img, g1), ref_col)
+    assert torch.equal(hip.col2im_1ch(ref_col, g1, None, "tanh01", 0.3), ref_img)
