@@ -59,6 +59,8 @@ def main(argv=None):
     ap.add_argument("--save", action="store_true", help="export every member to models/modelN")
     ap.add_argument("--no-plot", action="store_true")
     ap.add_argument("--quiet", action="store_true")
+    ap.add_argument("--log-jsonl", default=None,
+                    help="append one JSON record per phase (timings, member accuracies, loss histories) to this file")
     a = ap.parse_args(argv)
 
     space = get_space(a.preset, a.set)
@@ -99,19 +101,47 @@ def main(argv=None):
         ens = EnsembleModel(space, mode=mode, runtime=rt, device=device, data_kw=data_kw, verbose=verbose)
         say = print
 
+    from ..utils import trace
+    log = trace.JsonlLogger(a.log_jsonl if say is print else None)
+    log.log(event="start", preset=a.preset, mode=mode, device=device, members=space.random_model_size,
+            transfer=space.transfer_model_size, data_train_size=space.data_train_size, batch=space.batch_size)
+
+    def histories():
+        """Per-member loss histories where the members live in this process (local / spmd modes)."""
+        out = []
+        for e in getattr(ens, "accuracy_with_models", []):
+            actor = getattr(e[1], "_a", None)
+            if actor is not None:
+                out.append(actor.model.history)
+        for m in getattr(ens, "members", []):
+            if m.get("actor") is not None:
+                out.append(m["actor"].model.history)
+        return out
+
     try:
-        ens.make_and_train_new_models(space.random_model_size)
+        t1 = time.time()
+        with trace.range("generation_random"):
+            ens.make_and_train_new_models(space.random_model_size)
+        log.log(event="generation", kind="random", seconds=time.time() - t1, loss_histories=histories())
         if space.transfer_model_size > 0:
-            ens.make_and_train_transfer_models(space.transfer_model_size)
-        for acc in ens.member_test_accuracies():
-            say("model accuracy : ", acc, flush=True)                       # DDL.py:171-172
-        say("ensemble accuracy : ", ens.get_accuracy(), flush=True)         # DDL.py:174
+            t1 = time.time()
+            with trace.range("generation_transfer"):
+                ens.make_and_train_transfer_models(space.transfer_model_size)
+            log.log(event="generation", kind="transfer", seconds=time.time() - t1, loss_histories=histories())
+        with trace.range("evaluate"):
+            accs = [float(x) for x in ens.member_test_accuracies()]
+            for acc in accs:
+                say("model accuracy : ", acc, flush=True)                   # DDL.py:171-172
+            vote = float(ens.get_accuracy())
+        say("ensemble accuracy : ", vote, flush=True)                       # DDL.py:174
+        log.log(event="result", member_test_accuracy=accs, ensemble_accuracy=vote, seconds=time.time() - t0)
         if a.save:
             ens.save_models()
         if not a.no_plot and hasattr(ens, "plot_models"):
             ens.plot_models()
         say(f"done in {time.time() - t0:.1f}s", flush=True)
     finally:
+        log.close()
         if rt is not None:
             from ..parallel import runtime
             runtime.shutdown()

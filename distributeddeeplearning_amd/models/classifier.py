@@ -121,6 +121,7 @@ class RandomModel:
                 first = self._step_body(self._idx)
             torch.cuda.current_stream().wait_stream(side)
             hipgraph.quiesce()
+            F.hip_backend().save_choice_cache()
             pool = torch.cuda.graph_pool_handle()
             if self._sync_dp and not getattr(self.dp, "captures_safely", False):
                 ga, self._static_loss = hipgraph.capture(lambda: self._fwd_bwd(self._idx), pool)
@@ -360,6 +361,8 @@ class ReplicaGroupStep:
             self._body()
         torch.cuda.current_stream().wait_stream(side)
         hipgraph.quiesce()
+        F.hip_backend().sync_choices(dp)    # every rank captures rank 0's tuned plans
+        F.hip_backend().save_choice_cache()
         pool = torch.cuda.graph_pool_handle()
         if mode == "full":
             g, self.losses = hipgraph.capture(self._body, pool)

@@ -381,6 +381,10 @@ class GraphedGANStep:
                 t.train_step(self.real, prepared=True)
         torch.cuda.current_stream().wait_stream(side)
         hipgraph.quiesce()
+        if t.G.on_gpu:
+            hip = F.hip_backend()
+            hip.sync_choices(t.dp)          # every rank captures rank 0's tuned plans
+            hip.save_choice_cache()
         pool = torch.cuda.graph_pool_handle()
         self.graphs = []
         if self.full:

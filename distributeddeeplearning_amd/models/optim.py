@@ -4,8 +4,8 @@ Covers the optimizer set of the reference: Keras `Adam` / `SGD` / `RMSprop` with
 (/root/reference/DDL.py:39-42, eps 1e-7), TF-1 `AdamOptimizer(2e-4)` (eps 1e-8,
 /root/reference/GAN_distributed.py:93), and the GAN's accidental "fresh Adam applied twice"
 semantics as `adam_fresh_double`.  On device the update kernel also emits the bf16
-working copy of the parameters, and can fold in an in-place weight average (`avg_with`) for the
-periodic-averaging / local-SGD mode [R-ns].
+working copy of the parameters; the periodic-averaging / local-SGD mode [R-ns] folds its weight
+average in with one fused kernel of its own (`avg_delta`, parallel/averaging.py).
 """
 from __future__ import annotations
 

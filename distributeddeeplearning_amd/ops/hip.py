@@ -609,16 +609,14 @@ def argmax_match_count(pred, onehot):
 _OPT_KIND = {"adam": 0, "sgd": 1, "rmsprop": 2, "adam_fresh_double": 3}
 
 
-def optimizer_step(opt, grad_scale=1.0, avg_with=None, avg_weight=0.0):
+def optimizer_step(opt, grad_scale=1.0):
     net, c = opt.net, opt.cfg
     n = net.P.numel()
     if opt.step_dev.numel() < 2:
         raise ValueError("step_dev must hold [steps, scratch]")
-    if avg_with is not None:
-        _chk_f32(avg_with, n, "avg_with")
     _optim_step(net.P.data_ptr(), net.G.data_ptr(), _p(opt.m), _p(opt.v), net.Pc.data_ptr(),
                 opt.step_dev.data_ptr(), n, _OPT_KIND[c.kind], c.lr, c.beta1, c.beta2, c.eps, c.rho, grad_scale,
-                _p(avg_with), avg_weight, _stream())
+                None, 0.0, _stream())
     _done()
 
 
@@ -836,6 +834,101 @@ def _pconv_candidates(g, mode, B, Cs, Nd, ss, device):
 _CONV_CHOICE: Dict[Tuple, object] = {}
 AUTOTUNE = os.environ.get("DDL_AUTOTUNE", "1") == "1"
 
+# ---- plan choices are portable: export / import / persist --------------------------------------------------
+# A tuned choice is recorded as plain data under a device-independent key string, so that (a) data-parallel ranks
+# can all run rank 0's plans instead of eight independently (and noisily) tuned sets -- `sync_choices(dp)` between
+# the warm-up step and graph capture -- and (b) a later process on the same machine skips tuning: the table is
+# persisted to DDL_AUTOTUNE_CACHE (default ~/.cache/distributeddeeplearning_amd/autotune.json), keyed by the problem
+# and stamped with the kernel library's identity so a rebuilt libddl_hip.so never reuses stale plans.
+_CHOICE_SPEC: Dict[str, object] = {}        # key string -> ["igemm", tile] | ["pconv", budget, IMG, FR] | ["wgrad", index]
+_CHOICE_DIRTY = False
+
+
+def _lib_stamp() -> str:
+    st = _LIB_PATH.stat()
+    return f"{st.st_size}-{int(st.st_mtime)}"
+
+
+def _cache_path() -> Optional[Path]:
+    p = os.environ.get("DDL_AUTOTUNE_CACHE")
+    if p == "":
+        return None
+    return Path(p) if p else Path.home() / ".cache" / "distributeddeeplearning_amd" / "autotune.json"
+
+
+def _kstr(*parts) -> str:
+    out = []
+    for x in parts:
+        out.append(",".join(str(int(v)) for v in vars(x).values()) if isinstance(x, ConvGeom) else str(x))
+    return "|".join(out)
+
+
+def _load_choice_cache():
+    import json
+    p = _cache_path()
+    try:
+        if p is not None and p.exists():
+            blob = json.loads(p.read_text())
+            if blob.get("lib") == _lib_stamp():
+                _CHOICE_SPEC.update(blob.get("choices", {}))
+    except Exception:       # noqa: BLE001 - a broken cache file only costs a re-tune
+        pass
+
+
+def save_choice_cache():
+    """Persist the tuned plans (called by the benchmark / CLIs after warm-up; cheap, atomic)."""
+    import json
+    global _CHOICE_DIRTY
+    p = _cache_path()
+    if p is None or not _CHOICE_DIRTY:
+        return
+    try:
+        p.parent.mkdir(parents=True, exist_ok=True)
+        tmp = p.with_suffix(f".tmp{os.getpid()}")
+        tmp.write_text(json.dumps({"lib": _lib_stamp(), "choices": _CHOICE_SPEC}))
+        os.replace(tmp, p)
+        _CHOICE_DIRTY = False
+    except Exception:       # noqa: BLE001
+        pass
+
+
+def export_choices() -> Dict[str, object]:
+    return dict(_CHOICE_SPEC)
+
+
+def import_choices(table: Dict[str, object], overwrite: bool = True):
+    """Adopt another process's tuned plans; already-resolved in-memory choices for those keys are dropped so the
+    next launch of each problem rebuilds its plan from the imported record."""
+    global _CHOICE_DIRTY
+    for k, v in table.items():
+        if overwrite or k not in _CHOICE_SPEC:
+            if _CHOICE_SPEC.get(k) != v:
+                _CHOICE_SPEC[k] = v
+                _CHOICE_DIRTY = True
+    if overwrite:
+        _CONV_CHOICE.clear()
+
+
+def sync_choices(dp, src: int = 0):
+    """Every rank adopts rank `src`'s plan table (a collective over the default process group)."""
+    import torch.distributed as dist
+    if dp is None or getattr(dp, "world", 1) <= 1 or not (dist.is_available() and dist.is_initialized()):
+        return
+    box = [export_choices() if dp.rank == src else None]
+    dist.broadcast_object_list(box, src=src)
+    if dp.rank != src:
+        import_choices(box[0], overwrite=True)
+
+
+def _record_choice(kstr: str, spec):
+    global _CHOICE_DIRTY
+    if _CHOICE_SPEC.get(kstr) != spec:
+        _CHOICE_SPEC[kstr] = spec
+        _CHOICE_DIRTY = True
+
+
+_load_choice_cache()
+
 
 def _pconv_units(pl, B):
     return -(-B // pl["IMG"]) * pl["bands"]
@@ -944,7 +1037,17 @@ def _igemm_call(src, wgt, bias, dst, g, mode, B, Hs, Ws, Cs, Hd, Wd, Nd, Nw, ss,
         return
     slow = ACT_CODE[act] not in (0, 1, 6)
     key = (g, mode, B, Cs, Nd, slow, str(src.device))
+    kstr = _kstr("conv", g, mode, B, Cs, Nd, int(slow))
     choice = _CONV_CHOICE.get(key)
+    if choice is None and kstr in _CHOICE_SPEC:          # imported from rank 0 / the on-disk cache
+        spec = _CHOICE_SPEC[kstr]
+        if spec[0] == "igemm":
+            choice = ("igemm", spec[1])
+        else:
+            pl = _pconv_plan(g, mode, B, Cs, Nd, ss, src.device, budget=spec[1], img=spec[2], fr=spec[3], min_rows=64)
+            choice = ("pconv", pl) if pl is not None else None
+        if choice is not None:
+            _CONV_CHOICE[key] = choice
     if choice is None:
         if AUTOTUNE and not torch.cuda.is_current_stream_capturing():
             tiles = [1] if Nd <= 16 else ([3] if Nd <= 32 else ([4, 5, 2] if Nd <= 64 else [6, 8]))
@@ -960,6 +1063,8 @@ def _igemm_call(src, wgt, bias, dst, g, mode, B, Hs, Ws, Cs, Hd, Wd, Nd, Nw, ss,
                 timed.append((_time_us(fn), kind, pl))
             timed.sort(key=lambda t: t[0])
             choice = (timed[0][1], timed[0][2])
+            _record_choice(kstr, ["igemm", choice[1]] if choice[0] == "igemm" else
+                           ["pconv", choice[1]["budget"], choice[1]["IMG"], choice[1]["FR"]])
             if os.environ.get("DDL_AUTOTUNE_VERBOSE"):
                 desc = [(round(t, 1), k, p if k == "igemm" else (p["IMG"], p["BR"], p["FR"], p["budget"] // 1024))
                         for t, k, p in timed]
@@ -1308,13 +1413,17 @@ def conv_wgrad(x, dy, g: ConvGeom, layout="A", out=None, box=None):
 
     if plans:
         key = ("wgrad", g, B, Ip, Op, n_lim, c_lim, sn, st, sc)
+        kstr = _kstr("wgrad", g, B, Ip, Op, n_lim, c_lim, sn, st, sc, len(plans))
         choice = _CONV_CHOICE.get(key)
+        if choice is None and kstr in _CHOICE_SPEC and -1 <= int(_CHOICE_SPEC[kstr][1]) < len(plans):
+            choice = _CONV_CHOICE[key] = int(_CHOICE_SPEC[kstr][1])
         if choice is None:
             if AUTOTUNE and not torch.cuda.is_current_stream_capturing():
                 timed = [(_time_us(lambda pl=pl: run_w2(pl)), i) for i, pl in enumerate(plans)]
                 timed.append((_time_us(run_w1), -1))
                 timed.sort()
                 choice = timed[0][1]
+                _record_choice(kstr, ["wgrad", choice])
                 if os.environ.get("DDL_AUTOTUNE_VERBOSE"):
                     desc = [(round(t, 1), "wgrad" if i < 0 else
                              tuple(plans[i][k] for k in ("TN", "TC", "TPW", "IMG", "BR", "ngroups", "nsplit")))

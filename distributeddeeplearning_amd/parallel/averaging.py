@@ -28,6 +28,7 @@ class PeriodicAverager:
             raise ValueError("need every >= 1 and 1 <= delay <= every")
         self.dp, self.every, self.overlap, self.delay = dp, every, overlap, delay
         self.nets: List = []
+        self._bufs = {}
         self.t = 0
         self._pending = None          # (launch step, [(net, snap, total, work)], event)
         self._side = None
@@ -37,6 +38,10 @@ class PeriodicAverager:
         self.nets.append(net)
         if net.on_gpu and self._side is None:
             self._side = torch.cuda.Stream(device=net.device)
+        # snapshot / sum / statistics buffers are allocated ONCE per network: an average allocates nothing, so the
+        # side-stream work is a fixed sequence of copies + collectives on fixed addresses (capturable, no allocator
+        # traffic between streams)
+        self._bufs[id(net)] = (torch.empty_like(net.P), torch.empty_like(net.P), torch.empty_like(net.S))
 
     # ------------------------------------------------------------------ blocking form
     def _average_now(self):
@@ -61,9 +66,10 @@ class PeriodicAverager:
         ctx = torch.cuda.stream(self._side) if gpu else _null()
         with ctx:
             for net in self.nets:
-                snap = net.P.clone()
-                total = snap.clone()
-                stats = net.S.clone()
+                snap, total, stats = self._bufs[id(net)]
+                snap.copy_(net.P)
+                total.copy_(net.P)
+                stats.copy_(net.S)
                 self.dp.all_reduce_sum_(total)
                 self.dp.all_reduce_sum_(stats)
                 items.append((net, snap, total, stats))
@@ -72,6 +78,8 @@ class PeriodicAverager:
                 ev = torch.cuda.Event()
                 ev.record(self._side)
         self._pending = (self.t, items, ev)
+        # the buffers are reused by the next launch: it must not start before this one has been applied
+        # (guaranteed by `after_step`: a new launch only happens when nothing is pending)
 
     def _apply(self):
         _, items, ev = self._pending
@@ -81,14 +89,12 @@ class PeriodicAverager:
         inv = 1.0 / self.dp.world
         for net, snap, total, stats in items:
             if net.on_gpu:
+                # one fused kernel: P += mean(snapshot) - snapshot, bf16 working copy re-emitted
                 F.hip_backend().avg_delta(net.P, net.Pc, total, snap, inv)
                 net.refresh_working_copies(cast=False)
-                # tensors allocated on the side stream are consumed here
-                for t in (snap, total, stats):
-                    t.record_stream(torch.cuda.current_stream())
             else:
                 net.P.add_(total * inv - snap)
-            net.S.copy_(stats * inv)
+            net.S.copy_(stats).mul_(inv)
         self.n_averages += 1
 
     # ------------------------------------------------------------------ hooks

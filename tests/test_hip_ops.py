@@ -580,3 +580,31 @@ def test_batch_split_launches_for_tensors_beyond_32bit_addressing(hip, monkeypat
     close(dw.cpu(), ref_dw.cpu(), rtol=1e-4, atol=1e-4 * float(ref_dw.abs().max()))
     assert torch.equal(hip.im2col_1ch(img, g1), ref_col)
     assert torch.equal(hip.col2im_1ch(ref_col, g1, None, "tanh01", 0.3), ref_img)
+
+
+def test_autotune_choices_export_import_and_persist(hip, tmp_path, monkeypatch):
+    """Tuned plans are plain data: another rank / a later process rebuilds the same kernels from the table."""
+    torch.manual_seed(3)
+    g = G.conv2d_geom(14, 14, 32, 64, (5, 5), (2, 2), (1, 1), "same")
+    x = dev(hip, r16(torch.randn(40, 14, 14, 32)))
+    w = padw(hip, r16(torch.randn(64, 5, 5, 32) * 0.05))
+    dy = dev(hip, r16(torch.randn(40, 7, 7, 64)))
+    monkeypatch.setenv("DDL_AUTOTUNE_CACHE", str(tmp_path / "tune.json"))
+    y0 = hip.conv_fprop(x, w, None, g)
+    dw0 = hip.conv_wgrad(x, dy, g, "A")
+    table = hip.export_choices()
+    assert any(k.startswith("conv|") for k in table) and any(k.startswith("wgrad|") for k in table)
+    hip._CHOICE_DIRTY = True
+    hip.save_choice_cache()
+    assert (tmp_path / "tune.json").exists()
+    # a "new process": nothing resolved, tuning forbidden -> the plans must come from the table
+    hip._CONV_CHOICE.clear()
+    hip._CHOICE_SPEC.clear()
+    hip._load_choice_cache()
+    assert hip.export_choices() == table
+    monkeypatch.setattr(hip, "_time_us", lambda *a, **k: (_ for _ in ()).throw(AssertionError("re-tuned")))
+    assert torch.equal(hip.conv_fprop(x, w, None, g), y0)
+    assert torch.equal(hip.conv_wgrad(x, dy, g, "A"), dw0)
+    hip._CONV_CHOICE.clear()
+    hip.import_choices(table)                     # what sync_choices does on ranks != 0
+    assert torch.equal(hip.conv_fprop(x, w, None, g), y0)
