@@ -26,6 +26,7 @@ next to the real batch on device, the loss stays on device until someone asks fo
 """
 from __future__ import annotations
 
+import os
 from dataclasses import dataclass
 from typing import Optional
 
@@ -147,6 +148,7 @@ class GANTrainer:
         self.optG, self.optD = FlatOptimizer(self.G, ocfg), FlatOptimizer(self.D, ocfg)
         self._ocfg = ocfg
         self.rng = DeviceRNG(device, cfg.seed * 7919 + 17 + rank)
+        self._fake = None
         self.head: ConvOp = self.D.ops[-1]
         assert self.head.kind == "dense" and self.head.g.O == 1
         self.d_loss = self.g_loss = None
@@ -162,6 +164,15 @@ class GANTrainer:
         self.fused = bool(dp is not None and not self.sharded and self.G.on_gpu
                           and getattr(dp, "supports_fused_update", False))
         self._comm_stream = torch.cuda.Stream() if (dp is not None and self.G.on_gpu) else None
+        # "split" policy on device: the generator's weights are the same in the D phase and in the G phase of an
+        # iteration (G is updated last), so both forwards run as ONE pass over [z1 ; z2] with per-half batch
+        # statistics: half the generator launches, each on twice the rows (these kernels do not fill 256 CUs at
+        # B = 1000).  The pass writes into one [3B] image buffer laid out [real | G(z1) | G(z2)]: the D phase reads
+        # the first 2B images, the G phase the last B -- no concat, no copy of the real images per step.
+        self.merged = bool(self._split and self.G.on_gpu and self.G.can_forward_into()
+                           and os.environ.get("DDL_GAN_MERGED_G", "1") == "1")
+        self._buf3 = None
+        self._buf3_src = None
 
     # ---- the two phases -------------------------------------------------------------------
     def _d_head(self, feat, n_first, label_first, label_second, want_dx, want_dw):
@@ -172,8 +183,29 @@ class GANTrainer:
                                                     h.gbias if want_dw else None)
         return loss, dfeat
 
+    def _d_backward_merged(self, real):
+        B = real.shape[0]
+        if self._buf3 is None or self._buf3.shape[0] != 3 * B:
+            self._buf3 = torch.empty((3 * B,) + tuple(real.shape[1:]), dtype=real.dtype, device=real.device)
+            self._buf3_src = None
+        key = (real.data_ptr(), real._version)
+        if self._buf3_src != key:                    # the real images change only when the caller's tensor does
+            self._buf3[:B].copy_(real)
+            self._buf3_src = key
+        z = self.rng.uniform((2 * B, self.cfg.noise_dim), self.G.cdtype)
+        self.G.forward(z, training=True, out=self._buf3[B:], bn_groups=2)
+        self.G.narrow_saved(B, 2 * B, group=1)       # the G phase trains on z2 only
+        self._fake = self._buf3[2 * B:]
+        feat = self.D.forward(self._buf3[:2 * B], training=True, stop=-1, bn_groups=2)
+        loss, dfeat = self._d_head(feat, B, 1.0, 0.0, True, True)
+        self.D.backward(dfeat, need_input_grad=False, start=-1)
+        self.d_loss = loss
+        return loss
+
     def d_backward(self, real):
         """Forward/backward of the discriminator phase; leaves averaged grads in D.G."""
+        if self.merged and real.is_contiguous():
+            return self._d_backward_merged(real)
         B = real.shape[0]
         z = self.rng.uniform((B, self.cfg.noise_dim), self.G.cdtype)
         g_train = self._split           # "split": the D-phase fakes see batch statistics like the G-phase ones
@@ -195,7 +227,10 @@ class GANTrainer:
         return loss
 
     def g_forward(self, B):
-        """Generator forward of the G phase (independent of D, so it can overlap D's all-reduce)."""
+        """Generator forward of the G phase (independent of D, so it can overlap D's all-reduce).  Already done
+        by the merged pass of the D phase when `self.merged`."""
+        if self.merged and self._fake is not None:
+            return self._fake
         z = self.rng.uniform((B, self.cfg.noise_dim), self.G.cdtype)
         self._fake = self.G.forward(z, training=True)
         return self._fake
@@ -393,8 +428,10 @@ class GraphedGANStep:
         else:
             # A | all-reduce(D grads) on the comm stream || B1 (G forward) | B2 | all-reduce(G grads) | C
             self.comm_stream = torch.cuda.Stream()
-            for fn in (lambda: t.phase_a(self.real), lambda: t.phase_b1(self.B), lambda: t.phase_b2(self.B),
-                       t.phase_c):
+            fns = [lambda: t.phase_a(self.real), lambda: t.phase_b1(self.B), lambda: t.phase_b2(self.B), t.phase_c]
+            if t.merged:            # the G-phase forward is part of phase A's merged generator pass
+                fns.pop(1)
+            for fn in fns:
                 self.graphs.append(hipgraph.capture(fn, pool)[0])
 
     def step(self):
@@ -407,9 +444,12 @@ class GraphedGANStep:
             self.comm_stream.wait_stream(main)
             with torch.cuda.stream(self.comm_stream):      # D's 1 MB all-reduce hides behind G's forward
                 t.reduce_D()
-            self.graphs[1].replay()
+            k = 1
+            if not t.merged:
+                self.graphs[1].replay()
+                k = 2
             main.wait_stream(self.comm_stream)
-            self.graphs[2].replay()
+            self.graphs[k].replay()
             t.reduce_G()
-            self.graphs[3].replay()
+            self.graphs[k + 1].replay()
         return t.d_loss, t.g_loss

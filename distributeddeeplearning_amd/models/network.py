@@ -800,6 +800,22 @@ class Network:
         for op in self.ops:
             op.release()
 
+    def narrow_saved(self, lo: int, hi: int, group: int = 0):
+        """Keep only batch rows [lo, hi) of the activations the last training forward saved (and, for BatchNorm
+        layers that ran with batch groups, the statistics of `group`): the following backward then differentiates
+        that part of the batch alone.  Used when one forward serves two purposes -- the DCGAN generator runs ONCE
+        on [z1 ; z2] per step, the first half feeds the discriminator phase, only the second half is trained."""
+        for op in self.ops:
+            for attr in ("x", "y"):
+                t = getattr(op, attr, None)
+                if isinstance(t, torch.Tensor) and t.dim() >= 1:
+                    setattr(op, attr, t[lo:hi])
+            if isinstance(op, BNOp) and op.mean is not None and op.groups_used > 1:
+                op.mean, op.invstd = op.mean[group].contiguous(), op.invstd[group].contiguous()
+                op.groups_used = 1
+            if isinstance(op, ViewOp) and op.in_shape is not None:
+                op.in_shape = (hi - lo,) + tuple(op.in_shape[1:])
+
     def predict(self, x, batch_size: int = 4096, prepared: bool = False):
         """Inference forward; applies the softmax of a softmax head (Keras `model.predict`).
         Returns fp32 logical outputs."""

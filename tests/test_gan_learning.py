@@ -77,6 +77,9 @@ class _FixedNoise:
     def uniform(self, shape, dtype, lo=-1.0, hi=1.0):
         z = self.batches[self.i]
         self.i += 1
+        if shape[0] == 2 * z.shape[0]:      # the device trainer draws the D- and G-phase noise in one call
+            z = torch.cat([z, self.batches[self.i]])
+            self.i += 1
         assert tuple(z.shape) == tuple(shape)
         return z.to(self.device).to(self.dtype)
 
