@@ -10,6 +10,7 @@
 // global load of the row-major X.  W (<= 32 KiB) is staged into LDS once per block.  A wave owns 64
 // rows; results leave through the same LDS-transposed 16-byte-store epilogue as pconv.
 #include "common.h"
+#include <cstdlib>
 
 struct GemmSkArgs {
     const bf16_t* x; const bf16_t* w; const float* bias; bf16_t* y;
@@ -137,7 +138,18 @@ static int launch_sk(const GemmSkArgs& a, hipStream_t s) {
     size_t smem = (size_t)BN * SK_WPITCH(KP) + 4 * 16 * (BN * 2 + 16);
     constexpr int FRG = NT >= 8 ? 1 : (NT >= 4 ? 2 : 4);
     long blocks = (a.M + 64 * FRG - 1) / (64 * FRG);
-    dim3 grid((unsigned)(blocks > 8192 ? 8192 : blocks), (unsigned)((a.Nd + BN - 1) / BN));
+    const long ntiles = (a.Nd + BN - 1) / BN;
+    if (ntiles > 1) {
+        // Wide outputs: every block stages its 128-column weight tile (32 KiB) before it computes anything, so a block
+        // that then owns only 64 rows spends its life staging (the generator's Dense 128 -> 6272 at 2000 rows: 1568
+        // blocks, 50 MB of weight staging for 25 MB of output).  Cap the grid near `target` blocks instead; the row
+        // loop strides by gridDim.x, so each block walks several 64-row slabs under one staged tile.
+        static const long target = getenv("DDL_SK_WIDE_BLOCKS") ? atol(getenv("DDL_SK_WIDE_BLOCKS")) : 512;
+        long cap = target / ntiles;
+        if (cap < 1) cap = 1;
+        if (blocks > cap) blocks = cap;
+    }
+    dim3 grid((unsigned)(blocks > 8192 ? 8192 : blocks), (unsigned)ntiles);
     const bool fast = a.act == ACT_LINEAR || a.act == ACT_RELU || a.act == ACT_LEAKY;
     if (fast) gemm_sk_kernel<NT, KS, false><<<grid, 256, smem, s>>>(a);
     else gemm_sk_kernel<NT, KS, true><<<grid, 256, smem, s>>>(a);
