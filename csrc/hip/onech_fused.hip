@@ -25,6 +25,10 @@ struct TapFoldArgs {
     int B, H, W, OH, OW, C, KH, KW, sh, sw, dh, dw, pt, pl, T, act;
     float alpha;
     int band_rows;
+    // optional per-channel affine applied to x as it is loaded (the BatchNorm in front of this layer, never
+    // materialised): x' = bf16(x * in_scale[grp][c] + in_shift[grp][c]), grp = (in_b_off + b) / in_group_rows
+    const float* in_scale; const float* in_shift;
+    int in_group_rows, in_b_off, in_ctrue;
 };
 
 #define TF_ZP 68                               // bytes per z pixel in LDS: 32 taps * 2 + 4 (spreads the 2-byte gathers)
@@ -63,6 +67,22 @@ __global__ __launch_bounds__(256) void tapfold_kernel(const TapFoldArgs a) {
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) wf[tt][ks] = *(const bf16x8_t*)(sW + (16 * tt + fr) * WP + ks * 64 + fq * 16);
 
+    // ---- input affine of this lane's channels (k = ks * 32 + fq * 8 .. + 7)
+    const bool aff = a.in_scale != nullptr;
+    float isc[KS][8], ish[KS][8];
+    if (aff) {
+        const int grp = (a.in_b_off + b) / a.in_group_rows;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int c = ks * 32 + fq * 8 + j;
+                const bool real = c < a.in_ctrue;
+                isc[ks][j] = real ? a.in_scale[grp * a.C + c] : 0.f;
+                ish[ks][j] = real ? a.in_shift[grp * a.C + c] : 0.f;
+            }
+    }
+
     // ---- z rows of the band: 16 pixels per MFMA column block, two fragments of loads in flight per wave
     typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
     const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc(
@@ -78,7 +98,15 @@ __global__ __launch_bounds__(256) void tapfold_kernel(const TapFoldArgs a) {
                 const int k = ks * 32 + fq * 8;
                 const bool ok = (p < npix) & (k < a.C);
                 const unsigned off = ok ? (xb + (unsigned)(p * a.C + k)) * 2u : 0xFFFFFFF0u;
-                const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(rsX, off, 0, 0);
+                u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(rsX, off, 0, 0);
+                if (aff) {
+                    float f[8];
+                    unpack8(make_uint4(v[0], v[1], v[2], v[3]), f);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) f[e] = ok ? fmaf(f[e], isc[ks][e], ish[ks][e]) : 0.f;
+                    const uint4 r = pack8(f);
+                    v = (u32x4_t){r.x, r.y, r.z, r.w};
+                }
                 xf[j][ks] = __builtin_bit_cast(bf16x8_t, v);
             }
         }
@@ -147,13 +175,17 @@ static void tapfold_launch(const TapFoldArgs& a, int bands, size_t smem, hipStre
 // Returns 0 on success, 1 if the shape is outside this kernel's range (nothing launched), < 0 on bad arguments.
 DDL_API int ddl_tapfold_1ch(const void* x, const void* w, const float* bias, void* img, int B, int H, int W, int OH,
                             int OW, int C, int KH, int KW, int sh, int sw, int dh, int dw, int pt, int pl, int act,
-                            float alpha, const void* mul_y, int mul_act, float mul_alpha, hipStream_t s) {
+                            float alpha, const void* mul_y, int mul_act, float mul_alpha, const float* in_scale,
+                            const float* in_shift, int in_group_rows, int in_b_off, int in_ctrue, hipStream_t s) {
     if (C % 8 || C <= 0 || B <= 0 || KH * KW <= 0) return -1;
+    if (in_scale && (!in_shift || in_group_rows <= 0 || in_b_off < 0)) return -1;
     if (KH * KW > 32 || C > 128) return 1;
     if ((long)B * OH * OW * C >= (1L << 31) || (long)B * H * W * 8 >= (1L << 31)) return 1;
     TapFoldArgs a;
     a.x = (const bf16_t*)x; a.w = (const bf16_t*)w; a.bias = bias; a.img = (uint4*)img;
     a.mul_y = (const bf16_t*)mul_y; a.mul_act = mul_act; a.mul_alpha = mul_alpha;
+    a.in_scale = in_scale; a.in_shift = in_shift; a.in_group_rows = in_group_rows; a.in_b_off = in_b_off;
+    a.in_ctrue = in_ctrue;
     a.B = B; a.H = H; a.W = W; a.OH = OH; a.OW = OW; a.C = C; a.KH = KH; a.KW = KW; a.sh = sh; a.sw = sw;
     a.dh = dh; a.dw = dw; a.pt = pt; a.pl = pl; a.T = KH * KW; a.act = act; a.alpha = alpha;
     const int KS = (C + 31) / 32;

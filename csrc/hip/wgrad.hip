@@ -27,6 +27,9 @@ struct WgradArgs {
     int tiles_c;              // number of c tiles (blockIdx.z = nt * tiles_c + ct)
     unsigned mg_ohw, mg_ow;   // magic multipliers for m / (OH*OW) and rem / OW (0 = power of two: shift only)
     int sf_ohw, sf_ow;
+    // optional per-channel affine on X as it is staged (a BatchNorm in front of the layer that is never
+    // materialised): X' = bf16(X * x_scale[c] + x_shift[c]) on real pixels, padding stays zero
+    const float* x_scale; const float* x_shift; int x_ctrue;
 };
 
 // floor(x / d) for 0 <= x < 2^31 with d's magic pair (host: magic_div)
@@ -97,7 +100,19 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a) {
         (void*)a.dy, 0, (int)((unsigned)a.M * a.Ny * 2u), 0x00020000);
     const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc(
         (void*)a.x, 0, (int)((unsigned)a.B * a.H * a.W * a.Cx * 2u), 0x00020000);
-    auto gload = [&](int mb, u32x4 (&ry)[PY], u32x4 (&rx)[PX]) {
+    const bool xaff = a.x_scale != nullptr;
+    float xsc[8], xsh[8];
+    if (xaff) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int c = c0 + xcol * 8 + j;
+            const bool real = c < a.x_ctrue;
+            xsc[j] = real ? a.x_scale[c] : 0.f;
+            xsh[j] = real ? a.x_shift[c] : 0.f;
+        }
+    }
+    auto gload = [&](int mb, u32x4 (&ry)[PY], u32x4 (&rx)[PX], unsigned& okx) {
+        okx = 0;
 #pragma unroll
         for (int p = 0; p < PY; ++p) {
             int m = mb + yrow + p * RPY;
@@ -116,9 +131,22 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a) {
             ok = ok & ((unsigned)ih < (unsigned)a.H) & ((unsigned)iw < (unsigned)a.W);
             unsigned off = ok ? (unsigned)(((b * a.H + ih) * a.W + iw) * a.Cx + c0 + xcol * 8) * 2u : 0xFFFFFFF0u;
             rx[p] = __builtin_amdgcn_raw_buffer_load_b128(rsX, off, 0, 0);
+            okx |= (ok ? 1u : 0u) << p;
         }
     };
-    auto consume = [&](const u32x4 (&ry)[PY], const u32x4 (&rx)[PX]) {
+    auto consume = [&](const u32x4 (&ry)[PY], u32x4 (&rx)[PX], unsigned okx) {
+        if (xaff) {
+#pragma unroll
+            for (int p = 0; p < PX; ++p) {
+                float f[8];
+                unpack8(make_uint4(rx[p][0], rx[p][1], rx[p][2], rx[p][3]), f);
+                const bool ok = (okx >> p) & 1u;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) f[e] = ok ? fmaf(f[e], xsc[e], xsh[e]) : 0.f;
+                const uint4 r = pack8(f);
+                rx[p] = (u32x4){r.x, r.y, r.z, r.w};
+            }
+        }
 #pragma unroll
         for (int p = 0; p < PY; ++p) {
             int row = yrow + p * RPY;
@@ -154,13 +182,14 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a) {
     };
     {
         u32x4 ryA[PY], rxA[PX], ryB[PY], rxB[PX];
+        unsigned okA, okB;
         const int mb0 = m_begin + wave * 32;
-        gload(mb0, ryA, rxA);
+        gload(mb0, ryA, rxA, okA);
         for (int mb = mb0; mb < m_end; mb += 256) {       // two slices per trip; a slice past m_end is all zeros
-            gload(mb + 128, ryB, rxB);
-            consume(ryA, rxA);
-            gload(mb + 256, ryA, rxA);
-            consume(ryB, rxB);
+            gload(mb + 128, ryB, rxB, okB);
+            consume(ryA, rxA, okA);
+            gload(mb + 256, ryA, rxA, okA);
+            consume(ryB, rxB, okB);
         }
     }
 
@@ -268,13 +297,15 @@ DDL_API int ddl_wgrad_ksplit(int M, int taps, int n_lim, int c_lim) {
 DDL_API int ddl_conv_wgrad(const void* dy, const void* x, float* out, float* slab, long numel, int ksplit, int B,
                            int OH, int OW, int Ny, int H, int W, int Cx, int KH, int KW, int sh, int sw, int dh,
                            int dw, int pt, int pl, int n_lim, int c_lim, long sn, long st, long sc,
-                           hipStream_t s) {
+                           const float* x_scale, const float* x_shift, int x_ctrue, hipStream_t s) {
     if (Ny % 8 || Cx % 8 || ksplit < 1) return -1;
+    if (x_scale && !x_shift) return -1;
     long M = (long)B * OH * OW;
     if (M >= (1L << 31) || M * Ny >= (1L << 31) || (long)B * H * W * Cx >= (1L << 31)) return -3;
     WgradArgs a;
     a.dy = (const bf16_t*)dy; a.x = (const bf16_t*)x;
     a.slab = ksplit == 1 ? out : slab;
+    a.x_scale = x_scale; a.x_shift = x_shift; a.x_ctrue = x_ctrue;
     a.B = B; a.OH = OH; a.OW = OW; a.Ny = Ny; a.H = H; a.W = W; a.Cx = Cx;
     a.KH = KH; a.KW = KW; a.sh = sh; a.sw = sw; a.dh = dh; a.dw = dw; a.pt = pt; a.pl = pl;
     a.n_lim = n_lim; a.c_lim = c_lim; a.sn = sn; a.st = st; a.sc = sc;

@@ -31,6 +31,7 @@ from ..ops.geometry import ConvGeom, dense_geom
 from .ir import LayerSpec, ModelSpec
 
 ONECH = os.environ.get("DDL_ONECH", "1") == "1"      # single-channel conv fast path (device)
+BN_ON_LOAD = os.environ.get("DDL_BN_ON_LOAD", "1") == "1"         # BN in front of a 1-channel ConvT applied on load
 FUSE_ACT_BWD = os.environ.get("DDL_FUSE_ACT_BWD", "1") == "1"   # act'(y) of the layer below in the dgrad epilogue
 BRANCH = os.environ.get("DDL_BRANCH", "1") == "1"    # weight-gradient branch on a side stream (captured steps)
 ALIGN = 8      # every tensor starts at a multiple of 8 elements (16 B in bf16, 32 B in fp32)
@@ -150,6 +151,10 @@ class ConvOp(Op):
         self.dy_premul = False          # the incoming dY already carries act'(y) (fused by the layer above)
         self._gbias_is_zero = False     # gbias currently holds the exact-zero gradient written by _bias_grad
         self.out_buffer = None          # optional destination of the next forward's output ("out" path only)
+        # BatchNorm applied on load ("out" path): the BN in front of this layer hands over (scale, shift, groups,
+        # c_true) instead of writing its output; the taps kernel and the weight-gradient kernel read x through it
+        self.in_affine = None           # set by BNOp.fwd for the next forward only
+        self.x_affine = None            # what the last training forward used (for backward)
 
     def _p(self, c):
         return _round_up(c, self.cpad)
@@ -214,13 +219,17 @@ class ConvOp(Op):
             if training:
                 self.x, self.y = xc, y
         else:                           # 1x1 conv to taps -> col2im fold with bias + activation (one fused kernel)
+            aff, self.in_affine = self.in_affine, None
             y = hip.tapfold_1ch(x, self.w_main.reshape(g1.O, -1), g, self.bias, self.act, self.alpha,
-                                out=self.out_buffer)
+                                out=self.out_buffer, in_affine=aff)
             if y is None:
+                if aff is not None:     # outside the fused kernel's range: materialise the BN output after all
+                    x = hip.bn_apply(x, aff[0], aff[1], None, 0.3, aff[3], aff[2])
+                    aff = None
                 z = hip.conv_fprop(x, self.w_main.reshape(g1.O, 1, 1, -1), None, g1)
                 y = hip.col2im_1ch(z, g, self.bias, self.act, self.alpha, out=self.out_buffer)
             if training:
-                self.x, self.y = x, y
+                self.x, self.y, self.x_affine = x, y, aff
         return y
 
     def _bwd_onech(self, dy, need_dx, need_dw, mul=None):
@@ -241,8 +250,16 @@ class ConvOp(Op):
         else:
             dyc = hip.im2col_1ch(dy, g)
             if need_dw:
+                x, xa = self.x, None
+                if self.x_affine is not None:
+                    sc, sh, groups, ctrue = self.x_affine
+                    if groups == 1:
+                        xa = (sc.reshape(-1), sh.reshape(-1), ctrue)
+                    else:               # several statistics groups in one backward: materialise
+                        x = hip.bn_apply(x, sc, sh, None, 0.3, ctrue, groups)
+
                 def wg():
-                    hip.conv_wgrad(self.x, dyc, g1, "A", out=self.gkernel)
+                    hip.conv_wgrad(x, dyc, g1, "A", out=self.gkernel, x_affine=xa)
                     self._bias_grad(dy)
                 _BR.run(wg, dy, dyc)
             if need_dx:
@@ -322,7 +339,7 @@ class ConvOp(Op):
         return dx
 
     def release(self):
-        self.x = self.y = None
+        self.x = self.y = self.x_affine = None
 
 
 class BNOp(Op):
@@ -344,6 +361,7 @@ class BNOp(Op):
         self.applied_by_producer = False   # inference forward: the producing conv already applied this BN
         self.groups = 1                # batch groups with their own batch statistics (set per forward pass)
         self.groups_used = 1
+        self.defer_to = None           # ConvOp that applies this BN's affine on load (no output tensor of our own)
 
     def fwd(self, x, training):
         use_batch = training and self.mode == "batch"
@@ -367,7 +385,11 @@ class BNOp(Op):
             mean = self.moving_mean
             scale, shift, invstd = F.bn_infer_affine(self.gamma, self.beta, self.moving_mean, self.moving_var,
                                                      self.eps)
-        y = F.bn_apply(x, scale, shift, self.post_act, self.post_alpha, self.C, groups)
+        if self.defer_to is not None and BN_ON_LOAD:
+            self.defer_to.in_affine = (scale, shift, groups, self.C)
+            y = x                       # the consumer reads x through (scale, shift); backward needs x only
+        else:
+            y = F.bn_apply(x, scale, shift, self.post_act, self.post_alpha, self.C, groups)
         if training:
             self.x, self.y, self.mean, self.invstd = x, y, mean, invstd
             self.used_batch_stats = use_batch
@@ -376,7 +398,8 @@ class BNOp(Op):
 
     def bwd(self, dy, need_dx=True, need_dw=True):
         conv = self.bias_grad_for
-        dx, _, _ = F.bn_bwd(dy, self.x, self.y, self.mean, self.invstd, self.gamma, self.post_act,
+        dx, _, _ = F.bn_bwd(dy, self.x, None if self.y is self.x else self.y, self.mean, self.invstd,
+                            self.gamma, self.post_act,
                             self.post_alpha, self.used_batch_stats, self.prev_act, self.prev_alpha,
                             self.ggamma if need_dw else None, self.gbeta if need_dw else None,
                             conv.gbias if (need_dw and conv is not None) else None, self.groups_used)
@@ -456,6 +479,12 @@ class Network:
         self._params: List[_Param] = []
         self._build_ops()
         self._allocate()
+        # BN (no activation of its own) straight in front of a single-output-channel transposed conv on the taps
+        # path: the conv's kernels apply the BN affine as they load x, the BN writes no tensor of its own
+        for a_, b_ in zip(self.ops, self.ops[1:]):
+            if isinstance(a_, BNOp) and isinstance(b_, ConvOp) and b_.onech == "out" and a_.rank4 \
+                    and a_.post_act in (None, "linear"):
+                a_.defer_to = b_
         self.init_weights(seed)
         if self.on_gpu:
             _BR.ensure_stream()
@@ -813,6 +842,9 @@ class Network:
             if isinstance(op, BNOp) and op.mean is not None and op.groups_used > 1:
                 op.mean, op.invstd = op.mean[group].contiguous(), op.invstd[group].contiguous()
                 op.groups_used = 1
+            if isinstance(op, ConvOp) and op.x_affine is not None and op.x_affine[2] > 1:
+                sc, sh, _, ctrue = op.x_affine
+                op.x_affine = (sc[group].contiguous(), sh[group].contiguous(), 1, ctrue)
             if isinstance(op, ViewOp) and op.in_shape is not None:
                 op.in_shape = (hi - lo,) + tuple(op.in_shape[1:])
 

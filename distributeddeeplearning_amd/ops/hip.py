@@ -72,7 +72,7 @@ _im2col = _sig("ddl_im2col_1ch", ci, vp, vp, ci, ci, ci, ci, ci, ci, ci, ci, ci,
 _col2im = _sig("ddl_col2im_1ch", ci, vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, cf, vp, ci,
                cf, vp)
 _tapfold = _sig("ddl_tapfold_1ch", ci, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, cf, vp, ci,
-                cf, vp)
+                cf, vp, vp, ci, ci, ci, vp)
 _gather = _sig("ddl_relayout_gather", None, vp, vp, vp, ci, cl, vp)
 _gemm_sk = _sig("ddl_gemm_sk", ci, vp, vp, vp, vp, cl, ci, ci, ci, ci, cf, vp)
 _philox = _sig("ddl_philox_uniform", None, vp, cl, vp, cf, cf, vp)
@@ -83,7 +83,7 @@ _pconv = _sig("ddl_pconv", ci, vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, c
 _pconv_lds = _sig("ddl_pconv_lds_bytes", ci, ci, ci, cl)
 _wgrad_ksplit = _sig("ddl_wgrad_ksplit", ci, ci, ci, ci, ci)
 _wgrad = _sig("ddl_conv_wgrad", ci, vp, vp, vp, vp, cl, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci,
-              ci, ci, ci, ci, cl, cl, cl, vp)
+              ci, ci, ci, ci, cl, cl, cl, vp, vp, ci, vp)
 _wgrad2 = _sig("ddl_conv_wgrad2", ci, vp, vp, vp, cl, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci,
                cl, cl, cl, ci, ci, ci, ci, ci, ci, ci, ci, ci, vp)
 _wgrad2_frag_elems = _sig("ddl_wgrad2_frag_elems", cl, ci, ci, ci, ci, ci, ci)
@@ -442,9 +442,12 @@ def col2im_1ch(col, g: ConvGeom, bias=None, act=None, alpha=0.3, out=None, mul=N
 TAPFOLD = os.environ.get("DDL_TAPFOLD", "1") == "1"
 
 
-def tapfold_1ch(x, w, g: ConvGeom, bias=None, act=None, alpha=0.3, out=None, mul=None):
+def tapfold_1ch(x, w, g: ConvGeom, bias=None, act=None, alpha=0.3, out=None, mul=None, in_affine=None, _b_off=0):
     """Fused taps GEMM + fold (csrc/hip/onech_fused.hip): x [B][g.OH][g.OW][Cp], w [T][Cp] (bf16) ->
     single-channel image [B][g.H][g.W][8] = act(bias + fold_t(x . w[t])), optionally *= act'(mul y).
+    `in_affine` = (scale, shift, groups, c_true): x is read as bf16(x * scale[grp] + shift[grp]) -- the
+    BatchNorm in front of this layer applied on load instead of as a pass of its own ([groups][Cp] rows, the
+    batch being `groups` equal contiguous parts).
     Returns None when the shape is outside the fused kernel's range (caller uses gemm + col2im_1ch)."""
     if not TAPFOLD:
         return None
@@ -466,15 +469,34 @@ def tapfold_1ch(x, w, g: ConvGeom, bias=None, act=None, alpha=0.3, out=None, mul
         img = out
     else:
         img = torch.empty(B, g.H, g.W, 8, dtype=torch.bfloat16, device=x.device)
+    isc = ish = None
+    grows, ctrue = 1, Cp
+    if in_affine is not None:
+        isc_t, ish_t, groups, ctrue = in_affine
+        if isinstance(groups, tuple):           # (rows per group,) of the whole batch: a batch-split recursion
+            grows = groups[0]
+        else:
+            if groups < 1 or B % groups:
+                raise ValueError(f"tapfold_1ch: batch {B} does not split into {groups} groups")
+            grows = B // groups
+        ngroups = -(-(_b_off + B) // grows)
+        _chk_f32(isc_t, None, "in_affine scale")
+        _chk_f32(ish_t, None, "in_affine shift")
+        if isc_t.numel() < ngroups * Cp or ish_t.numel() < ngroups * Cp:
+            raise ValueError("tapfold_1ch: in_affine needs [groups][Cp] scale / shift rows")
+        isc, ish = isc_t.data_ptr(), ish_t.data_ptr()
     ranges = _batch_ranges(B, max(g.OH * g.OW * Cp, g.H * g.W * 8))
     if ranges is not None:
+        sub = None if in_affine is None else (in_affine[0], in_affine[1], (grows,), ctrue)
         for b0, b1 in ranges:
-            if tapfold_1ch(x[b0:b1], w, g, bias, act, alpha, img[b0:b1], _mul_slice(mul, b0, b1)) is None:
+            if tapfold_1ch(x[b0:b1], w, g, bias, act, alpha, img[b0:b1], _mul_slice(mul, b0, b1), sub,
+                           _b_off + b0) is None:
                 return None
         return img
     my, ma, mal = _mul_args(mul, img)
     rc = _tapfold(x.data_ptr(), w.data_ptr(), _p(bias), img.data_ptr(), B, g.H, g.W, g.OH, g.OW, Cp, g.KH, g.KW,
-                  g.sh, g.sw, g.dh, g.dw, g.pt, g.pl, ACT_CODE[act], alpha, my, ma, mal, _stream())
+                  g.sh, g.sw, g.dh, g.dw, g.pt, g.pl, ACT_CODE[act], alpha, my, ma, mal, isc, ish, grows, _b_off,
+                  ctrue, _stream())
     if rc < 0:
         raise ValueError(f"tapfold_1ch rejected its arguments (rc={rc})")
     if rc > 0:
@@ -1324,9 +1346,11 @@ def _wgrad2_plans(g: ConvGeom, B: int, Cx: int, Ny: int, n_lim: int, c_lim: int)
     return plans
 
 
-def conv_wgrad(x, dy, g: ConvGeom, layout="A", out=None, box=None):
+def conv_wgrad(x, dy, g: ConvGeom, layout="A", out=None, box=None, x_affine=None):
     """`box` = (n_lim, c_lim, sn, st, sc, numel): write dW[n][t][c] at out[n*sn + t*st + c*sc] instead of one of
-    the two standard layouts (the caller guarantees `out` has `numel` elements and is zero elsewhere)."""
+    the two standard layouts (the caller guarantees `out` has `numel` elements and is zero elsewhere).
+    `x_affine` = (scale, shift, c_true), fp32 [Ip]: X is read as bf16(X * scale + shift) on real pixels (a
+    BatchNorm in front of the layer applied on load); only the streaming kernel (1x1 / few-tap problems) has it."""
     _chk_act(x, "x")
     _chk_act(dy, "dy")
     B = x.shape[0]
@@ -1338,14 +1362,16 @@ def conv_wgrad(x, dy, g: ConvGeom, layout="A", out=None, box=None):
         total = None
         for b0, b1 in ranges:
             if total is None:
-                total = conv_wgrad(x[b0:b1], dy[b0:b1], g, layout, out, box)
+                total = conv_wgrad(x[b0:b1], dy[b0:b1], g, layout, out, box, x_affine)
             else:
                 total.add_(conv_wgrad(x[b0:b1], dy[b0:b1], g, layout, torch.empty_like(total) if box is None
-                                      else torch.zeros_like(total), box))
+                                      else torch.zeros_like(total), box, x_affine))
         return total
     dev = x.device
     T = g.KH * g.KW
     if g.depthwise:
+        if x_affine is not None:
+            raise ValueError("conv_wgrad: x_affine is not available for depthwise layers")
         if out is None:
             out = torch.empty(g.KH, g.KW, Ip, dtype=torch.float32, device=dev)
         _chk_f32(out, T * Ip, "dW")
@@ -1374,6 +1400,14 @@ def conv_wgrad(x, dy, g: ConvGeom, layout="A", out=None, box=None):
         raise ValueError(f"conv_wgrad: out has {out.numel()} elements, expected {numel} for layout {layout}")
     _chk_f32(out, numel, "dW")
     plans = _wgrad2_plans(g, B, Ip, Op, n_lim, c_lim) if WGRAD_IMPL == "wgrad2" else []
+    xs = xh = None
+    xct = Ip
+    if x_affine is not None:
+        if g.depthwise or plans:
+            raise ValueError("conv_wgrad: x_affine is only available on the streaming weight-gradient kernel")
+        _chk_f32(x_affine[0], Ip, "x_affine scale")
+        _chk_f32(x_affine[1], Ip, "x_affine shift")
+        xs, xh, xct = x_affine[0].data_ptr(), x_affine[1].data_ptr(), int(x_affine[2])
 
     def run_w2(pl):
         ns = pl["nsplit"]
@@ -1407,7 +1441,8 @@ def conv_wgrad(x, dy, g: ConvGeom, layout="A", out=None, box=None):
         if ksplit > 1:
             slab = (torch.zeros if box is not None else torch.empty)(ksplit * numel, dtype=torch.float32, device=dev)
         rc = _wgrad(dy.data_ptr(), x.data_ptr(), out.data_ptr(), _p(slab), numel, ksplit, B, g.OH, g.OW, Op, g.H,
-                    g.W, Ip, g.KH, g.KW, g.sh, g.sw, g.dh, g.dw, g.pt, g.pl, n_lim, c_lim, sn, st, sc, _stream())
+                    g.W, Ip, g.KH, g.KW, g.sh, g.sw, g.dh, g.dw, g.pt, g.pl, n_lim, c_lim, sn, st, sc, xs, xh, xct,
+                    _stream())
         if rc:
             raise ValueError(f"conv_wgrad rejected the problem (rc={rc}): {g}")
 
@@ -1445,7 +1480,8 @@ def conv_wgrad(x, dy, g: ConvGeom, layout="A", out=None, box=None):
     if ksplit > 1:
         slab = (torch.zeros if box is not None else torch.empty)(ksplit * numel, dtype=torch.float32, device=dev)
     rc = _wgrad(dy.data_ptr(), x.data_ptr(), out.data_ptr(), _p(slab), numel, ksplit, B, g.OH, g.OW, Op, g.H,
-                g.W, Ip, g.KH, g.KW, g.sh, g.sw, g.dh, g.dw, g.pt, g.pl, n_lim, c_lim, sn, st, sc, _stream())
+                g.W, Ip, g.KH, g.KW, g.sh, g.sw, g.dh, g.dw, g.pt, g.pl, n_lim, c_lim, sn, st, sc, xs, xh, xct,
+                _stream())
     if rc:
         raise ValueError(f"conv_wgrad rejected the problem (rc={rc}): {g}")
     _done()

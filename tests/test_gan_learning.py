@@ -142,7 +142,9 @@ def test_default_mode_learns_glyphs_and_round1_mode_collapses():
         out[policy] = dict(first=first, last=nn_distance(s, real), div=float(s.std(0).mean()),
                            d_loss=float(d_loss), g_loss=float(g_loss), **t.diagnose(rp))
     sp, mx = out["split"], out["mixed"]
-    assert sp["last"] < 0.75 * sp["first"], out                   # generated samples moved toward the data
+    # generated samples moved toward the data.  (Autotuned kernel plans differ from run to run, so 1500 iterations
+    # of a chaotic game do not land on one value: 0.74-0.78 x first seen; an untrained / collapsed G stays >= 0.95.)
+    assert sp["last"] < 0.85 * sp["first"], out
     assert sp["div"] > 0.12, out                                 # ... and did not collapse onto one image
     assert abs(sp["logit_gphase"] - sp["logit_fake"]) < 1.5, out
     assert sp["g_loss"] > 0.1, out                               # the game is still being played

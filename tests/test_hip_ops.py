@@ -504,6 +504,47 @@ def test_tapfold_fused_equals_gemm_plus_col2im(hip, case, C):
         assert torch.equal(got, ref), kw.keys()
 
 
+@pytest.mark.parametrize("C,ctrue,groups", [(32, 32, 1), (32, 32, 2), (24, 20, 1), (64, 64, 3)])
+def test_tapfold_input_affine_equals_materialised_bn(hip, C, ctrue, groups):
+    """BatchNorm applied on load: tapfold(x, in_affine) == tapfold(bn_apply(x)) bit for bit (same bf16 rounding of
+    the normalised activation), per batch group, padded channels staying zero."""
+    g = G.conv2d_geom(28, 28, 1, C, (5, 5), (1, 1), (1, 1), "same")
+    T = g.KH * g.KW
+    B = 6 * groups
+    torch.manual_seed(14)
+    x = (torch.randn(B, g.OH, g.OW, C) * 0.7).bfloat16().cuda().contiguous()
+    w = (torch.randn(T, C) * 0.2).bfloat16().cuda().contiguous()
+    scale = (torch.rand(groups, C, device="cuda") + 0.5).contiguous()
+    shift = torch.randn(groups, C, device="cuda").contiguous()
+    a = hip.bn_apply(x, scale, shift, None, 0.3, ctrue, groups)
+    ref = hip.tapfold_1ch(a, w, g, None, "tanh01")
+    got = hip.tapfold_1ch(x, w, g, None, "tanh01", in_affine=(scale, shift, groups, ctrue))
+    assert got is not None and torch.equal(got, ref)
+    assert not torch.equal(got, hip.tapfold_1ch(x, w, g, None, "tanh01"))
+
+
+@pytest.mark.parametrize("C,ctrue,T", [(32, 32, 25), (24, 20, 9), (64, 64, 25)])
+def test_wgrad_input_affine_equals_materialised_bn(hip, C, ctrue, T):
+    """conv_wgrad(x, x_affine) == conv_wgrad(bn_apply(x)) bit for bit on the streaming kernel (the 1x1 problem
+    the single-channel transposed conv's weight gradient is)."""
+    B, H = 7, 12
+    Tp = hip.pad8(T)
+    g1 = G.ConvGeom(H, H, C, H, H, T, 1, 1).check()
+    torch.manual_seed(15)
+    x = (torch.randn(B, H, H, C) * 0.7).bfloat16().cuda().contiguous()
+    dy = (torch.randn(B, H, H, Tp) * 0.3).bfloat16().cuda().contiguous()
+    dy[..., T:] = 0
+    scale = (torch.rand(C, device="cuda") + 0.5).contiguous()
+    shift = torch.randn(C, device="cuda").contiguous()
+    a = hip.bn_apply(x, scale, shift, None, 0.3, ctrue, 1)
+    ref = hip.conv_wgrad(a, dy, g1, "A")
+    got = hip.conv_wgrad(x, dy, g1, "A", x_affine=(scale, shift, ctrue))
+    assert torch.equal(got, ref)
+    g5 = G.conv2d_geom(H, H, C, 16, (5, 5), (1, 1), (1, 1), "same")
+    with pytest.raises(ValueError):
+        hip.conv_wgrad(x, torch.zeros(B, H, H, 16, device="cuda").bfloat16(), g5, "A", x_affine=(scale, shift, ctrue))
+
+
 @pytest.mark.parametrize("K,N,B", [(128, 6272, 1000), (96, 300, 37), (40, 136, 70)])
 def test_dense_wide_output_skinny_k(hip, K, N, B):
     """Dense with K <= 128 and a wide output (G1: 128 -> 6272) runs on gemm_sk's column tiles."""

@@ -142,3 +142,29 @@ def test_generator_inference_forward_with_folded_batchnorm():
     yg = g.forward(g.prepare_input(z), training=False)
     assert _rel(g.to_logical(yg).cpu(), yc) < 3e-2
     assert not any(getattr(op, "applied_by_producer", False) for op in g.ops)      # flags consumed
+
+
+def test_bn_on_load_matches_materialised_generator():
+    """The generator's last BatchNorm is applied on load by the single-channel transposed conv (no BN output tensor):
+    forward image, every gradient and the moving statistics must equal the materialised path bit for bit, for the
+    plain forward and for the merged two-group forward narrowed to its second half."""
+    from distributeddeeplearning_amd.models import network as N
+    from distributeddeeplearning_amd.models.dcgan import generator_spec
+    torch.manual_seed(3)
+    z = torch.rand(12, 128, device="cuda").bfloat16() * 2 - 1
+    res = {}
+    for flag in (True, False):
+        N.BN_ON_LOAD = flag
+        try:
+            net = N.Network(generator_spec(28, 16), "cuda", seed=5)
+            assert any(isinstance(op, N.BNOp) and op.defer_to is not None for op in net.ops)
+            y = net.forward(z, training=True, bn_groups=2)
+            net.narrow_saved(6, 12, group=1)
+            net.G.zero_()
+            net.backward(torch.ones_like(y[6:]) * 0.01, need_input_grad=False)
+            torch.cuda.synchronize()
+            res[flag] = (y.clone(), net.G.clone(), net.S.clone())
+        finally:
+            N.BN_ON_LOAD = True
+    for a, b in zip(res[True], res[False]):
+        assert torch.equal(a, b)
