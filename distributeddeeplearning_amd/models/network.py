@@ -475,6 +475,10 @@ class Network:
         self.bn_mode = bn_mode
         self.softmax_head = False
         self.branch_wgrad = False       # captured steps: wgrad chain as a parallel graph branch (SideBranch)
+        # CPU oracle only: round every op's output (forward) and input gradient (backward) to bf16, the points at
+        # which the device executor stores bf16 tensors -- the oracle then differs from the device by fp32
+        # summation order alone and the end-to-end tests can use tight tolerances (tests/test_layerwise_gpu.py)
+        self.emulate_bf16 = False
         self.ops: List[Op] = []
         self._params: List[_Param] = []
         self._build_ops()
@@ -768,6 +772,8 @@ class Network:
         try:
             for op in self.ops[start:stop]:
                 x = op.fwd(x, training)
+                if self.emulate_bf16 and not self.on_gpu and not isinstance(op, ViewOp):
+                    x = x.bfloat16().float()
         finally:
             if out is not None:
                 last.out_buffer = None
@@ -822,6 +828,8 @@ class Network:
                 dy = op.bwd(dy, need_dx=need_dx, need_dw=need_dw, mul=mul)
             else:
                 dy = op.bwd(dy, need_dx=need_dx, need_dw=need_dw)
+            if self.emulate_bf16 and not self.on_gpu and dy is not None and not isinstance(op, ViewOp):
+                dy = dy.bfloat16().float()
         _BR.join()
         return dy
 

@@ -14,6 +14,7 @@ def _pair(spec, seed=0, bn="batch"):
     st = {k: v.bfloat16().float() for k, v in c.logical_state().items()}
     c.load_logical_state(st)
     g.load_logical_state(st)
+    c.emulate_bf16 = True       # the oracle rounds to bf16 where the device stores bf16 (tests/test_layerwise_gpu.py)
     return c, g
 
 
@@ -31,23 +32,23 @@ def test_discriminator_fwd_bwd(bn):
     x = torch.rand(64, 28, 28, 1).bfloat16().float()
     yc = c.forward(c.prepare_input(x), training=True)
     yg = g.forward(g.prepare_input(x), training=True)
-    assert _rel(g.to_logical(yg).cpu(), yc) < 3e-2
-    dy = torch.randn_like(yc).bfloat16().float() / 64
+    assert _rel(g.to_logical(yg).cpu(), yc) < 1e-2
+    dy = torch.randn_like(yc).abs().bfloat16().float() / 64
     dxc = c.backward(dy, need_input_grad=True)
     import distributeddeeplearning_amd.ops.hip as hip
     dxg = g.backward(hip.pad_channels(dy.cuda(), 8), need_input_grad=True)
-    assert _rel(g.to_logical(dxg, 1).cpu(), dxc) < 8e-2
+    assert _rel(g.to_logical(dxg, 1).cpu(), dxc) < 3e-2
     _cmp_grads(c, g)
 
 
 def _cmp_grads(c, g):
-    """Kernels to 8 %; per-channel vectors (bias / gamma / beta: long bf16 column sums at the end of
-    a bf16 gradient chain) to 15 %."""
+    """Against the bf16-emulating oracle: kernels to 3 %; per-channel vectors (bias / gamma / beta: mixed-sign
+    sums over batch x pixels, which amplify the elementwise error of what they sum) to 6 %."""
     batch_bn = any(getattr(op, "mode", None) == "batch" for op in c.ops)
     for (k, gc), (_, gg) in zip(_grads(c).items(), _grads(g).items()):
         if batch_bn and k[1] == "bias" and float(gc.norm()) < 1e-5:
             continue        # a bias in front of batch-statistics BN has an exactly-zero gradient: only noise
-        tol = 8e-2 if k[1] in ("kernel", "depthwise_kernel") else 15e-2
+        tol = 3e-2 if k[1] in ("kernel", "depthwise_kernel") else 6e-2
         assert _rel(gg.reshape(gc.shape), gc) < tol, k
 
 
@@ -66,8 +67,8 @@ def test_generator_fwd_bwd():
     z = (torch.rand(32, 128) * 2 - 1).bfloat16().float()
     yc = c.forward(c.prepare_input(z), training=True)
     yg = g.forward(g.prepare_input(z), training=True)
-    assert _rel(g.to_logical(yg).cpu(), yc) < 3e-2
-    dy = torch.randn_like(yc).bfloat16().float()
+    assert _rel(g.to_logical(yg).cpu(), yc) < 1e-2
+    dy = torch.randn_like(yc).abs().bfloat16().float()
     c.backward(dy)
     import distributeddeeplearning_amd.ops.hip as hip
     g.backward(hip.pad_channels(dy.cuda(), 8))
@@ -140,7 +141,7 @@ def test_generator_inference_forward_with_folded_batchnorm():
     z = (torch.rand(200, 128, generator=gen) * 2 - 1).bfloat16().float()
     yc = c.forward(c.prepare_input(z), training=False)
     yg = g.forward(g.prepare_input(z), training=False)
-    assert _rel(g.to_logical(yg).cpu(), yc) < 3e-2
+    assert _rel(g.to_logical(yg).cpu(), yc) < 1e-2
     assert not any(getattr(op, "applied_by_producer", False) for op in g.ops)      # flags consumed
 
 
