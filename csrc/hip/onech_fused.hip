@@ -88,10 +88,13 @@ __global__ __launch_bounds__(256) void tapfold_kernel(const TapFoldArgs a) {
     const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc(
         (void*)a.x, 0, (int)((unsigned)a.B * a.OH * a.OW * a.C * 2u), 0x00020000);
     const unsigned xb = (unsigned)((b * a.OH + oh_lo) * a.OW * a.C);      // element offset of the band's first z row
-    for (int f0 = wave * 2; f0 * 16 < npix; f0 += 8) {
-        bf16x8_t xf[2][KS];
+    // NF fragments (16 pixels x KS 16-byte loads each) in flight per wave: the kernel streams x once and is bound
+    // by how many loads it keeps outstanding (two fragments: 41 us for 100 MB; see profiles/r2_dcgan28_*)
+    constexpr int NF = KS == 1 ? 4 : 2;
+    for (int f0 = wave * NF; f0 * 16 < npix; f0 += 4 * NF) {
+        bf16x8_t xf[NF][KS];
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
+        for (int j = 0; j < NF; ++j) {
             const int p = (f0 + j) * 16 + fr;
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
@@ -111,7 +114,7 @@ __global__ __launch_bounds__(256) void tapfold_kernel(const TapFoldArgs a) {
             }
         }
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
+        for (int j = 0; j < NF; ++j) {
             const int p = (f0 + j) * 16 + fr;
             f32x4 acc[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
 #pragma unroll

@@ -153,6 +153,7 @@ class ConvOp(Op):
         self.out_buffer = None          # optional destination of the next forward's output ("out" path only)
         # BatchNorm applied on load ("out" path): the BN in front of this layer hands over (scale, shift, groups,
         # c_true) instead of writing its output; the taps kernel and the weight-gradient kernel read x through it
+        self._slabs = {}                # persistent zeroed split-K slabs of the boxed weight gradient ("in" path)
         self.in_affine = None           # set by BNOp.fwd for the next forward only
         self.x_affine = None            # what the last training forward used (for backward)
 
@@ -240,7 +241,7 @@ class ConvOp(Op):
             if need_dw:                 # dW[n][t] -> canonical [O][KH][KW][8] slot (n, t, channel 0)
                 def wg():
                     hip.conv_wgrad(self.x, dy, g1, "A", out=self.gkernel,
-                                   box=(g.O, T, T * 8, 0, 8, self.gkernel.numel()))
+                                   box=(g.O, T, T * 8, 0, 8, self.gkernel.numel()), slab_holder=self._slabs)
                     self._bias_grad(dy)
                 _BR.run(wg, dy)
             if need_dx:

@@ -1346,7 +1346,23 @@ def _wgrad2_plans(g: ConvGeom, B: int, Cx: int, Ny: int, n_lim: int, c_lim: int)
     return plans
 
 
-def conv_wgrad(x, dy, g: ConvGeom, layout="A", out=None, box=None, x_affine=None):
+def _box_slab(holder, n, box, device):
+    """Split-K slab of a custom-box weight gradient.  The kernel writes box elements only and the slab reduce sweeps
+    every element, so the rest must read as zero -- but nothing ever writes it: a zeroed slab kept by the caller
+    (`holder`, a dict owned by the layer; filled on the first, uncaptured call) stays valid for the layer's life
+    instead of a 6 MB fill per step.  Without a holder the slab is zero-filled per call."""
+    if holder is None:
+        return torch.zeros(n, dtype=torch.float32, device=device)
+    key = (n, tuple(box))
+    slab = holder.get(key)
+    if slab is None:
+        slab = torch.zeros(n, dtype=torch.float32, device=device)
+        if not torch.cuda.is_current_stream_capturing():
+            holder[key] = slab
+    return slab
+
+
+def conv_wgrad(x, dy, g: ConvGeom, layout="A", out=None, box=None, x_affine=None, slab_holder=None):
     """`box` = (n_lim, c_lim, sn, st, sc, numel): write dW[n][t][c] at out[n*sn + t*st + c*sc] instead of one of
     the two standard layouts (the caller guarantees `out` has `numel` elements and is zero elsewhere).
     `x_affine` = (scale, shift, c_true), fp32 [Ip]: X is read as bf16(X * scale + shift) on real pixels (a
@@ -1362,10 +1378,10 @@ def conv_wgrad(x, dy, g: ConvGeom, layout="A", out=None, box=None, x_affine=None
         total = None
         for b0, b1 in ranges:
             if total is None:
-                total = conv_wgrad(x[b0:b1], dy[b0:b1], g, layout, out, box, x_affine)
+                total = conv_wgrad(x[b0:b1], dy[b0:b1], g, layout, out, box, x_affine, slab_holder)
             else:
                 total.add_(conv_wgrad(x[b0:b1], dy[b0:b1], g, layout, torch.empty_like(total) if box is None
-                                      else torch.zeros_like(total), box, x_affine))
+                                      else torch.zeros_like(total), box, x_affine, slab_holder))
         return total
     dev = x.device
     T = g.KH * g.KW
@@ -1439,7 +1455,8 @@ def conv_wgrad(x, dy, g: ConvGeom, layout="A", out=None, box=None, x_affine=None
         ksplit = _wgrad_ksplit(M, T, n_lim, c_lim)
         slab = None
         if ksplit > 1:
-            slab = (torch.zeros if box is not None else torch.empty)(ksplit * numel, dtype=torch.float32, device=dev)
+            slab = _box_slab(slab_holder, ksplit * numel, box, dev) if box is not None else \
+                torch.empty(ksplit * numel, dtype=torch.float32, device=dev)
         rc = _wgrad(dy.data_ptr(), x.data_ptr(), out.data_ptr(), _p(slab), numel, ksplit, B, g.OH, g.OW, Op, g.H,
                     g.W, Ip, g.KH, g.KW, g.sh, g.sw, g.dh, g.dw, g.pt, g.pl, n_lim, c_lim, sn, st, sc, xs, xh, xct,
                     _stream())
@@ -1478,7 +1495,8 @@ def conv_wgrad(x, dy, g: ConvGeom, layout="A", out=None, box=None, x_affine=None
     # with a custom box the slab reduce also sweeps elements the kernel never writes: they must read as 0
     slab = None
     if ksplit > 1:
-        slab = (torch.zeros if box is not None else torch.empty)(ksplit * numel, dtype=torch.float32, device=dev)
+        slab = _box_slab(slab_holder, ksplit * numel, box, dev) if box is not None else \
+            torch.empty(ksplit * numel, dtype=torch.float32, device=dev)
     rc = _wgrad(dy.data_ptr(), x.data_ptr(), out.data_ptr(), _p(slab), numel, ksplit, B, g.OH, g.OW, Op, g.H,
                 g.W, Ip, g.KH, g.KW, g.sh, g.sw, g.dh, g.dw, g.pt, g.pl, n_lim, c_lim, sn, st, sc, xs, xh, xct,
                 _stream())
