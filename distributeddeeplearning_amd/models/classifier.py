@@ -43,6 +43,7 @@ class RandomModel:
         self.verbose = verbose
         self.dp, self.averager = dp, averager
         self.net = Network(compiled.spec, device, seed)
+        self.net.set_no_input_grad()    # a classifier never needs the gradient of its input images
         # wgrad chain as a parallel graph branch (network.SideBranch): +2 % on the 5-replica step at batch 512, but at
         # the reference's batch 32 the fork / join edges cost more than they hide (10 MLP members: 66.9 -> 44.4 ms
         # per 32 steps without it) and they keep members on different streams from overlapping (-> 22.3 ms)

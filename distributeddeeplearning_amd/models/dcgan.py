@@ -144,6 +144,7 @@ class GANTrainer:
         # same seed on every rank -> identical initial replicas (dp.broadcast makes it certain)
         self.G = Network(generator_spec(cfg.size, cfg.base, cfg.noise_dim), device, cfg.seed + 1, bn_mode)
         self.D = Network(discriminator_spec(cfg.size, cfg.base), device, cfg.seed + 2, bn_mode)
+        self.G.set_no_input_grad()      # nothing differentiates with respect to the noise
         ocfg = OptimConfig.tf_adam(cfg.lr, fresh_double=cfg.reference_exact)
         self.optG, self.optD = FlatOptimizer(self.G, ocfg), FlatOptimizer(self.D, ocfg)
         self._ocfg = ocfg

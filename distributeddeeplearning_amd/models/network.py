@@ -708,6 +708,16 @@ class Network:
         self.S.copy_(S)
         self.refresh_working_copies()
 
+    def first_param_op(self):
+        return next((op for op in self.ops if op.has_params), None)
+
+    def set_no_input_grad(self, flag: bool = True):
+        """Promise that `backward(need_input_grad=True)` is never called (a generator, a classifier): the first
+        layer's adjoint-direction weight copy is then never read and drops out of the per-step relayout (the
+        generator's Dense 128 -> 6272 is 3/4 of its relayout work)."""
+        self.no_input_grad = bool(flag)
+        self._relayout_tab = None
+
     def refresh_working_copies(self, cast: bool = True):
         """Re-derive the bf16 working copies from the fp32 master (device only).  The fused
         optimizer already writes `Pc`, in which case `cast=False` only redoes the relayouts."""
@@ -802,6 +812,8 @@ class Network:
         (y of the producer network's last layer: G -> D chains), `dy_premultiplied` tells this network that
         its incoming dY already carries the last layer's act'(y)."""
         start = len(self.ops) if start is None else (start if start >= 0 else len(self.ops) + start)
+        if need_input_grad and getattr(self, "no_input_grad", False):
+            raise ValueError("this network was declared input-gradient-free (set_no_input_grad)")
         first_param = next((i for i, op in enumerate(self.ops) if op.has_params), len(self.ops))
         _BR.enabled = self.branch_wgrad
         for op in self.ops:

@@ -335,7 +335,10 @@ def relayout_alt(net):
     tab = getattr(net, "_relayout_tab", None)
     if tab is None:
         descs, mx = [], 0
+        skip = net.first_param_op() if getattr(net, "no_input_grad", False) else None
         for op, alt_off in net._alt:
+            if op is skip:              # its adjoint-direction copy only ever serves the network-input gradient
+                continue
             R, T, Cc, Rp = op.relayout_dims()
             poff = net._pmap[(op.name, "kernel")].offset
             descs.append((poff, alt_off, R, T, Cc, Rp))
