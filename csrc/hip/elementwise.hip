@@ -1147,6 +1147,46 @@ __global__ void relayout_gather_kernel(const float* __restrict__ P, bf16_t* __re
     }
 }
 
+// Both kinds of weight copy of a network in ONE launch: blockIdx.y < n_alt walks an alternate-layout descriptor,
+// the rest walk strided-gather descriptors (two launches per optimizer step otherwise, each a few microseconds
+// of mostly launch latency).
+__global__ void relayout_both_kernel(const float* __restrict__ P, bf16_t* __restrict__ alt,
+                                     const RelayoutDesc* __restrict__ adescs, int n_alt, bf16_t* __restrict__ gout,
+                                     const GatherDesc* __restrict__ gdescs) {
+    if ((int)blockIdx.y < n_alt) {
+        const RelayoutDesc d = adescs[blockIdx.y];
+        const long total = (long)d.C * d.T * d.Rp;
+        const float* src = P + d.src_off;
+        bf16_t* dst = alt + d.dst_off;
+        for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+            int r = (int)(i % d.Rp);
+            long q = i / d.Rp;
+            int t = (int)(q % d.T);
+            int c = (int)(q / d.T);
+            float v = r < d.R ? src[((long)r * d.T + t) * d.C + c] : 0.f;
+            dst[i] = f2bf(v);
+        }
+    } else {
+        const GatherDesc d = gdescs[blockIdx.y - n_alt];
+        const long total = (long)d.R2 * d.C2;
+        for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+            int c = (int)(i % d.C2);
+            int r = (int)(i / d.C2);
+            float v = (r < d.R1 && c < d.C1) ? P[d.src_off + r * d.sr + c * d.sc] : 0.f;
+            gout[d.dst_off + i] = f2bf(v);
+        }
+    }
+}
+
+DDL_API void ddl_relayout_both(const float* P, void* alt, const void* adescs, int n_alt, void* gout,
+                               const void* gdescs, int n_gather, long max_elems, hipStream_t s) {
+    if (n_alt + n_gather <= 0) return;
+    int gx = ew_grid(max_elems);
+    if (gx > 256) gx = 256;
+    relayout_both_kernel<<<dim3(gx, n_alt + n_gather), EW_BLOCK, 0, s>>>(
+        P, (bf16_t*)alt, (const RelayoutDesc*)adescs, n_alt, (bf16_t*)gout, (const GatherDesc*)gdescs);
+}
+
 DDL_API void ddl_relayout_gather(const float* P, void* out, const void* descs, int n, long max_elems,
                                  hipStream_t s) {
     if (n <= 0) return;

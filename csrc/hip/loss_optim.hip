@@ -295,11 +295,20 @@ __global__ void optim_kernel(float4* __restrict__ P, const float4* __restrict__ 
                              float4* __restrict__ Vo, uint2* __restrict__ Pc, int* __restrict__ step,
                              long n4, int kind, float lr, float b1, float b2, float eps, float rho,
                              float gscale, const float4* __restrict__ avg, float avg_w) {
-    const OptimHyper h = optim_prepare(kind, lr, b1, b2, eps, rho, step);
+    // step = {completed updates, ticket}.  Every block reads the counter before it finishes; the LAST block to
+    // finish advances it (no one-thread kernel in front of every optimizer launch).
+    const OptimHyper h = optim_prepare(kind, lr, b1, b2, eps, rho, step, 1);
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
         float4 g4 = G[i];
         g4.x *= gscale; g4.y *= gscale; g4.z *= gscale; g4.w *= gscale;
         optim_update4(h, P, Mo, Vo, Pc, i, g4, avg, avg_w);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        if (atomicAdd(step + 1, 1) == (int)gridDim.x - 1) {
+            step[1] = 0;
+            atomicAdd(step, 1);
+        }
     }
 }
 
@@ -310,7 +319,6 @@ DDL_API void ddl_optim_step(float* P, const float* G, float* M, float* V, void* 
                             float lr, float b1, float b2, float eps, float rho, float gscale, const float* avg,
                             float avg_w, hipStream_t s) {
     long n4 = n / 4;
-    step_inc_kernel<<<1, 1, 0, s>>>(step);
     long g = (n4 + 255) / 256;
     int grid = (int)(g > 2048 ? 2048 : (g < 1 ? 1 : g));
     optim_kernel<<<grid, 256, 0, s>>>((float4*)P, (const float4*)G, (float4*)M, (float4*)V, (uint2*)Pc, step, n4,

@@ -11,10 +11,12 @@ struct OptimHyper {
 };
 
 __device__ __forceinline__ OptimHyper optim_prepare(int kind, float lr, float b1, float b2, float eps, float rho,
-                                                    const int* __restrict__ step) {
+                                                    const int* __restrict__ step, int t_add = 0) {
+    // t_add = 1: the counter still holds the number of COMPLETED updates (the calling kernel advances it itself
+    // when its last block finishes); 0: somebody advanced it before the launch
     OptimHyper h{kind, lr, b1, b2, eps, rho, lr, lr};
     if (kind == 0) {
-        float t = (float)step[0];
+        float t = (float)(step[0] + t_add);
         h.lr_t = lr * sqrtf(1.f - powf(b2, t)) / (1.f - powf(b1, t));
     } else if (kind == 3) {
         h.lr_t = lr * sqrtf(1.f - b2) / (1.f - b1);

@@ -726,8 +726,7 @@ class Network:
         hip = F.hip_backend()
         if cast:
             hip.cast_f32_to_bf16(self.P, self.Pc)
-        hip.relayout_alt(self)
-        hip.relayout_gather(self)
+        hip.relayout_all(self)
 
     # ------------------------------------------------------------------ execution
     def set_bn_mode(self, mode: str):

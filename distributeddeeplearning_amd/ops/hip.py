@@ -74,6 +74,7 @@ _col2im = _sig("ddl_col2im_1ch", ci, vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, ci,
 _tapfold = _sig("ddl_tapfold_1ch", ci, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, cf, vp, ci,
                 cf, vp, vp, ci, ci, ci, vp)
 _gather = _sig("ddl_relayout_gather", None, vp, vp, vp, ci, cl, vp)
+_relayout_both = _sig("ddl_relayout_both", None, vp, vp, vp, ci, vp, vp, ci, cl, vp)
 _gemm_sk = _sig("ddl_gemm_sk", ci, vp, vp, vp, vp, cl, ci, ci, ci, ci, cf, vp)
 _philox = _sig("ddl_philox_uniform", None, vp, cl, vp, cf, cf, vp)
 _igemm = _sig("ddl_igemm_conv", ci, vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci,
@@ -330,7 +331,7 @@ def cast_f32_to_bf16(src, dst):
     _done()
 
 
-def relayout_alt(net):
+def relayout_alt(net, launch=True):
     """Refresh every alternate-layout weight copy of `net` in one launch."""
     tab = getattr(net, "_relayout_tab", None)
     if tab is None:
@@ -350,12 +351,27 @@ def relayout_alt(net):
         dev = torch.from_numpy(arr.view(np.uint8).copy()).to(net.device) if len(descs) else None
         tab = net._relayout_tab = (dev, len(descs), mx)
     dev, n, mx = tab
-    if n:
+    if n and launch:
         _relayout(net.P.data_ptr(), net.Palt.data_ptr(), dev.data_ptr(), n, mx, _stream())
         _done()
 
 
-def relayout_gather(net):
+def relayout_all(net):
+    """Alternate-layout and strided-gather weight copies of `net`, one launch when it has both kinds."""
+    if not net._gather:
+        return relayout_alt(net)
+    relayout_alt(net, launch=False)
+    relayout_gather(net, launch=False)
+    adev, na, amx = net._relayout_tab
+    gdev, ng, gmx = net._gather_tab
+    if na == 0:
+        return relayout_gather(net)
+    _relayout_both(net.P.data_ptr(), net.Palt.data_ptr(), adev.data_ptr(), na, net.Pg.data_ptr(), gdev.data_ptr(), ng,
+                   max(amx, gmx), _stream())
+    _done()
+
+
+def relayout_gather(net, launch=True):
     """Refresh the strided-gather weight copies (one-channel conv path) of `net` in one launch."""
     if not net._gather:
         return
@@ -368,6 +384,8 @@ def relayout_gather(net):
         mx = max(d[4] * d[5] for d in net._gather)
         tab = net._gather_tab = (torch.from_numpy(arr.view(np.uint8).copy()).to(net.device), len(net._gather), mx)
     dev, n, mx = tab
+    if not launch:
+        return
     _gather(net.P.data_ptr(), net.Pg.data_ptr(), dev.data_ptr(), n, mx, _stream())
     _done()
 
