@@ -216,3 +216,135 @@ DDL_API int ddl_tapfold_1ch(const void* x, const void* w, const float* bias, voi
 #undef TF_CASE
     return 1;
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// Direct convolution FROM a single-channel image (the discriminator's first layer; the input gradient of the
+// generator's last layer): y[b][oh][ow][n] = act(bias[n] + sum_t img[b][oh*sh + kh*dh - pt][ow*sw + kw*dw - pl] * w[n][t]).
+// The unfused path materialises the taps-as-channels tensor (im2col_1ch, [B][OH][OW][32]) and runs a 1x1 GEMM over
+// it: 25-50 MB written and read back per call.  Here a block stages its image once into LDS as a zero-haloed plane
+// of bf16 scalars (2 KB for 28x28) and every lane assembles its MFMA B fragment -- 8 consecutive taps of one output
+// pixel -- from eight 2-byte LDS reads at per-lane constant offsets.  Same MFMA operand order and rounding as
+// gemm_sk on the im2col tensor, so results are bit-identical to the unfused path.  T <= 32 taps, N <= 64.
+struct TapConvArgs {
+    const bf16_t* img;        // [B][H][W][8] (channel 0 real)
+    const bf16_t* w;          // [N][Tp] rows (Tp = taps padded to 8)
+    const float* bias;        // [>= n_lim] or null
+    bf16_t* y;                // [B][OH][OW][Np]
+    int B, H, W, OH, OW, KH, KW, sh, sw, dh, dw, pt, pl, T, Tp, Np, n_lim, act;
+    float alpha;
+    int PH, PW;
+};
+
+template <int NT, bool SLOW>
+__global__ __launch_bounds__(256) void tapconv_1ch_kernel(const TapConvArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    bf16_t* sI = (bf16_t*)smem;                 // [PH][PW] zero-haloed plane
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int fr = lane & 15, fq = lane >> 4;
+    const int b = blockIdx.x;
+    const int plane = a.PH * a.PW;
+    for (int i = tid; i < plane; i += 256) sI[i] = 0;
+    __syncthreads();
+    {
+        const uint4* src = (const uint4*)a.img + (size_t)b * a.H * a.W;
+        const float invW = 1.0f / (float)a.W;
+        for (int i = tid; i < a.H * a.W; i += 256) {
+            const int r = tf_fdiv(i, invW), c = i - r * a.W;
+            sI[(r + a.pt) * a.PW + c + a.pl] = (bf16_t)(src[i].x & 0xffffu);
+        }
+    }
+    // weights: lane (row n = 16t + fr, taps fq*8 .. +7), zero beyond Tp / N
+    bf16x8_t wf[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const int n = 16 * t + fr;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (n < a.n_lim && fq * 8 < a.Tp) v = *(const uint4*)(a.w + (size_t)n * a.Tp + fq * 8);
+        wf[t] = __builtin_bit_cast(bf16x8_t, v);
+    }
+    int toff[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int t = fq * 8 + j;
+        const int kh = t / a.KW, kw = t - kh * a.KW;
+        toff[j] = t < a.T ? (kh * a.dh) * a.PW + kw * a.dw : 0;
+    }
+    float bv[NT][4];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int n = 16 * t + 4 * fq + e;
+            bv[t][e] = (a.bias && n < a.n_lim) ? a.bias[n] : 0.f;
+        }
+    __syncthreads();
+
+    const int npix = a.OH * a.OW;
+    const float invOW = 1.0f / (float)a.OW;
+    const int act = a.act;
+    const float alpha = a.alpha;
+    for (int f = wave; f * 16 < npix; f += 4) {
+        const int p = f * 16 + fr;
+        const int pp = p < npix ? p : 0;
+        const int oh = tf_fdiv(pp, invOW), ow = pp - oh * a.OW;
+        const int base = (oh * a.sh) * a.PW + ow * a.sw;
+        uint32_t q[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            q[j] = (uint32_t)sI[base + toff[2 * j]] | ((uint32_t)sI[base + toff[2 * j + 1]] << 16);
+        typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+        const bf16x8_t xf = __builtin_bit_cast(bf16x8_t, (u32x4_t){q[0], q[1], q[2], q[3]});
+        f32x4 acc[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+            acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[t], xf, (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+        if (p < npix) {
+            bf16_t* dst = a.y + ((size_t)b * npix + p) * a.Np;
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float x = acc[t][e] + bv[t][e];
+                    if (SLOW) x = act_apply(x, act, alpha);
+                    else if (act == ACT_RELU) x = fmaxf(x, 0.f);
+                    else if (act == ACT_LEAKY) x = x > 0.f ? x : alpha * x;
+                    v[e] = (16 * t + 4 * fq + e < a.n_lim) ? x : 0.f;
+                }
+                if (16 * t + 4 * fq < a.Np)
+                    *(uint2*)(dst + 16 * t + 4 * fq) = make_uint2(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]));
+            }
+        }
+    }
+}
+
+// Returns 0 on success, 1 if the shape is outside this kernel's range (nothing launched), < 0 on bad arguments.
+DDL_API int ddl_tapconv_1ch(const void* img, const void* w, const float* bias, void* y, int B, int H, int W, int OH,
+                            int OW, int KH, int KW, int sh, int sw, int dh, int dw, int pt, int pl, int Tp, int Np,
+                            int n_lim, int act, float alpha, hipStream_t s) {
+    if (B <= 0 || KH * KW <= 0 || Np % 8 || Tp % 8 || n_lim <= 0 || n_lim > Np) return -1;
+    if (KH * KW > 32 || Tp > 32 || Tp < KH * KW || Np > 64) return 1;
+    if ((long)B * OH * OW * Np >= (1L << 31) || (long)B * H * W * 8 >= (1L << 31)) return 1;
+    TapConvArgs a;
+    a.img = (const bf16_t*)img; a.w = (const bf16_t*)w; a.bias = bias; a.y = (bf16_t*)y;
+    a.B = B; a.H = H; a.W = W; a.OH = OH; a.OW = OW; a.KH = KH; a.KW = KW; a.sh = sh; a.sw = sw; a.dh = dh; a.dw = dw;
+    a.pt = pt; a.pl = pl; a.T = KH * KW; a.Tp = Tp; a.Np = Np; a.n_lim = n_lim; a.act = act; a.alpha = alpha;
+    // plane: every tap of every output pixel in range, and the whole image (pt / pl may exceed what outputs reach)
+    int ph = (OH - 1) * sh + (KH - 1) * dh + 1, pw = (OW - 1) * sw + (KW - 1) * dw + 1;
+    if (ph < H + pt) ph = H + pt;
+    if (pw < W + pl) pw = W + pl;
+    a.PH = ph; a.PW = pw;
+    const size_t smem = ((size_t)ph * pw * 2 + 15) / 16 * 16;
+    if (smem > 64 * 1024 || (long)OH * OW >= (1L << 21) || (long)H * W >= (1L << 21)) return 1;
+    const bool fast = act == ACT_LINEAR || act == ACT_RELU || act == ACT_LEAKY;
+    const int NT = (Np + 15) / 16;
+#define TC_CASE(NT_) \
+    if (NT == NT_) { \
+        if (fast) tapconv_1ch_kernel<NT_, false><<<B, 256, smem, s>>>(a); \
+        else tapconv_1ch_kernel<NT_, true><<<B, 256, smem, s>>>(a); \
+        return 0; \
+    }
+    TC_CASE(1) TC_CASE(2) TC_CASE(3) TC_CASE(4)
+#undef TC_CASE
+    return 1;
+}

@@ -143,7 +143,7 @@ class ConvOp(Op):
         self.kernel = self.bias = None            # fp32 master views
         self.gkernel = self.gbias = None          # fp32 gradient views
         self.w_main = self.w_alt = None           # compute-dtype views
-        self.x = self.y = None
+        self.x = self.y = self.x_img = None
         # single-channel fast path (device only): see ops/hip.py im2col_1ch / col2im_1ch
         self.onech = None               # None | "in" (Conv2D 1->N) | "out" (Conv2DTranspose C->1)
         self.g1 = None                  # the equivalent 1x1 geometry on the taps-as-channels tensor
@@ -214,11 +214,14 @@ class ConvOp(Op):
 
     def _fwd_onech(self, x, training):
         g, g1, hip = self.g, self.g1, F.hip_backend()
-        if self.onech == "in":          # im2col -> 1x1 conv with the layer's bias + activation
-            xc = hip.im2col_1ch(x, g)
-            y = hip.conv_fprop(xc, self.w_tap, self.bias, g1, self.act, self.alpha)
-            if training:
-                self.x, self.y = xc, y
+        if self.onech == "in":          # direct conv from the 1-channel image (or im2col -> 1x1 conv)
+            xc = None
+            y = hip.tapconv_1ch(x, self.w_tap, g, self.bias, self.act, self.alpha)
+            if y is None:
+                xc = hip.im2col_1ch(x, g)
+                y = hip.conv_fprop(xc, self.w_tap, self.bias, g1, self.act, self.alpha)
+            if training:                # the taps tensor is only the weight gradient's operand: built there if needed
+                self.x, self.x_img, self.y = xc, x, y
         else:                           # 1x1 conv to taps -> col2im fold with bias + activation (one fused kernel)
             aff, self.in_affine = self.in_affine, None
             y = hip.tapfold_1ch(x, self.w_main.reshape(g1.O, -1), g, self.bias, self.act, self.alpha,
@@ -240,6 +243,8 @@ class ConvOp(Op):
         if self.onech == "in":
             if need_dw:                 # dW[n][t] -> canonical [O][KH][KW][8] slot (n, t, channel 0)
                 def wg():
+                    if self.x is None:
+                        self.x = hip.im2col_1ch(self.x_img, g)
                     hip.conv_wgrad(self.x, dy, g1, "A", out=self.gkernel,
                                    box=(g.O, T, T * 8, 0, 8, self.gkernel.numel()), slab_holder=self._slabs)
                     self._bias_grad(dy)
@@ -249,7 +254,12 @@ class ConvOp(Op):
                 if dx is None:
                     dx = hip.col2im_1ch(hip.conv_dgrad(dy, self.w_tapT, g1), g, mul=mul)
         else:
-            dyc = hip.im2col_1ch(dy, g)
+            dyc = [None]                # the taps tensor of dY: the weight gradient's operand (side branch)
+            if need_dx:                 # input gradient straight from the dY image when nothing is fused behind it
+                dx = hip.tapconv_1ch(dy, self.w_tapT, g) if mul is None else None
+                if dx is None:
+                    dyc[0] = hip.im2col_1ch(dy, g)
+                    dx = hip.conv_dgrad(dyc[0], self.w_tapT, g1, mul=mul)
             if need_dw:
                 x, xa = self.x, None
                 if self.x_affine is not None:
@@ -260,11 +270,10 @@ class ConvOp(Op):
                         x = hip.bn_apply(x, sc, sh, None, 0.3, ctrue, groups)
 
                 def wg():
-                    hip.conv_wgrad(x, dyc, g1, "A", out=self.gkernel, x_affine=xa)
+                    d = dyc[0] if dyc[0] is not None else hip.im2col_1ch(dy, g)
+                    hip.conv_wgrad(x, d, g1, "A", out=self.gkernel, x_affine=xa)
                     self._bias_grad(dy)
-                _BR.run(wg, dy, dyc)
-            if need_dx:
-                dx = hip.conv_dgrad(dyc, self.w_tapT, g1, mul=mul)
+                _BR.run(wg, dy)
         return dx
 
     def fwd(self, x, training):
@@ -340,7 +349,7 @@ class ConvOp(Op):
         return dx
 
     def release(self):
-        self.x = self.y = self.x_affine = None
+        self.x = self.y = self.x_affine = self.x_img = None
 
 
 class BNOp(Op):
@@ -855,7 +864,7 @@ class Network:
         that part of the batch alone.  Used when one forward serves two purposes -- the DCGAN generator runs ONCE
         on [z1 ; z2] per step, the first half feeds the discriminator phase, only the second half is trained."""
         for op in self.ops:
-            for attr in ("x", "y"):
+            for attr in ("x", "y", "x_img"):
                 t = getattr(op, attr, None)
                 if isinstance(t, torch.Tensor) and t.dim() >= 1:
                     setattr(op, attr, t[lo:hi])

@@ -73,6 +73,8 @@ _col2im = _sig("ddl_col2im_1ch", ci, vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, ci,
                cf, vp)
 _tapfold = _sig("ddl_tapfold_1ch", ci, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, cf, vp, ci,
                 cf, vp, vp, ci, ci, ci, vp)
+_tapconv = _sig("ddl_tapconv_1ch", ci, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci,
+                cf, vp)
 _gather = _sig("ddl_relayout_gather", None, vp, vp, vp, ci, cl, vp)
 _relayout_both = _sig("ddl_relayout_both", None, vp, vp, vp, ci, vp, vp, ci, cl, vp)
 _gemm_sk = _sig("ddl_gemm_sk", ci, vp, vp, vp, vp, cl, ci, ci, ci, ci, cf, vp)
@@ -524,6 +526,52 @@ def tapfold_1ch(x, w, g: ConvGeom, bias=None, act=None, alpha=0.3, out=None, mul
         return None
     _done()
     return img
+
+
+TAPCONV = os.environ.get("DDL_TAPCONV", "1") == "1"
+
+
+def tapconv_1ch(img, w, g: ConvGeom, bias=None, act=None, alpha=0.3, out=None):
+    """Direct convolution from a single-channel image (csrc/hip/onech_fused.hip: tapconv_1ch_kernel):
+    img [B][g.H][g.W][8] (channel 0 real), w [N][1][1][Tp] bf16 (row n = the taps of output channel n) ->
+    [B][g.OH][g.OW][pad8(N)] = act(bias + sum_t img[tap t of the pixel] * w[n][t]): im2col_1ch + the 1x1 GEMM in
+    one kernel, bit-identical to them.  Returns None when the shape is outside the kernel's range."""
+    if not TAPCONV:
+        return None
+    _chk_act(img, "img")
+    B = img.shape[0]
+    T = g.KH * g.KW
+    if tuple(img.shape[1:]) != (g.H, g.W, 8):
+        raise ValueError(f"tapconv_1ch: image {tuple(img.shape)} vs geometry {g}")
+    if not (w.is_cuda and w.dtype == torch.bfloat16 and w.is_contiguous()) or w.dim() != 4:
+        raise ValueError("tapconv_1ch: weights must be contiguous bf16 [N][1][1][Tp]")
+    N, Tp = w.shape[0], w.shape[-1]
+    Np = pad8(N)
+    if T > 32 or Tp > 32 or Tp < T or Np > 64:
+        return None
+    if bias is not None:
+        _chk_f32(bias, N, "bias")
+    if out is not None:
+        _chk_act(out, "out")
+        if tuple(out.shape) != (B, g.OH, g.OW, Np):
+            raise ValueError(f"tapconv_1ch: out {tuple(out.shape)} != {(B, g.OH, g.OW, Np)}")
+        y = out
+    else:
+        y = torch.empty(B, g.OH, g.OW, Np, dtype=torch.bfloat16, device=img.device)
+    ranges = _batch_ranges(B, max(g.OH * g.OW * Np, g.H * g.W * 8))
+    if ranges is not None:
+        for b0, b1 in ranges:
+            if tapconv_1ch(img[b0:b1], w, g, bias, act, alpha, y[b0:b1]) is None:
+                return None
+        return y
+    rc = _tapconv(img.data_ptr(), w.data_ptr(), _p(bias), y.data_ptr(), B, g.H, g.W, g.OH, g.OW, g.KH, g.KW, g.sh,
+                  g.sw, g.dh, g.dw, g.pt, g.pl, Tp, Np, N, ACT_CODE[act], alpha, _stream())
+    if rc < 0:
+        raise ValueError(f"tapconv_1ch rejected its arguments (rc={rc})")
+    if rc > 0:
+        return None
+    _done()
+    return y
 
 
 def pad_channels(x, c_phys, index=None, scale=1.0, c_true=None):

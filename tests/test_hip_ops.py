@@ -504,6 +504,36 @@ def test_tapfold_fused_equals_gemm_plus_col2im(hip, case, C):
         assert torch.equal(got, ref), kw.keys()
 
 
+@pytest.mark.parametrize("case", ONECH_CASES)
+@pytest.mark.parametrize("N", [32, 20, 64])
+def test_tapconv_fused_equals_im2col_plus_gemm(hip, case, N):
+    """Direct convolution from the single-channel image must reproduce im2col_1ch + the 1x1 GEMM bit for bit (same
+    MFMA k order over the taps, same bias / activation epilogue), padded output channels staying zero."""
+    H, W, k, s, d, pad = case
+    g = G.conv2d_geom(H, W, 1, N, k, s, d, pad)
+    T, Tp = g.KH * g.KW, hip.pad8(g.KH * g.KW)
+    if T > 32:
+        pytest.skip("outside the fused kernel's range")
+    B = 21
+    torch.manual_seed(16)
+    img = torch.zeros(B, H, W, 8)
+    img[..., 0] = torch.randn(B, H, W)
+    img = img.bfloat16().cuda().contiguous()
+    w = torch.zeros(N, 1, 1, Tp)
+    w[..., :T] = torch.randn(N, 1, 1, T) * 0.3
+    w = w.bfloat16().cuda().contiguous()
+    bias = torch.randn(N, device="cuda")
+    g1 = G.ConvGeom(g.OH, g.OW, T, g.OH, g.OW, N, 1, 1).check()
+    xc = hip.im2col_1ch(img, g)
+    for kw in (dict(bias=None, act=None), dict(bias=bias, act="leaky"), dict(bias=bias, act="tanh")):
+        ref = hip.conv_fprop(xc, w, kw["bias"], g1, kw["act"], 0.3)
+        got = hip.tapconv_1ch(img, w, g, kw["bias"], kw["act"], 0.3)
+        assert got is not None
+        assert torch.equal(got, ref), kw
+        if N % 8:
+            assert float(got[..., N:].float().abs().max()) == 0.0
+
+
 @pytest.mark.parametrize("C,ctrue,groups", [(32, 32, 1), (32, 32, 2), (24, 20, 1), (64, 64, 3)])
 def test_tapfold_input_affine_equals_materialised_bn(hip, C, ctrue, groups):
     """BatchNorm applied on load: tapfold(x, in_affine) == tapfold(bn_apply(x)) bit for bit (same bf16 rounding of
