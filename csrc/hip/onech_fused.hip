@@ -246,11 +246,25 @@ __global__ __launch_bounds__(256) void tapconv_1ch_kernel(const TapConvArgs a) {
     for (int i = tid; i < plane; i += 256) sI[i] = 0;
     __syncthreads();
     {
-        const uint4* src = (const uint4*)a.img + (size_t)b * a.H * a.W;
+        // channel 0 of every pixel: 4-byte loads at a 16-byte stride, four in flight per thread before any LDS store
+        const uint32_t* src = (const uint32_t*)a.img + (size_t)b * a.H * a.W * 4;
         const float invW = 1.0f / (float)a.W;
-        for (int i = tid; i < a.H * a.W; i += 256) {
-            const int r = tf_fdiv(i, invW), c = i - r * a.W;
-            sI[(r + a.pt) * a.PW + c + a.pl] = (bf16_t)(src[i].x & 0xffffu);
+        const int HW = a.H * a.W;
+        for (int i0 = tid; i0 < HW; i0 += 1024) {
+            uint32_t v[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int i = i0 + k * 256;
+                v[k] = i < HW ? src[(size_t)i * 4] : 0u;
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int i = i0 + k * 256;
+                if (i < HW) {
+                    const int r = tf_fdiv(i, invW), c = i - r * a.W;
+                    sI[(r + a.pt) * a.PW + c + a.pl] = (bf16_t)(v[k] & 0xffffu);
+                }
+            }
         }
     }
     // weights: lane (row n = 16t + fr, taps fq*8 .. +7), zero beyond Tp / N
