@@ -287,9 +287,10 @@ class _CommOps:
 
 
 class SpmdEnsemble:
-    """The same generations under `torchrun`: one process per GPU, member i lives on rank
-    i % world, every rank draws the same architectures from the same seeded RNG, and the only
-    communication is at generation boundaries."""
+    """The same generations under `torchrun`: one process per GPU, every rank draws the same architectures from
+    the same seeded RNG, the members of a generation are spread over the ranks by estimated cost (longest
+    processing time first onto the least-loaded rank -- every rank computes the same assignment, nothing is
+    communicated), and the only communication is at generation boundaries."""
 
     def __init__(self, space: SearchSpace, device, comm=None, data_kw: Optional[dict] = None,
                  verbose: bool = False):
@@ -310,17 +311,46 @@ class SpmdEnsemble:
         self.members: List[dict] = []     # {number, owner, compiled, acc, actor (owner only)}
 
     def _add(self, compiled, parent=None) -> dict:
+        """Register a member (seeds drawn now, in member order); its owner rank and actor follow in `_place`."""
         n = len(self.members)
         sample_seed = int(self.rng.integers(0, 2 ** 31 - 1))
         seed = int(self.rng.integers(0, 2 ** 31 - 1))
-        m = dict(number=n, owner=n % self.world, compiled=compiled, acc=float("nan"), actor=None)
-        if m["owner"] == self.rank:
-            m["actor"] = MemberActor(self.space, compiled, sample_seed, seed, n, self.data_kw, parent,
-                                     device=str(self.device), verbose=self.verbose)
+        m = dict(number=n, owner=None, compiled=compiled, acc=float("nan"), actor=None,
+                 _make=(sample_seed, seed, parent))
         self.members.append(m)
         return m
 
+    @staticmethod
+    def member_cost(compiled) -> float:
+        """Relative training cost of a member: multiply-accumulates of one forward pass (convolutions count their
+        output pixels, Dense layers their weights); parameters alone would rate a small conv stack as free."""
+        spec = compiled.spec
+        shapes = spec.infer_shapes()
+        cost = 1.0
+        for lname, wname, ks, _ in spec.param_specs():
+            n = float(np.prod(ks))
+            if "kernel" in wname and spec.layer(lname).kind != "dense":
+                out = shapes[lname]
+                n *= float(out[0] * out[1])          # every output pixel applies the whole kernel
+            cost += n
+        return cost
+
+    def _place(self, new: List[dict]):
+        """Longest-processing-time-first assignment of a generation to the ranks; identical on every rank."""
+        load = [0.0] * self.world
+        order = sorted(range(len(new)), key=lambda i: (-self.member_cost(new[i]["compiled"]), i))
+        for i in order:
+            r = min(range(self.world), key=lambda k: (load[k], k))
+            load[r] += self.member_cost(new[i]["compiled"])
+            new[i]["owner"] = r
+        for m in new:
+            sample_seed, seed, parent = m.pop("_make")
+            if m["owner"] == self.rank:
+                m["actor"] = MemberActor(self.space, m["compiled"], sample_seed, seed, m["number"], self.data_kw,
+                                         parent, device=str(self.device), verbose=self.verbose)
+
     def _train_and_gather(self, new: List[dict]):
+        self._place(new)
         accs = torch.zeros(len(new), dtype=torch.float32, device=self.device)
         train_concurrently([m["actor"].model for m in new if m["actor"] is not None])     # this rank's members
         for i, m in enumerate(new):

@@ -108,3 +108,24 @@ def test_spmd_single_rank_matches_local_semantics():
     accs = [m["acc"] for m in ens.members]
     assert len(accs) == 5 and accs == sorted(accs, reverse=True)
     assert 0 <= ens.get_accuracy() <= 1 and len(ens.member_test_accuracies()) == 5
+
+
+def test_spmd_placement_balances_cost_and_is_rank_independent():
+    """SPMD members were i % world.  Placement is now longest-processing-time-first on an estimated cost,
+    computed identically by every rank: same owners from any rank's point of view, no rank idle, and the heaviest
+    rank within one member of the mean."""
+    from distributeddeeplearning_amd.models import search
+    sp = config.get_space("ddl_normal3", OVER)
+    owners = []
+    for rank in (0, 3):
+        e = SpmdEnsemble(sp, "cpu", data_kw=DATA_KW)
+        e.world, e.rank = 4, rank
+        new = [e._add(search.make_new_model(sp, e.rng, e.data.input_shape, 10)) for _ in range(10)]
+        e._place(new)
+        owners.append([m["owner"] for m in new])
+        assert all((m["actor"] is not None) == (m["owner"] == rank) for m in new)
+        costs = [SpmdEnsemble.member_cost(m["compiled"]) for m in new]
+        load = [sum(c for c, m in zip(costs, new) if m["owner"] == r) for r in range(4)]
+        assert min(load) > 0
+        assert max(load) <= sum(costs) / 4 + max(costs)
+    assert owners[0] == owners[1]
