@@ -461,7 +461,8 @@ DDL_API int ddl_pconv(const void* src, const void* wgt, const float* bias, void*
     a.inv_PW = 1.0f / (float)PW;
     int units = ((B + IMG - 1) / IMG) * bands;
 #define PC_CASE(BN_, FR_) if (BN == BN_ && FR == FR_) return launch_pconv<BN_, FR_>(a, units, smem, s);
-    PC_CASE(16, 4) PC_CASE(16, 8) PC_CASE(32, 4) PC_CASE(32, 8) PC_CASE(64, 4) PC_CASE(64, 8) PC_CASE(128, 4)
+    PC_CASE(16, 4) PC_CASE(16, 8) PC_CASE(32, 2) PC_CASE(32, 4) PC_CASE(32, 8) PC_CASE(64, 2) PC_CASE(64, 4) PC_CASE(64, 8)
+    PC_CASE(128, 4)
 #undef PC_CASE
     return -4;
 }

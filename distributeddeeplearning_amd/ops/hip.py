@@ -911,7 +911,7 @@ def _pconv_candidates(g, mode, B, Cs, Nd, ss, device):
         if base["bands"] == 1:
             imgs |= {max(1, base["IMG"] // 2), base["IMG"] * 2}
         for im in sorted(imgs):
-            for fr in (4, 8):
+            for fr in ((2, 4, 8) if 32 <= Nd <= 64 else (4, 8)):      # FR 2: 128-row passes for small units
                 pl = _pconv_plan(g, mode, B, Cs, Nd, ss, device, budget=budget, img=im, fr=fr, min_rows=64)
                 if pl is None:
                     continue
