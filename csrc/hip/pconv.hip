@@ -238,6 +238,9 @@ __global__ __launch_bounds__(256, (BN * FR >= 512 ? 1 : 2)) void pconv_kernel(co
             // Weight pipeline: loads run three stages ahead (two register sets in flight), the LDS stage
             // is double-buffered, one barrier per stage.  Loads past the last stage are zeros, never stored.
             gload(regA);                 // stage 0
+            // the previous segment's epilogue used the weight stages as its transpose scratch: every wave must be
+            // out of it before stage 0 lands there
+            __syncthreads();
             lstore(0, regA);
             gload(regB);                 // stage 1
             gload(regA);                 // stage 2
@@ -420,9 +423,10 @@ static int launch_pconv(PConvArgs& a, int units, size_t smem, hipStream_t s) {
 }
 
 DDL_API int ddl_pconv_lds_bytes(int BN, int total_stages, long patch_bytes) {
-    long w = 2L * BN * WPITCH, k = (long)total_stages * 64, e = 4L * (16 * (BN * 2 + 16) + 64);
+    // the epilogue's transpose scratch (4 waves x (16 rows x (2 BN + 16) + 64) bytes) aliases the weight stages
+    long w = 2L * BN * WPITCH, k = (long)total_stages * 64;
     long p = (patch_bytes + 15) / 16 * 16;
-    long tot = p + w + k + e;
+    long tot = p + w + k;
     return tot > (1L << 30) ? -1 : (int)tot;
 }
 
@@ -453,8 +457,9 @@ DDL_API int ddl_pconv(const void* src, const void* wgt, const float* bias, void*
     if ((long)IMG * PH * PW * (Cs / 8) >= (1L << 22)) return -2;
     a.w_off = (int)((patch + 15) / 16 * 16);
     a.k_off = a.w_off + 2 * BN * WPITCH;
-    a.e_off = a.k_off + total_stages * 64;
-    size_t smem = (size_t)a.e_off + 4 * (16 * (BN * 2 + 16) + 64);
+    a.e_off = a.w_off;                    // epilogue scratch aliases the weight stages (see the kernel)
+    if (4 * (16 * (BN * 2 + 16) + 64) > 2 * BN * WPITCH) return -2;
+    size_t smem = (size_t)a.k_off + (size_t)total_stages * 64;
     if (smem > 160 * 1024) return -2;
     a.inv_per_img = 1.0f / (float)(PH * PW * (Cs / 8));
     a.inv_cs8 = 1.0f / (float)(Cs / 8);
