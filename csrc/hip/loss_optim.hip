@@ -1,6 +1,7 @@
 // Fused loss kernels (softmax-CE / softmax-MSE / sigmoid-BCE / Dense(K->1)+BCE forward+backward),
 // metrics, the flat multi-tensor optimizers and the Philox noise generator.
 #include "common.h"
+#include <cstdlib>
 #include "optim_update.h"
 
 #define LB 256
@@ -320,7 +321,9 @@ DDL_API void ddl_optim_step(float* P, const float* G, float* M, float* V, void* 
                             float avg_w, hipStream_t s) {
     long n4 = n / 4;
     long g = (n4 + 255) / 256;
-    int grid = (int)(g > 2048 ? 2048 : (g < 1 ? 1 : g));
+    // every block ends with one atomic on the ticket word (~10 ns each, serialised): keep the grid small
+    static const long cap = getenv("DDL_OPT_BLOCKS") ? atol(getenv("DDL_OPT_BLOCKS")) : 256;
+    int grid = (int)(g > cap ? cap : (g < 1 ? 1 : g));
     optim_kernel<<<grid, 256, 0, s>>>((float4*)P, (const float4*)G, (float4*)M, (float4*)V, (uint2*)Pc, step, n4,
                                       kind, lr, b1, b2, eps, rho, gscale, (const float4*)avg, avg_w);
 }
