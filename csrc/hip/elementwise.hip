@@ -726,13 +726,25 @@ __global__ __launch_bounds__(EW_BLOCK) void bn_bwd_apply_cs_kernel(
 DDL_API void ddl_bn_bwd(const void* dy, const void* x, const void* y, void* dx, long rows, int C,
                         const float* mean, const float* invstd, const float* gamma, int act, float alpha,
                         int train_stats, int prev_act, float prev_alpha, float* part, float* dgamma,
-                        float* dbeta, float* c1, float* c2, float* dbias, int c_bias, int groups, hipStream_t s) {
+                        float* dbeta, float* c1, float* c2, float* dbias, int c_bias, int groups, int part_blocks,
+                        hipStream_t s) {
     // `dbias` (optional, c_bias entries): bias gradient of the conv feeding this BN, = column sums of dx;
     // `part` then holds 5 (instead of 2) partial rows per block.
+    // `part_blocks` > 0: `part` already holds [2][C][groups * part_blocks] column sums of (dy, dy * xhat) written by
+    // the kernel that produced dy (the fused discriminator head): no reduction pass here.
     dim3 grid;
     colreduce_grid(rows, C, &grid);
     grid.z = groups;
-    if (dbias) {
+    if (part_blocks > 0 && !dbias) {
+        grid.x = part_blocks;
+        if ((int)grid.x > fin_wide_min())
+            bn_bwd_finalize_wide_kernel<2><<<C, 256, 0, s>>>(part, grid.x, C, rows, train_stats, dgamma, dbeta, c1, c2,
+                                                              mean, invstd, gamma, nullptr, 0, groups);
+        else
+            bn_bwd_finalize_kernel<2><<<FIN_GRID(C), FIN_BLOCK, 0, s>>>(part, grid.x, C, rows, train_stats, dgamma,
+                                                                      dbeta, c1, c2, mean, invstd, gamma, nullptr,
+                                                                      0, groups);
+    } else if (dbias) {
         colreduce_kernel<3><<<grid, EW_BLOCK, 0, s>>>((const uint4*)dy, (const uint4*)x, (const uint4*)y, mean,
                                                       invstd, part, rows, C, act, alpha, prev_act, prev_alpha);
         if ((int)grid.x > fin_wide_min())

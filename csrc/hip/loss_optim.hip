@@ -108,31 +108,67 @@ DDL_API void ddl_sigmoid_bce(const float* logits, const float* labels, float* ro
 #define HEAD_ROWS 4      // waves (= rows in flight) per block
 #define HEAD_VMAX 8      // uint4 vectors per lane  -> K <= 4096
 
+// Optional fusion of the BatchNorm (+ activation) in FRONT of the head and of that BatchNorm's backward reduction
+// (BNF instantiation; the DCGAN discriminator ends BN -> LeakyReLU -> Flatten -> Dense(1)):
+//   * x is the PRE-BatchNorm tensor; a = bf16(act(x * scale[c] + shift[c])) is formed on load and never stored
+//     (saves the bn_apply pass), c = (flat index) mod C;
+//   * dX receives g = bf16(dlogit * w) * act'(a), the gradient with respect to the BatchNorm output BEFORE its
+//     activation, and the block's column sums of g and g * xhat go to bn_part[2][C][gridDim.y * gridDim.x] --
+//     exactly what colreduce_kernel<1> would produce from (dX, x, a) in another pass over the three tensors.
+// Batch groups (per-half statistics) ride on blockIdx.y: a block only sees rows of its group.  All VM vectors of a
+// lane must carry the same 8 channels: 512 % C == 0.
+struct HeadBn {
+    const float* scale; const float* shift; const float* mean; const float* invstd;   // [groups][C]
+    float* part;                                                                     // [2][C][groups * nb]
+    int C, rows_per_group, act; float alpha;
+};
+
+template <int VM, bool BNF>
 __global__ __launch_bounds__(HEAD_ROWS * 64) void dense1_bce_kernel(
     const uint4* __restrict__ x, const bf16_t* __restrict__ w, const float* __restrict__ bias,
     float label_first, float label_second, int n_first, int M, int K, uint4* __restrict__ dx,
     float* __restrict__ dw_part, float* __restrict__ logits, float* __restrict__ rowloss,
-    float* __restrict__ dlogit_out, int want_dx, int want_dw) {
-    __shared__ float sw[HEAD_VMAX * 64 * 8];
+    float* __restrict__ dlogit_out, int want_dx, int want_dw, const HeadBn bn) {
+    __shared__ float sw[VM * 64 * 8];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int kv = K / 8;                       // vectors per row
     for (int i = threadIdx.x; i < K; i += blockDim.x) sw[i] = bf2f(w[i]);
     __syncthreads();
-    float acc_dw[HEAD_VMAX][8];
+    float acc_dw[VM][8];
 #pragma unroll
-    for (int v = 0; v < HEAD_VMAX; ++v)
+    for (int v = 0; v < VM; ++v)
 #pragma unroll
         for (int j = 0; j < 8; ++j) acc_dw[v][j] = 0.f;
     const float b = bias[0];
     const float invM = 1.f / (float)M;
-    for (int r = blockIdx.x * HEAD_ROWS + wv; r < M; r += gridDim.x * HEAD_ROWS) {
-        float f[HEAD_VMAX][8];
+    // BatchNorm fusion: this lane's 8 channels (the same for every v) and their per-group coefficients
+    float sc[8], sh[8], mu[8], is[8], s0[8], s1[8];
+    const int c0 = BNF ? (lane * 8) % bn.C : 0;
+    if (BNF) {
+        const int go = blockIdx.y * bn.C + c0;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            sc[j] = bn.scale[go + j]; sh[j] = bn.shift[go + j]; mu[j] = bn.mean[go + j]; is[j] = bn.invstd[go + j];
+            s0[j] = s1[j] = 0.f;
+        }
+    }
+    const int r_lo = BNF ? blockIdx.y * bn.rows_per_group : 0;
+    const int r_hi = BNF ? min(M, r_lo + bn.rows_per_group) : M;
+    for (int r = r_lo + blockIdx.x * HEAD_ROWS + wv; r < r_hi; r += gridDim.x * HEAD_ROWS) {
+        float f[VM][8], xr[BNF ? VM : 1][8];
         float dot = 0.f;
 #pragma unroll
-        for (int v = 0; v < HEAD_VMAX; ++v) {
+        for (int v = 0; v < VM; ++v) {
             int idx = v * 64 + lane;
             if (idx < kv) {
                 unpack8(x[(size_t)r * kv + idx], f[v]);
+                if (BNF) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        xr[v][j] = f[v][j];
+                        f[v][j] = bf2f(f2bf(act_apply(fmaf(f[v][j], sc[j], sh[j]), bn.act, bn.alpha)));
+                    }
+                }
 #pragma unroll
                 for (int j = 0; j < 8; ++j) dot += f[v][j] * sw[idx * 8 + j];
             }
@@ -142,7 +178,7 @@ __global__ __launch_bounds__(HEAD_ROWS * 64) void dense1_bce_kernel(
         float dl = (1.f / (1.f + __expf(-dot)) - z) * invM;
         if (lane == 0) { logits[r] = dot; rowloss[r] = bce_logits(dot, z); dlogit_out[r] = dl; }
 #pragma unroll
-        for (int v = 0; v < HEAD_VMAX; ++v) {
+        for (int v = 0; v < VM; ++v) {
             int idx = v * 64 + lane;
             if (idx < kv) {
                 if (want_dw) {
@@ -153,19 +189,53 @@ __global__ __launch_bounds__(HEAD_ROWS * 64) void dense1_bce_kernel(
                     float o[8];
 #pragma unroll
                     for (int j = 0; j < 8; ++j) o[j] = dl * sw[idx * 8 + j];
+                    if (BNF) {
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) {
+                            o[j] = bf2f(f2bf(bf2f(f2bf(o[j])) * act_grad_y(f[v][j], bn.act, bn.alpha)));
+                            s0[j] += o[j];
+                            s1[j] += o[j] * (xr[v][j] - mu[j]) * is[j];
+                        }
+                    }
                     dx[(size_t)r * kv + idx] = pack8(o);
                 }
             }
         }
     }
+    const int bidx = blockIdx.y * gridDim.x + blockIdx.x;
+    __syncthreads();
+    if (BNF && want_dx) {
+        // lanes l, l + C/8, ... hold the same channels: fold them, then the four waves through LDS
+        const int P = bn.C / 8;
+        for (int off = P; off < 64; off <<= 1) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { s0[j] += __shfl_xor(s0[j], off, 64); s1[j] += __shfl_xor(s1[j], off, 64); }
+        }
+        float* red = sw;                           // [4 waves][P lanes][16]; P * 64 floats <= K floats of sw
+        const int pl = P < 64 ? P : 64;
+        if (lane < pl) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { red[(wv * pl + lane) * 16 + j] = s0[j]; red[(wv * pl + lane) * 16 + 8 + j] = s1[j]; }
+        }
+        __syncthreads();
+        const size_t nbt = (size_t)gridDim.x * gridDim.y;
+        for (int t = threadIdx.x; t < pl * 16; t += blockDim.x) {
+            const int l = t >> 4, e = t & 15;
+            float v = red[t];
+#pragma unroll
+            for (int q = 1; q < HEAD_ROWS; ++q) v += red[q * pl * 16 + t];
+            const int k = e >> 3, c = (l * 8) % bn.C + (e & 7);
+            bn.part[((size_t)k * bn.C + c) * nbt + bidx] = v;
+        }
+        __syncthreads();
+    }
     if (!want_dw) return;
     // reduce the HEAD_ROWS waves' partial dW through LDS (reuse sw after a barrier)
-    __syncthreads();
     float* red = sw;    // K floats
     for (int q = 0; q < HEAD_ROWS; ++q) {
         if (wv == q) {
 #pragma unroll
-            for (int v = 0; v < HEAD_VMAX; ++v) {
+            for (int v = 0; v < VM; ++v) {
                 int idx = v * 64 + lane;
                 if (idx < kv) {
 #pragma unroll
@@ -178,7 +248,7 @@ __global__ __launch_bounds__(HEAD_ROWS * 64) void dense1_bce_kernel(
         }
         __syncthreads();
     }
-    for (int i = threadIdx.x; i < K; i += blockDim.x) dw_part[(size_t)blockIdx.x * K + i] = red[i];
+    for (int i = threadIdx.x; i < K; i += blockDim.x) dw_part[(size_t)bidx * K + i] = red[i];
 }
 
 // dw[k] = sum_b dw_part[b][k]: 256 threads = 32 k-columns x 8 partial lanes; block 0 also sums db.
@@ -236,18 +306,36 @@ DDL_API int ddl_dense1_bce_blocks(int M) {
     return nb > 256 ? 256 : (nb < 1 ? 1 : nb);
 }
 
+// bn_*: optional fused BatchNorm in front of the head (see HeadBn); bn_part receives [2][C][groups * blocks] partials
+// for ddl_bn_bwd(..., part_blocks = blocks).  `groups` = batch groups (rows split evenly), 1 without BN fusion.
 DDL_API int ddl_dense1_bce(const void* x, const void* w, const float* bias, float label_first,
                            float label_second, int n_first, int M, int K, void* dx, float* dw_part,
                            float* logits, float* rowloss, float* dlogit, float* loss_out, float* dw, float* db,
-                           int want_dx, int want_dw, hipStream_t s) {
+                           int want_dx, int want_dw, const float* bn_scale, const float* bn_shift,
+                           const float* bn_mean, const float* bn_invstd, float* bn_part, int bn_C, int groups,
+                           int bn_act, float bn_alpha, hipStream_t s) {
     if (K % 8 != 0 || K > HEAD_VMAX * 64 * 8) return -1;
-    int nb = ddl_dense1_bce_blocks(M);
-    dense1_bce_kernel<<<nb, HEAD_ROWS * 64, 0, s>>>((const uint4*)x, (const bf16_t*)w, bias, label_first,
-                                                    label_second, n_first, M, K, (uint4*)dx, dw_part, logits,
-                                                    rowloss, dlogit, want_dx, want_dw);
+    HeadBn bn{bn_scale, bn_shift, bn_mean, bn_invstd, bn_part, bn_C, M, bn_act, bn_alpha};
+    const bool fuse = bn_scale != nullptr;
+    if (fuse) {
+        if (!bn_shift || !bn_mean || !bn_invstd || !bn_part || bn_C <= 0 || bn_C % 8 || 512 % bn_C || K % bn_C ||
+            K > 4 * 64 * 8 || groups < 1 || M % groups || (bn_C / 8) * 64 > K)
+            return -2;
+        bn.rows_per_group = M / groups;
+    } else {
+        groups = 1;
+    }
+    int nb = ddl_dense1_bce_blocks(M / groups);
+    dim3 grid(nb, groups);
+#define HEAD_ARGS (const uint4*)x, (const bf16_t*)w, bias, label_first, label_second, n_first, M, K, (uint4*)dx, \
+                  dw_part, logits, rowloss, dlogit, want_dx, want_dw, bn
+    if (fuse) dense1_bce_kernel<4, true><<<grid, HEAD_ROWS * 64, 0, s>>>(HEAD_ARGS);
+    else if (K <= 4 * 64 * 8) dense1_bce_kernel<4, false><<<grid, HEAD_ROWS * 64, 0, s>>>(HEAD_ARGS);
+    else dense1_bce_kernel<HEAD_VMAX, false><<<grid, HEAD_ROWS * 64, 0, s>>>(HEAD_ARGS);
+#undef HEAD_ARGS
     if (want_dw) {
         const int fb = (K + 31) / 32;
-        head_finalize_kernel<<<fb, 256, 0, s>>>(dw_part, nb, K, dlogit, M, dw, db, rowloss,
+        head_finalize_kernel<<<fb, 256, 0, s>>>(dw_part, nb * groups, K, dlogit, M, dw, db, rowloss,
                                                 fb > 1 ? loss_out : nullptr);
         if (fb > 1) return 0;
     }

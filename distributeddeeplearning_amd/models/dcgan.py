@@ -174,8 +174,50 @@ class GANTrainer:
                            and os.environ.get("DDL_GAN_MERGED_G", "1") == "1")
         self._buf3 = None
         self._buf3_src = None
+        # D ends BN -> LeakyReLU -> Flatten -> Dense(1): with batch statistics on device the head kernel applies
+        # that BatchNorm on load and emits its backward reduction (ops/hip.py dense1_bce_fwd_bwd `bn=`)
+        self._head_bn = self._find_head_bn()
+
+    def _find_head_bn(self):
+        from .network import BNOp, ViewOp
+        ops = self.D.ops
+        if not (self.D.on_gpu and os.environ.get("DDL_GAN_HEAD_BN", "1") == "1" and len(ops) >= 4):
+            return None
+        bn, view, head = ops[-3], ops[-2], ops[-1]
+        if not (isinstance(bn, BNOp) and isinstance(view, ViewOp) and head is self.head):
+            return None
+        K = int(self.head.w_main.numel())
+        if bn.mode != "batch" or not bn.rank4 or bn.Cp != bn.C or bn.bias_grad_for is not None:
+            return None
+        if 512 % bn.Cp or K % bn.Cp or K > 2048 or (bn.Cp // 8) * 64 > K:
+            return None
+        return bn
 
     # ---- the two phases -------------------------------------------------------------------
+    def _d_forward_head(self, xs, groups, n_first, label_first, label_second, want_dw):
+        """D forward + loss head (+ the head's own backward).  Returns (loss, resume) where `resume(**kw)` runs
+        the rest of D's backward with the keyword arguments of `Network.backward`."""
+        bn = self._head_bn
+        if bn is None:
+            feat = self.D.forward(xs, training=True, stop=-1, bn_groups=groups)
+            loss, dfeat = self._d_head(feat, n_first, label_first, label_second, True, want_dw)
+            return loss, lambda **kw: self.D.backward(dfeat, start=-1, **kw)
+        h = self.head
+        x = self.D.forward(xs, training=True, stop=-3, bn_groups=groups)
+        bn.groups = groups
+        scale, shift, mean, invstd = bn.fwd_stats(x)
+        info = dict(scale=scale, shift=shift, mean=mean, invstd=invstd, C=bn.Cp, groups=groups, act=bn.post_act,
+                    alpha=bn.post_alpha)
+        loss, g, _, _, _ = F.dense1_bce_fwd_bwd(x.reshape(x.shape[0], -1), h.w_main, h.bias, label_first,
+                                                label_second, n_first, True, want_dw,
+                                                h.gkernel if want_dw else None, h.gbias if want_dw else None,
+                                                bn=info)
+
+        def resume(**kw):
+            dx = bn.bwd_from_part(g.reshape(x.shape), info["part"], info["nb"], need_dw=kw.get("need_dw", True))
+            return self.D.backward(dx, start=-3, **kw)
+        return loss, resume
+
     def _d_head(self, feat, n_first, label_first, label_second, want_dx, want_dw):
         h = self.head
         loss, dfeat, _, _, _ = F.dense1_bce_fwd_bwd(feat, h.w_main, h.bias, label_first, label_second,
@@ -197,9 +239,8 @@ class GANTrainer:
         self.G.forward(z, training=True, out=self._buf3[B:], bn_groups=2)
         self.G.narrow_saved(B, 2 * B, group=1)       # the G phase trains on z2 only
         self._fake = self._buf3[2 * B:]
-        feat = self.D.forward(self._buf3[:2 * B], training=True, stop=-1, bn_groups=2)
-        loss, dfeat = self._d_head(feat, B, 1.0, 0.0, True, True)
-        self.D.backward(dfeat, need_input_grad=False, start=-1)
+        loss, resume = self._d_forward_head(self._buf3[:2 * B], 2, B, 1.0, 0.0, True)
+        resume(need_input_grad=False)
         self.d_loss = loss
         return loss
 
@@ -221,9 +262,8 @@ class GANTrainer:
             xs = torch.cat([real, fake], 0)
         if g_train:
             self.G.release()
-        feat = self.D.forward(xs, training=True, stop=-1, bn_groups=2 if self._split else 1)
-        loss, dfeat = self._d_head(feat, B, 1.0, 0.0, True, True)
-        self.D.backward(dfeat, need_input_grad=False, start=-1)
+        loss, resume = self._d_forward_head(xs, 2 if self._split else 1, B, 1.0, 0.0, True)
+        resume(need_input_grad=False)
         self.d_loss = loss
         return loss
 
@@ -238,12 +278,11 @@ class GANTrainer:
 
     def g_backward(self, B, fake=None):
         fake = self.g_forward(B) if fake is None else fake
-        feat = self.D.forward(fake, training=True, stop=-1)
-        loss, dfeat = self._d_head(feat, B, 1.0, 1.0, True, False)
+        loss, resume = self._d_forward_head(fake, 1, B, 1.0, 1.0, False)
         # the generator's output activation backward rides in the epilogue of D's input-gradient kernel
         from .network import FUSE_ACT_BWD
         mul = Network.act_owner(self.G.ops[-1]) if (FUSE_ACT_BWD and isinstance(self.D.ops[0], ConvOp)) else None
-        dfake = self.D.backward(dfeat, need_input_grad=True, need_dw=False, start=-1, input_mul=mul)
+        dfake = resume(need_input_grad=True, need_dw=False, input_mul=mul)
         self.G.backward(dfake, need_input_grad=False, dy_premultiplied=mul is not None)
         self.g_loss = loss
         self._fake = None

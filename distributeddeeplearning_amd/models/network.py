@@ -406,6 +406,34 @@ class BNOp(Op):
             self.groups_used = groups
         return y
 
+    def fwd_stats(self, x):
+        """Training forward WITHOUT the apply pass: batch statistics, moving-average update and the per-channel
+        (scale, shift) a fused consumer applies on load (the GAN trainer's discriminator head).  Saves what
+        `bwd_from_part` needs.  Device, batch-statistics mode only."""
+        pre, self.pre_stats = self.pre_stats, None
+        groups = self.groups
+        if pre is not None:
+            scale, shift, mean, invstd = F.bn_train_affine_from_part(
+                pre[0], pre[1], x.numel() // x.shape[-1], self.gamma, self.beta, self.moving_mean,
+                self.moving_var, self.momentum, self.eps, self.rank4, True, groups)
+        else:
+            scale, shift, mean, invstd = F.bn_train_affine(x, self.gamma, self.beta, self.moving_mean,
+                                                           self.moving_var, self.momentum, self.eps,
+                                                           self.rank4, True, groups)
+        self.x, self.y, self.mean, self.invstd = x, None, mean, invstd
+        self.used_batch_stats, self.groups_used = True, groups
+        return scale, shift, mean, invstd
+
+    def bwd_from_part(self, g, part, part_blocks, need_dw=True):
+        """Backward when the consumer already produced g = dL/d(BN output before its activation) together with
+        the column sums of (g, g * xhat): finalize + apply only."""
+        hip = F.hip_backend()
+        dx, _, _ = hip.bn_bwd(g, self.x, None, self.mean, self.invstd, self.gamma, None, 0.3, True,
+                              self.prev_act, self.prev_alpha, self.ggamma if need_dw else None,
+                              self.gbeta if need_dw else None, None, self.groups_used, part=part,
+                              part_blocks=part_blocks)
+        return dx
+
     def bwd(self, dy, need_dx=True, need_dw=True):
         conv = self.bias_grad_for
         dx, _, _ = F.bn_bwd(dy, self.x, None if self.y is self.x else self.y, self.mean, self.invstd,

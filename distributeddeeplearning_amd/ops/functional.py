@@ -211,10 +211,13 @@ def sigmoid_bce(logits, labels, want_grad=True):
 
 
 def dense1_bce_fwd_bwd(x, w, b, label_first, label_second, n_first, want_dx=True, want_dw=True,
-                       out_dw=None, out_db=None):
+                       out_dw=None, out_db=None, bn=None):
+    """`bn`: device only -- the BatchNorm in front of the head fused into the kernel (ops/hip.py)."""
     if x.is_cuda:
         return hip_backend().dense1_bce_fwd_bwd(x, w, b, label_first, label_second, n_first, want_dx, want_dw,
-                                                out_dw, out_db)
+                                                out_dw, out_db, bn)
+    if bn is not None:
+        raise ValueError("dense1_bce: the BatchNorm fusion exists on the device only")
     loss, dx, dw, db, logits = cpu_ref.dense1_bce_fwd_bwd(x, w, b, label_first, label_second, n_first,
                                                           want_dx, want_dw)
     if want_dw and out_dw is not None:

@@ -51,7 +51,7 @@ _bn_infer_affine = _sig("ddl_bn_infer_affine", None, vp, vp, vp, vp, cf, ci, vp,
 _bn_apply = _sig("ddl_bn_apply", None, vp, vp, vp, vp, cl, ci, ci, ci, cf, ci, vp)
 _bn_apply_infer = _sig("ddl_bn_apply_infer", None, vp, vp, vp, vp, vp, vp, cf, cl, ci, ci, ci, cf, vp)
 _bn_bwd = _sig("ddl_bn_bwd", None, vp, vp, vp, vp, cl, ci, vp, vp, vp, ci, cf, ci, ci, cf, vp, vp, vp, vp, vp, vp, ci,
-              ci, vp)
+              ci, ci, vp)
 _bias_grad = _sig("ddl_bias_grad", None, vp, cl, ci, ci, vp, vp, vp)
 _cast = _sig("ddl_cast_f32_bf16", None, vp, vp, cl, vp)
 _relayout = _sig("ddl_relayout_alt", None, vp, vp, vp, ci, cl, vp)
@@ -62,7 +62,8 @@ _affine = _sig("ddl_affine", None, vp, vp, cl, ci, ci, cf, cf, vp)
 _softmax_loss = _sig("ddl_softmax_loss", None, vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, vp)
 _sigmoid_bce = _sig("ddl_sigmoid_bce", None, vp, vp, vp, vp, vp, ci, vp)
 _dense1_blocks = _sig("ddl_dense1_bce_blocks", ci, ci)
-_dense1_bce = _sig("ddl_dense1_bce", ci, vp, vp, vp, cf, cf, ci, ci, ci, vp, vp, vp, vp, vp, vp, vp, vp, ci, ci, vp)
+_dense1_bce = _sig("ddl_dense1_bce", ci, vp, vp, vp, cf, cf, ci, ci, ci, vp, vp, vp, vp, vp, vp, vp, vp, ci, ci,
+                   vp, vp, vp, vp, vp, ci, ci, ci, cf, vp)
 _argmax_match = _sig("ddl_argmax_match", None, vp, vp, ci, ci, vp, vp)
 _optim_step = _sig("ddl_optim_step", None, vp, vp, vp, vp, vp, vp, cl, ci, cf, cf, cf, cf, cf, cf, vp, cf, vp)
 _step_inc = _sig("ddl_step_inc", None, vp, vp)
@@ -278,9 +279,11 @@ def bn_apply_infer(x, gamma, beta, mm, mv, eps, act=None, alpha=0.3, c_true=None
 
 
 def bn_bwd(dy, x, y, mean, invstd, gamma, act, alpha, train_stats, prev_act=None, prev_alpha=0.3,
-           out_dgamma=None, out_dbeta=None, out_dbias=None, groups=1):
+           out_dgamma=None, out_dbeta=None, out_dbias=None, groups=1, part=None, part_blocks=0):
     """`out_dbias` (fp32, <= C entries): also emit the bias gradient of the conv layer feeding this BN
-    (= column sums of dx) from the same reduction pass (colreduce MODE 3)."""
+    (= column sums of dx) from the same reduction pass (colreduce MODE 3).
+    `part`, `part_blocks`: column sums of (dy, dy * xhat) already written by the producer of dy as
+    [2][Cp][groups * part_blocks] (the fused discriminator head): the reduction pass is skipped."""
     _chk_act(dy, "dy")
     _chk_act(x, "x")
     if dy.shape != x.shape:
@@ -297,7 +300,13 @@ def bn_bwd(dy, x, y, mean, invstd, gamma, act, alpha, train_stats, prev_act=None
         _chk_f32(out_dbias, None, "dbias")
         if out_dbias.numel() > Cp:
             raise ValueError("bn_bwd: bias gradient longer than the channel dim")
-    part = _part(rows, Cp, dev, 5 if out_dbias is not None else 2, groups)
+    if part is not None:
+        if out_dbias is not None or part_blocks <= 0:
+            raise ValueError("bn_bwd: precomputed partials exclude the fused bias gradient and need part_blocks")
+        _chk_f32(part, 2 * Cp * groups * part_blocks, "bn_bwd partials")
+    else:
+        part_blocks = 0
+        part = _part(rows, Cp, dev, 5 if out_dbias is not None else 2, groups)
     coef = torch.empty(2, groups * Cp, dtype=torch.float32, device=dev)
     if out_dgamma is None:
         out_dgamma = torch.empty(Cp, dtype=torch.float32, device=dev)
@@ -308,7 +317,8 @@ def bn_bwd(dy, x, y, mean, invstd, gamma, act, alpha, train_stats, prev_act=None
     _bn_bwd(dy.data_ptr(), x.data_ptr(), _p(y), dx.data_ptr(), rows, Cp, mean.data_ptr(), invstd.data_ptr(),
             gamma.data_ptr(), ACT_CODE[act], alpha, int(bool(train_stats)), ACT_CODE[prev_act], prev_alpha,
             part.data_ptr(), out_dgamma.data_ptr(), out_dbeta.data_ptr(), coef[0].data_ptr(),
-            coef[1].data_ptr(), _p(out_dbias), 0 if out_dbias is None else out_dbias.numel(), groups, _stream())
+            coef[1].data_ptr(), _p(out_dbias), 0 if out_dbias is None else out_dbias.numel(), groups, part_blocks,
+            _stream())
     _done()
     return dx, out_dgamma, out_dbeta
 
@@ -656,7 +666,12 @@ def sigmoid_bce(logits, labels, want_grad=True):
 
 
 def dense1_bce_fwd_bwd(x, w, b, label_first, label_second, n_first, want_dx=True, want_dw=True,
-                       out_dw=None, out_db=None):
+                       out_dw=None, out_db=None, bn=None):
+    """Dense(K -> 1) + sigmoid-BCE forward and backward in one kernel.
+    `bn` = dict(scale, shift, mean, invstd ([groups][C] fp32), C, groups, act, alpha): `x` is the tensor in FRONT
+    of a BatchNorm(+activation) that is applied on load; the returned dx is then the gradient with respect to the
+    BatchNorm's pre-activation output and bn["part"], bn["nb"] receive the column sums of (dx, dx * xhat) for
+    `bn_bwd(..., part=, part_blocks=)` -- no bn_apply pass, no reduction pass (csrc/hip/loss_optim.hip HeadBn)."""
     _chk_act(x, "x")
     M = x.shape[0]
     K = x.numel() // M
@@ -664,11 +679,26 @@ def dense1_bce_fwd_bwd(x, w, b, label_first, label_second, n_first, want_dx=True
         raise ValueError(f"dense1_bce: weight must be bf16 with {K} elements")
     _chk_f32(b, 1, "bias")
     dev = x.device
+    groups = 1
+    bsc = bsh = bmu = bis = bpart = None
+    bC, bact, balpha = 0, 0, 0.0
+    if bn is not None:
+        bC, groups = int(bn["C"]), int(bn["groups"])
+        if M % groups or K % bC or 512 % bC or K > 2048 or (bC // 8) * 64 > K:
+            raise ValueError(f"dense1_bce: BatchNorm fusion does not support M={M} K={K} C={bC} groups={groups}")
+        for k_ in ("scale", "shift", "mean", "invstd"):
+            _chk_f32(bn[k_], groups * bC, f"bn {k_}")
+        bact, balpha = ACT_CODE[bn.get("act")], float(bn.get("alpha", 0.3))
     dx = torch.empty_like(x) if want_dx else None
-    nb = _dense1_blocks(M)
-    dw_part = torch.empty(nb * K, dtype=torch.float32, device=dev) if want_dw else None
+    nb = _dense1_blocks(M // groups)
+    dw_part = torch.empty(nb * groups * K, dtype=torch.float32, device=dev) if want_dw else None
     aux = torch.empty(3, M, dtype=torch.float32, device=dev)       # logits, rowloss, dlogit
     loss = torch.empty((), dtype=torch.float32, device=dev)
+    if bn is not None:
+        part = torch.empty(2 * bC * groups * nb, dtype=torch.float32, device=dev)
+        bn["part"], bn["nb"] = part, nb
+        bsc, bsh, bmu, bis, bpart = (bn["scale"].data_ptr(), bn["shift"].data_ptr(), bn["mean"].data_ptr(),
+                                     bn["invstd"].data_ptr(), part.data_ptr())
     if want_dw and out_dw is None:
         out_dw = torch.empty(K, dtype=torch.float32, device=dev)
         out_db = torch.empty(1, dtype=torch.float32, device=dev)
@@ -678,7 +708,7 @@ def dense1_bce_fwd_bwd(x, w, b, label_first, label_second, n_first, want_dx=True
     rc = _dense1_bce(x.data_ptr(), w.data_ptr(), b.data_ptr(), label_first, label_second, n_first, M, K,
                      _p(dx), _p(dw_part), aux[0].data_ptr(), aux[1].data_ptr(), aux[2].data_ptr(),
                      loss.data_ptr(), _p(out_dw) if want_dw else None, _p(out_db) if want_dw else None,
-                     int(want_dx), int(want_dw), _stream())
+                     int(want_dx), int(want_dw), bsc, bsh, bmu, bis, bpart, bC, groups, bact, balpha, _stream())
     if rc != 0:
         raise ValueError(f"dense1_bce: unsupported K={K} (rc={rc})")
     _done()

@@ -169,3 +169,29 @@ def test_bn_on_load_matches_materialised_generator():
             N.BN_ON_LOAD = True
     for a, b in zip(res[True], res[False]):
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("policy", ["split", "mixed"])
+def test_fused_head_batchnorm_matches_unfused_trainer(policy, monkeypatch):
+    """The discriminator head kernel applies the last BatchNorm on load and emits its backward reduction: losses
+    equal the unfused path bit for bit (same bf16 activation), gradients to rounding (g is rounded once more)."""
+    torch.manual_seed(5)
+    real = (torch.rand(96, 28, 28, 1) > 0.6).float()
+    out = {}
+    for flag in ("1", "0"):
+        monkeypatch.setenv("DDL_GAN_HEAD_BN", flag)
+        t = GANTrainer(GANConfig(batch=96, bn_policy=policy, seed=9), "cuda")
+        assert (t._head_bn is not None) == (flag == "1")
+        rp = t.D.prepare_input(real)
+        t.D.G.zero_()
+        t.G.G.zero_()
+        dl = t.d_backward(rp)
+        gD = t.D.G.clone()
+        gl = t.g_backward(96)
+        torch.cuda.synchronize()
+        out[flag] = (float(dl), float(gl), gD, t.G.G.clone(), t.D.S.clone())
+    a, b = out["1"], out["0"]
+    assert a[0] == b[0] and a[1] == b[1]
+    assert torch.equal(a[4], b[4])                                  # moving statistics
+    for ga, gb in ((a[2], b[2]), (a[3], b[3])):
+        assert float((ga - gb).norm() / gb.norm()) < 1e-2
