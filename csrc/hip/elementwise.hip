@@ -730,12 +730,21 @@ DDL_API void ddl_bn_bwd(const void* dy, const void* x, const void* y, void* dx, 
                         hipStream_t s) {
     // `dbias` (optional, c_bias entries): bias gradient of the conv feeding this BN, = column sums of dx;
     // `part` then holds 5 (instead of 2) partial rows per block.
-    // `part_blocks` > 0: `part` already holds [2][C][groups * part_blocks] column sums of (dy, dy * xhat) written by
-    // the kernel that produced dy (the fused discriminator head): no reduction pass here.
+    // `part_blocks` > 0: `part` already holds [2 or 5][C][groups * part_blocks] column sums written by the kernel that
+    // produced dy (the fused discriminator head, tapconv_1ch's RED epilogue): no reduction pass here.
     dim3 grid;
     colreduce_grid(rows, C, &grid);
     grid.z = groups;
-    if (part_blocks > 0 && !dbias) {
+    if (part_blocks > 0 && dbias) {
+        grid.x = part_blocks;
+        if ((int)grid.x > fin_wide_min())
+            bn_bwd_finalize_wide_kernel<5><<<C, 256, 0, s>>>(part, grid.x, C, rows, train_stats, dgamma, dbeta, c1, c2,
+                                                              mean, invstd, gamma, dbias, c_bias, groups);
+        else
+            bn_bwd_finalize_kernel<5><<<FIN_GRID(C), FIN_BLOCK, 0, s>>>(part, grid.x, C, rows, train_stats, dgamma,
+                                                                      dbeta, c1, c2, mean, invstd, gamma, dbias,
+                                                                      c_bias, groups);
+    } else if (part_blocks > 0) {
         grid.x = part_blocks;
         if ((int)grid.x > fin_wide_min())
             bn_bwd_finalize_wide_kernel<2><<<C, 256, 0, s>>>(part, grid.x, C, rows, train_stats, dgamma, dbeta, c1, c2,

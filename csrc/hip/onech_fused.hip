@@ -233,9 +233,15 @@ struct TapConvArgs {
     int B, H, W, OH, OW, KH, KW, sh, sw, dh, dw, pt, pl, T, Tp, Np, n_lim, act;
     float alpha;
     int PH, PW;
+    // RED instantiations: y is the gradient arriving at a BatchNorm's output (no activation of its own) whose INPUT
+    // is rx [B][OH][OW][Np]; the block also emits that BatchNorm's backward column sums over its image, laid out
+    // r_part[RED][Np][gridDim.x] exactly like colreduce_kernel<1> (RED 2: sum g, sum g * xhat) / <3> (RED 5: plus,
+    // with a = prev_act'(rx), sum a * g, sum a * rx, sum a) -- the reduction pass over (y, rx) is not needed.
+    const bf16_t* rx; const float* r_mean; const float* r_invstd; float* r_part;
+    int r_prev_act; float r_prev_alpha; int red_off;
 };
 
-template <int NT, bool SLOW>
+template <int NT, bool SLOW, int RED>
 __global__ __launch_bounds__(256) void tapconv_1ch_kernel(const TapConvArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     bf16_t* sI = (bf16_t*)smem;                 // [PH][PW] zero-haloed plane
@@ -297,6 +303,19 @@ __global__ __launch_bounds__(256) void tapconv_1ch_kernel(const TapConvArgs a) {
     const float invOW = 1.0f / (float)a.OW;
     const int act = a.act;
     const float alpha = a.alpha;
+    float rs[RED ? RED : 1][NT][4], rmu[RED ? NT : 1][4], ris[RED ? NT : 1][4];
+    if (RED) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int c = 16 * t + 4 * fq + e;
+                rmu[t][e] = c < a.Np ? a.r_mean[c] : 0.f;
+                ris[t][e] = c < a.Np ? a.r_invstd[c] : 0.f;
+#pragma unroll
+                for (int k = 0; k < RED; ++k) rs[k][t][e] = 0.f;
+            }
+    }
     for (int f = wave; f * 16 < npix; f += 4) {
         const int p = f * 16 + fr;
         const int pp = p < npix ? p : 0;
@@ -325,9 +344,54 @@ __global__ __launch_bounds__(256) void tapconv_1ch_kernel(const TapConvArgs a) {
                     else if (act == ACT_LEAKY) x = x > 0.f ? x : alpha * x;
                     v[e] = (16 * t + 4 * fq + e < a.n_lim) ? x : 0.f;
                 }
-                if (16 * t + 4 * fq < a.Np)
+                if (16 * t + 4 * fq < a.Np) {
                     *(uint2*)(dst + 16 * t + 4 * fq) = make_uint2(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]));
+                    if (RED) {
+                        const uint2 xr = *(const uint2*)(a.rx + ((size_t)b * npix + p) * a.Np + 16 * t + 4 * fq);
+                        const float xv[4] = {__uint_as_float(xr.x << 16), __uint_as_float(xr.x & 0xffff0000u),
+                                             __uint_as_float(xr.y << 16), __uint_as_float(xr.y & 0xffff0000u)};
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const float g = bf2f(f2bf(v[e]));           // what the stored tensor holds
+                            rs[0][t][e] += g;
+                            rs[1][t][e] += g * (xv[e] - rmu[t][e]) * ris[t][e];
+                            if (RED == 5) {
+                                const float ad = act_grad_y(xv[e], a.r_prev_act, a.r_prev_alpha);
+                                rs[RED - 3][t][e] += ad * g;
+                                rs[RED - 2][t][e] += ad * xv[e];
+                                rs[RED - 1][t][e] += ad;
+                            }
+                        }
+                    }
+                }
             }
+        }
+    }
+    if (RED) {
+        // the 16 lanes sharing fq hold the same channels for 16 different pixels: fold them, then the four waves
+#pragma unroll
+        for (int k = 0; k < RED; ++k)
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int o = 1; o < 16; o <<= 1) rs[k][t][e] += __shfl_xor(rs[k][t][e], o, 64);
+        float* red = (float*)(smem + a.red_off);       // [4 waves][RED][NT * 16 channels]
+        if (fr == 0) {
+#pragma unroll
+            for (int k = 0; k < RED; ++k)
+#pragma unroll
+                for (int t = 0; t < NT; ++t)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) red[(wave * RED + k) * (NT * 16) + 16 * t + 4 * fq + e] = rs[k][t][e];
+        }
+        __syncthreads();
+        for (int i = tid; i < RED * NT * 16; i += 256) {
+            const int k = i / (NT * 16), c = i - k * (NT * 16);
+            if (c >= a.Np) continue;
+            const float v = ((red[i] + red[RED * NT * 16 + i]) + red[2 * RED * NT * 16 + i]) + red[3 * RED * NT * 16 + i];
+            a.r_part[((size_t)k * a.Np + c) * gridDim.x + b] = v;
         }
     }
 }
@@ -335,8 +399,11 @@ __global__ __launch_bounds__(256) void tapconv_1ch_kernel(const TapConvArgs a) {
 // Returns 0 on success, 1 if the shape is outside this kernel's range (nothing launched), < 0 on bad arguments.
 DDL_API int ddl_tapconv_1ch(const void* img, const void* w, const float* bias, void* y, int B, int H, int W, int OH,
                             int OW, int KH, int KW, int sh, int sw, int dh, int dw, int pt, int pl, int Tp, int Np,
-                            int n_lim, int act, float alpha, hipStream_t s) {
+                            int n_lim, int act, float alpha, const void* rx, const float* r_mean,
+                            const float* r_invstd, float* r_part, int r_sums, int r_prev_act, float r_prev_alpha,
+                            hipStream_t s) {
     if (B <= 0 || KH * KW <= 0 || Np % 8 || Tp % 8 || n_lim <= 0 || n_lim > Np) return -1;
+    if (rx && (!r_mean || !r_invstd || !r_part || (r_sums != 2 && r_sums != 5))) return -1;
     if (KH * KW > 32 || Tp > 32 || Tp < KH * KW || Np > 64) return 1;
     if ((long)B * OH * OW * Np >= (1L << 31) || (long)B * H * W * 8 >= (1L << 31)) return 1;
     TapConvArgs a;
@@ -348,14 +415,20 @@ DDL_API int ddl_tapconv_1ch(const void* img, const void* w, const float* bias, v
     if (ph < H + pt) ph = H + pt;
     if (pw < W + pl) pw = W + pl;
     a.PH = ph; a.PW = pw;
-    const size_t smem = ((size_t)ph * pw * 2 + 15) / 16 * 16;
+    const int NT = (Np + 15) / 16;
+    a.rx = (const bf16_t*)rx; a.r_mean = r_mean; a.r_invstd = r_invstd; a.r_part = r_part;
+    a.r_prev_act = r_prev_act; a.r_prev_alpha = r_prev_alpha;
+    a.red_off = (int)(((size_t)ph * pw * 2 + 15) / 16 * 16);
+    const size_t smem = (size_t)a.red_off + (rx ? (size_t)4 * 5 * NT * 16 * 4 : 0);
     if (smem > 64 * 1024 || (long)OH * OW >= (1L << 21) || (long)H * W >= (1L << 21)) return 1;
     const bool fast = act == ACT_LINEAR || act == ACT_RELU || act == ACT_LEAKY;
-    const int NT = (Np + 15) / 16;
+    if (rx && !fast) return 1;
 #define TC_CASE(NT_) \
     if (NT == NT_) { \
-        if (fast) tapconv_1ch_kernel<NT_, false><<<B, 256, smem, s>>>(a); \
-        else tapconv_1ch_kernel<NT_, true><<<B, 256, smem, s>>>(a); \
+        if (rx && r_sums == 5) tapconv_1ch_kernel<NT_, false, 5><<<B, 256, smem, s>>>(a); \
+        else if (rx) tapconv_1ch_kernel<NT_, false, 2><<<B, 256, smem, s>>>(a); \
+        else if (fast) tapconv_1ch_kernel<NT_, false, 0><<<B, 256, smem, s>>>(a); \
+        else tapconv_1ch_kernel<NT_, true, 0><<<B, 256, smem, s>>>(a); \
         return 0; \
     }
     TC_CASE(1) TC_CASE(2) TC_CASE(3) TC_CASE(4)

@@ -31,6 +31,7 @@ from ..ops.geometry import ConvGeom, dense_geom
 from .ir import LayerSpec, ModelSpec
 
 ONECH = os.environ.get("DDL_ONECH", "1") == "1"      # single-channel conv fast path (device)
+BN_BWD_FUSE = os.environ.get("DDL_BN_BWD_FUSE", "1") == "1"       # BN backward column sums from the kernel that makes dy
 BN_ON_LOAD = os.environ.get("DDL_BN_ON_LOAD", "1") == "1"         # BN in front of a 1-channel ConvT applied on load
 FUSE_ACT_BWD = os.environ.get("DDL_FUSE_ACT_BWD", "1") == "1"   # act'(y) of the layer below in the dgrad epilogue
 BRANCH = os.environ.get("DDL_BRANCH", "1") == "1"    # weight-gradient branch on a side stream (captured steps)
@@ -154,6 +155,7 @@ class ConvOp(Op):
         # BatchNorm applied on load ("out" path): the BN in front of this layer hands over (scale, shift, groups,
         # c_true) instead of writing its output; the taps kernel and the weight-gradient kernel read x through it
         self._slabs = {}                # persistent zeroed split-K slabs of the boxed weight gradient ("in" path)
+        self.in_bn = None               # the BatchNorm whose apply this layer performs on load (BNOp.defer_to is us)
         self.in_affine = None           # set by BNOp.fwd for the next forward only
         self.x_affine = None            # what the last training forward used (for backward)
 
@@ -256,7 +258,16 @@ class ConvOp(Op):
         else:
             dyc = [None]                # the taps tensor of dY: the weight gradient's operand (side branch)
             if need_dx:                 # input gradient straight from the dY image when nothing is fused behind it
-                dx = hip.tapconv_1ch(dy, self.w_tapT, g) if mul is None else None
+                red, bn = None, self.in_bn
+                if (mul is None and BN_BWD_FUSE and bn is not None and bn.used_batch_stats and bn.groups_used == 1
+                        and bn.x is not None and bn.y is bn.x):
+                    # dx is the gradient at that BatchNorm's output: the kernel also emits its backward column sums
+                    sums = 5 if (need_dw and bn.bias_grad_for is not None) else 2
+                    red = dict(x=bn.x, mean=bn.mean.reshape(-1), invstd=bn.invstd.reshape(-1), sums=sums,
+                               prev_act=bn.prev_act, prev_alpha=bn.prev_alpha)
+                dx = hip.tapconv_1ch(dy, self.w_tapT, g, bn_red=red) if mul is None else None
+                if dx is not None and red is not None and "part" in red:
+                    bn.pre_bwd = (red["part"], red["nb"], red["sums"])
                 if dx is None:
                     dyc[0] = hip.im2col_1ch(dy, g)
                     dx = hip.conv_dgrad(dyc[0], self.w_tapT, g1, mul=mul)
@@ -372,6 +383,7 @@ class BNOp(Op):
         self.groups = 1                # batch groups with their own batch statistics (set per forward pass)
         self.groups_used = 1
         self.defer_to = None           # ConvOp that applies this BN's affine on load (no output tensor of our own)
+        self.pre_bwd = None            # (partials, blocks, sums) of our backward reduction, left by the kernel that made dy
 
     def fwd(self, x, training):
         use_batch = training and self.mode == "batch"
@@ -436,6 +448,14 @@ class BNOp(Op):
 
     def bwd(self, dy, need_dx=True, need_dw=True):
         conv = self.bias_grad_for
+        pre, self.pre_bwd = self.pre_bwd, None
+        if pre is not None and pre[2] == (5 if (need_dw and conv is not None) else 2):
+            dx, _, _ = F.hip_backend().bn_bwd(
+                dy, self.x, None, self.mean, self.invstd, self.gamma, None, 0.3, self.used_batch_stats, self.prev_act,
+                self.prev_alpha, self.ggamma if need_dw else None, self.gbeta if need_dw else None,
+                conv.gbias if (need_dw and conv is not None) else None, self.groups_used, part=pre[0],
+                part_blocks=pre[1])
+            return dx
         dx, _, _ = F.bn_bwd(dy, self.x, None if self.y is self.x else self.y, self.mean, self.invstd,
                             self.gamma, self.post_act,
                             self.post_alpha, self.used_batch_stats, self.prev_act, self.prev_alpha,
@@ -444,7 +464,7 @@ class BNOp(Op):
         return dx
 
     def release(self):
-        self.x = self.y = self.mean = self.invstd = None
+        self.x = self.y = self.mean = self.invstd = self.pre_bwd = None
 
 
 class ViewOp(Op):
@@ -527,6 +547,7 @@ class Network:
             if isinstance(a_, BNOp) and isinstance(b_, ConvOp) and b_.onech == "out" and a_.rank4 \
                     and a_.post_act in (None, "linear"):
                 a_.defer_to = b_
+                b_.in_bn = a_
         self.init_weights(seed)
         if self.on_gpu:
             _BR.ensure_stream()

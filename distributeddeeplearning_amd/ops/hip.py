@@ -75,7 +75,7 @@ _col2im = _sig("ddl_col2im_1ch", ci, vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, ci,
 _tapfold = _sig("ddl_tapfold_1ch", ci, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, cf, vp, ci,
                 cf, vp, vp, ci, ci, ci, vp)
 _tapconv = _sig("ddl_tapconv_1ch", ci, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci,
-                cf, vp)
+                cf, vp, vp, vp, vp, ci, ci, cf, vp)
 _gather = _sig("ddl_relayout_gather", None, vp, vp, vp, ci, cl, vp)
 _relayout_both = _sig("ddl_relayout_both", None, vp, vp, vp, ci, vp, vp, ci, cl, vp)
 _gemm_sk = _sig("ddl_gemm_sk", ci, vp, vp, vp, vp, cl, ci, ci, ci, ci, cf, vp)
@@ -301,9 +301,9 @@ def bn_bwd(dy, x, y, mean, invstd, gamma, act, alpha, train_stats, prev_act=None
         if out_dbias.numel() > Cp:
             raise ValueError("bn_bwd: bias gradient longer than the channel dim")
     if part is not None:
-        if out_dbias is not None or part_blocks <= 0:
-            raise ValueError("bn_bwd: precomputed partials exclude the fused bias gradient and need part_blocks")
-        _chk_f32(part, 2 * Cp * groups * part_blocks, "bn_bwd partials")
+        if part_blocks <= 0:
+            raise ValueError("bn_bwd: precomputed partials need part_blocks")
+        _chk_f32(part, (5 if out_dbias is not None else 2) * Cp * groups * part_blocks, "bn_bwd partials")
     else:
         part_blocks = 0
         part = _part(rows, Cp, dev, 5 if out_dbias is not None else 2, groups)
@@ -541,11 +541,14 @@ def tapfold_1ch(x, w, g: ConvGeom, bias=None, act=None, alpha=0.3, out=None, mul
 TAPCONV = os.environ.get("DDL_TAPCONV", "1") == "1"
 
 
-def tapconv_1ch(img, w, g: ConvGeom, bias=None, act=None, alpha=0.3, out=None):
+def tapconv_1ch(img, w, g: ConvGeom, bias=None, act=None, alpha=0.3, out=None, bn_red=None):
     """Direct convolution from a single-channel image (csrc/hip/onech_fused.hip: tapconv_1ch_kernel):
     img [B][g.H][g.W][8] (channel 0 real), w [N][1][1][Tp] bf16 (row n = the taps of output channel n) ->
     [B][g.OH][g.OW][pad8(N)] = act(bias + sum_t img[tap t of the pixel] * w[n][t]): im2col_1ch + the 1x1 GEMM in
-    one kernel, bit-identical to them.  Returns None when the shape is outside the kernel's range."""
+    one kernel, bit-identical to them.  Returns None when the shape is outside the kernel's range.
+    `bn_red` = dict(x, mean, invstd, sums (2 | 5), prev_act, prev_alpha): the result is the gradient at the output of
+    a BatchNorm whose input is `x`; the kernel also emits that BatchNorm's backward column sums (what
+    colreduce<1> / <3> would compute from the result and x in another pass) into bn_red["part"], bn_red["nb"]."""
     if not TAPCONV:
         return None
     _chk_act(img, "img")
@@ -570,12 +573,28 @@ def tapconv_1ch(img, w, g: ConvGeom, bias=None, act=None, alpha=0.3, out=None):
         y = torch.empty(B, g.OH, g.OW, Np, dtype=torch.bfloat16, device=img.device)
     ranges = _batch_ranges(B, max(g.OH * g.OW * Np, g.H * g.W * 8))
     if ranges is not None:
-        for b0, b1 in ranges:
+        for b0, b1 in ranges:           # (no reduction fusion across split launches: bn_red stays untouched)
             if tapconv_1ch(img[b0:b1], w, g, bias, act, alpha, y[b0:b1]) is None:
                 return None
         return y
+    rx = rmu = ris = rpart = None
+    rsums, ract, ralpha = 0, 0, 0.0
+    if bn_red is not None and ACT_CODE[act] in (0, 1, 6):
+        xr = bn_red["x"]
+        _chk_act(xr, "bn_red x")
+        if tuple(xr.shape) != tuple(y.shape):
+            raise ValueError(f"tapconv_1ch: bn_red x {tuple(xr.shape)} vs output {tuple(y.shape)}")
+        rsums = int(bn_red["sums"])
+        _chk_f32(bn_red["mean"], Np, "bn_red mean")
+        _chk_f32(bn_red["invstd"], Np, "bn_red invstd")
+        part = torch.empty(rsums * Np * B, dtype=torch.float32, device=img.device)
+        rx, rmu, ris, rpart = xr.data_ptr(), bn_red["mean"].data_ptr(), bn_red["invstd"].data_ptr(), part.data_ptr()
+        ract, ralpha = ACT_CODE[bn_red.get("prev_act")], float(bn_red.get("prev_alpha", 0.3))
     rc = _tapconv(img.data_ptr(), w.data_ptr(), _p(bias), y.data_ptr(), B, g.H, g.W, g.OH, g.OW, g.KH, g.KW, g.sh,
-                  g.sw, g.dh, g.dw, g.pt, g.pl, Tp, Np, N, ACT_CODE[act], alpha, _stream())
+                  g.sw, g.dh, g.dw, g.pt, g.pl, Tp, Np, N, ACT_CODE[act], alpha, rx, rmu, ris, rpart, rsums, ract,
+                  ralpha, _stream())
+    if rc == 0 and rx is not None:
+        bn_red["part"], bn_red["nb"] = part, B
     if rc < 0:
         raise ValueError(f"tapconv_1ch rejected its arguments (rc={rc})")
     if rc > 0:

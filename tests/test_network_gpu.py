@@ -148,14 +148,16 @@ def test_generator_inference_forward_with_folded_batchnorm():
 def test_bn_on_load_matches_materialised_generator():
     """The generator's last BatchNorm is applied on load by the single-channel transposed conv (no BN output tensor):
     forward image, every gradient and the moving statistics must equal the materialised path bit for bit, for the
-    plain forward and for the merged two-group forward narrowed to its second half."""
+    plain forward and for the merged two-group forward narrowed to its second half.  With the BatchNorm's backward
+    column sums coming out of the input-gradient kernel (one partial per image instead of colreduce's blocks) the
+    gradients agree to summation order."""
     from distributeddeeplearning_amd.models import network as N
     from distributeddeeplearning_amd.models.dcgan import generator_spec
     torch.manual_seed(3)
     z = torch.rand(12, 128, device="cuda").bfloat16() * 2 - 1
     res = {}
-    for flag in (True, False):
-        N.BN_ON_LOAD = flag
+    for on_load, fuse_bwd in ((True, False), (False, False), (True, True)):
+        N.BN_ON_LOAD, N.BN_BWD_FUSE = on_load, fuse_bwd
         try:
             net = N.Network(generator_spec(28, 16), "cuda", seed=5)
             assert any(isinstance(op, N.BNOp) and op.defer_to is not None for op in net.ops)
@@ -164,11 +166,15 @@ def test_bn_on_load_matches_materialised_generator():
             net.G.zero_()
             net.backward(torch.ones_like(y[6:]) * 0.01, need_input_grad=False)
             torch.cuda.synchronize()
-            res[flag] = (y.clone(), net.G.clone(), net.S.clone())
+            res[(on_load, fuse_bwd)] = (y.clone(), net.G.clone(), net.S.clone())
         finally:
-            N.BN_ON_LOAD = True
-    for a, b in zip(res[True], res[False]):
+            N.BN_ON_LOAD, N.BN_BWD_FUSE = True, True
+    for a, b in zip(res[(True, False)], res[(False, False)]):
         assert torch.equal(a, b)
+    fy, fg, fs = res[(True, True)]
+    ry, rg, rs = res[(True, False)]
+    assert torch.equal(fy, ry) and torch.equal(fs, rs)
+    assert float((fg - rg).norm() / rg.norm()) < 2e-3
 
 
 @pytest.mark.parametrize("policy", ["split", "mixed"])
