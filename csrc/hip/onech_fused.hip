@@ -316,9 +316,27 @@ __global__ __launch_bounds__(256) void tapconv_1ch_kernel(const TapConvArgs a) {
                 for (int k = 0; k < RED; ++k) rs[k][t][e] = 0.f;
             }
     }
+    // RED: the BatchNorm-input values of a fragment are fetched one fragment ahead (a load issued where it is
+    // consumed would expose a full memory latency per fragment: 12 of them per wave)
+    uint2 xq[RED ? NT : 1];
+    auto fetch_x = [&](int f_, uint2 (&dst_)[RED ? NT : 1]) {
+        const int p_ = f_ * 16 + fr;
+#pragma unroll
+        for (int t = 0; t < (RED ? NT : 0); ++t) {
+            const bool ok = (p_ < npix) & (16 * t + 4 * fq < a.Np);
+            dst_[t] = ok ? *(const uint2*)(a.rx + ((size_t)b * npix + p_) * a.Np + 16 * t + 4 * fq) : make_uint2(0, 0);
+        }
+    };
+    if (RED) fetch_x(wave, xq);
     for (int f = wave; f * 16 < npix; f += 4) {
         const int p = f * 16 + fr;
         const int pp = p < npix ? p : 0;
+        uint2 xcur[RED ? NT : 1];
+        if (RED) {
+#pragma unroll
+            for (int t = 0; t < NT; ++t) xcur[t] = xq[t];
+            fetch_x(f + 4, xq);
+        }
         const int oh = tf_fdiv(pp, invOW), ow = pp - oh * a.OW;
         const int base = (oh * a.sh) * a.PW + ow * a.sw;
         uint32_t q[4];
@@ -347,7 +365,7 @@ __global__ __launch_bounds__(256) void tapconv_1ch_kernel(const TapConvArgs a) {
                 if (16 * t + 4 * fq < a.Np) {
                     *(uint2*)(dst + 16 * t + 4 * fq) = make_uint2(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]));
                     if (RED) {
-                        const uint2 xr = *(const uint2*)(a.rx + ((size_t)b * npix + p) * a.Np + 16 * t + 4 * fq);
+                        const uint2 xr = xcur[t];
                         const float xv[4] = {__uint_as_float(xr.x << 16), __uint_as_float(xr.x & 0xffff0000u),
                                              __uint_as_float(xr.y << 16), __uint_as_float(xr.y & 0xffff0000u)};
 #pragma unroll

@@ -260,7 +260,7 @@ class ConvOp(Op):
             if need_dx:                 # input gradient straight from the dY image when nothing is fused behind it
                 red, bn = None, self.in_bn
                 if (mul is None and BN_BWD_FUSE and bn is not None and bn.used_batch_stats and bn.groups_used == 1
-                        and bn.x is not None and bn.y is bn.x):
+                        and bn.x is not None and bn.defer_to is self and self.x_affine is not None):
                     # dx is the gradient at that BatchNorm's output: the kernel also emits its backward column sums
                     sums = 5 if (need_dw and bn.bias_grad_for is not None) else 2
                     red = dict(x=bn.x, mean=bn.mean.reshape(-1), invstd=bn.invstd.reshape(-1), sums=sums,
@@ -456,7 +456,8 @@ class BNOp(Op):
                 conv.gbias if (need_dw and conv is not None) else None, self.groups_used, part=pre[0],
                 part_blocks=pre[1])
             return dx
-        dx, _, _ = F.bn_bwd(dy, self.x, None if self.y is self.x else self.y, self.mean, self.invstd,
+        no_y = self.x.is_cuda and (self.y is self.x or self.post_act in (None, "linear"))
+        dx, _, _ = F.bn_bwd(dy, self.x, None if no_y else self.y, self.mean, self.invstd,
                             self.gamma, self.post_act,
                             self.post_alpha, self.used_batch_stats, self.prev_act, self.prev_alpha,
                             self.ggamma if need_dw else None, self.gbeta if need_dw else None,
