@@ -47,6 +47,10 @@ struct PConvArgs {
     // AFFINE instantiation: an inference-phase BatchNorm right behind this layer, folded into the epilogue:
     // out = act(conv + bias) * k + (beta - moving_mean * k), k = gamma * rsqrt(moving_var + eps)
     const float* bn_gamma; const float* bn_beta; const float* bn_mean; const float* bn_var; float bn_eps;
+    // optional per-channel affine on the SOURCE as the patch is staged (a BatchNorm in front of this layer that is
+    // never materialised): src' = bf16(src * in_scale[grp][c] + in_shift[grp][c]) on real pixels, grp =
+    // image / in_group_rows; halo and missing images stay zero
+    const float* in_scale; const float* in_shift; int in_group_rows, in_ctrue;
 };
 
 // floor(x / d) for 0 <= x < 2^22 via a float reciprocal (the +0.5 keeps x/d away from integers)
@@ -95,7 +99,7 @@ __global__ __launch_bounds__(256, (BN * FR >= 512 ? 1 : 2)) void pconv_kernel(co
         // eight independent 16-byte loads in flight per thread before the first LDS store
         for (int base = tid; base < total; base += 256 * 8) {
             u32x4 v[8];
-            int dst[8];
+            int dst[8], aoff[8];
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
                 int u = base + k * 256;
@@ -109,6 +113,25 @@ __global__ __launch_bounds__(256, (BN * FR >= 512 ? 1 : 2)) void pconv_kernel(co
                 unsigned off = ok ? (unsigned)(((b * a.Hs + sr) * a.Ws + sc) * Cs + c8 * 8) * 2u : OOB;
                 v[k] = __builtin_amdgcn_raw_buffer_load_b128(rsA, off, 0, 0);
                 dst[k] = in ? img * a.img_bytes + pix * a.pitch + c8 * 16 : -1;
+                aoff[k] = ok ? ((b << 8) | c8) : -1;            // decoded only when an input affine is present
+            }
+            if (a.in_scale) {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    if (aoff[k] < 0) continue;
+                    const int cb = (aoff[k] & 255) * 8;
+                    const int ao = ((aoff[k] >> 8) / a.in_group_rows) * Cs + cb;
+                    const float4 sa = *(const float4*)(a.in_scale + ao), sb = *(const float4*)(a.in_scale + ao + 4);
+                    const float4 ha = *(const float4*)(a.in_shift + ao), hb = *(const float4*)(a.in_shift + ao + 4);
+                    const float sc[8] = {sa.x, sa.y, sa.z, sa.w, sb.x, sb.y, sb.z, sb.w};
+                    const float sh[8] = {ha.x, ha.y, ha.z, ha.w, hb.x, hb.y, hb.z, hb.w};
+                    float f[8];
+                    unpack8(make_uint4(v[k][0], v[k][1], v[k][2], v[k][3]), f);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) f[e] = (cb + e < a.in_ctrue) ? fmaf(f[e], sc[e], sh[e]) : 0.f;
+                    const uint4 r = pack8(f);
+                    v[k] = (u32x4){r.x, r.y, r.z, r.w};
+                }
             }
 #pragma unroll
             for (int k = 0; k < 8; ++k)
@@ -437,7 +460,8 @@ DDL_API int ddl_pconv(const void* src, const void* wgt, const float* bias, void*
                       int Wd, int Nd, int Nw, int ssh, int ssw, int sdh, int sdw, int Ttot, int act, float alpha,
                       int IMG, int BR, int bands, int omin_h, int omin_w, int PH, int PW, int pitch, int BN, int FR,
                       float* stats, const float* bn_gamma, const float* bn_beta, const float* bn_mean,
-                      const float* bn_var, float bn_eps, hipStream_t s) {
+                      const float* bn_var, float bn_eps, const float* in_scale, const float* in_shift,
+                      int in_group_rows, int in_ctrue, hipStream_t s) {
     if (Cs % 8 != 0 || Cs <= 0 || Nd <= 0 || Nd % 8 != 0 || n_classes <= 0 || B <= 0 || IMG <= 0 || BR <= 0) return -1;
     if (pitch % 16 != 0 || pitch < Cs * 2) return -1;
     if ((long)B * Hs * Ws * Cs >= (1L << 31) || (long)B * Hd * Wd * Nd >= (1L << 31)) return -3;
@@ -448,6 +472,8 @@ DDL_API int ddl_pconv(const void* src, const void* wgt, const float* bias, void*
     a.stats = stats;
     if (stats && bn_gamma) return -1;
     a.bn_gamma = bn_gamma; a.bn_beta = bn_beta; a.bn_mean = bn_mean; a.bn_var = bn_var; a.bn_eps = bn_eps;
+    if (in_scale && (!in_shift || in_group_rows <= 0 || Cs > 2048 || B >= (1 << 23))) return -1;
+    a.in_scale = in_scale; a.in_shift = in_shift; a.in_group_rows = in_scale ? in_group_rows : 1; a.in_ctrue = in_ctrue;
     a.n_classes = n_classes; a.total_stages = total_stages;
     a.B = B; a.Hs = Hs; a.Ws = Ws; a.Cs = Cs; a.Hd = Hd; a.Wd = Wd; a.Nd = Nd; a.Nw = Nw;
     a.ssh = ssh; a.ssw = ssw; a.sdh = sdh; a.sdw = sdw; a.wrow = Ttot * Cs; a.act = act; a.alpha = alpha;

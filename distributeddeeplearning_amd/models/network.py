@@ -298,13 +298,15 @@ class ConvOp(Op):
         bi = None
         if not training and bn is not None and bn.post_act in (None, "linear") and x.is_cuda:
             so, bi = {}, (bn.gamma, bn.beta, bn.moving_mean, bn.moving_var, bn.eps)
+        aff, self.in_affine = self.in_affine, None
         if self.kind == "dense":
             B = x.shape[0]
             x4 = x.reshape(B, 1, 1, -1)
             y = F.conv_fprop(x4, self._w4(self.w_main), self.bias, g, self.act, self.alpha, stats_out=so,
                              bn_infer=bi).reshape(B, -1)
         elif self.kind == "conv2d_transpose":
-            y = F.conv_dgrad(x, self.w_main, g, self.bias, self.act, self.alpha, stats_out=so, bn_infer=bi)
+            y = F.conv_dgrad(x, self.w_main, g, self.bias, self.act, self.alpha, stats_out=so, bn_infer=bi,
+                             in_affine=aff)
         else:
             y = F.conv_fprop(x, self.w_main, self.bias, g, self.act, self.alpha, stats_out=so, bn_infer=bi)
         if so and "part" in so:
@@ -314,7 +316,7 @@ class ConvOp(Op):
         elif so and so.get("affine"):
             bn.applied_by_producer = True
         if training:
-            self.x, self.y = x, y
+            self.x, self.y, self.x_affine = x, y, aff
         return y
 
     def bwd(self, dy, need_dx=True, need_dw=True, mul=None):
@@ -344,7 +346,11 @@ class ConvOp(Op):
             # core X = our output (dy), core Y = our input (x)
             if need_dw:
                 def wg():
-                    F.conv_wgrad(dy, x, g, "B", out=self.gkernel)
+                    xx = x
+                    if self.x_affine is not None:       # the BatchNorm output was never written: rebuild it for
+                        sc, sh, groups, ctrue = self.x_affine       # the weight gradient (on the wgrad branch)
+                        xx = F.hip_backend().bn_apply(x, sc, sh, None, 0.3, ctrue, groups)
+                    F.conv_wgrad(dy, xx, g, "B", out=self.gkernel)
                     self._bias_grad(dy)
                 _BR.run(wg, dy)
             if need_dx:
@@ -545,8 +551,11 @@ class Network:
         # BN (no activation of its own) straight in front of a single-output-channel transposed conv on the taps
         # path: the conv's kernels apply the BN affine as they load x, the BN writes no tensor of its own
         for a_, b_ in zip(self.ops, self.ops[1:]):
-            if isinstance(a_, BNOp) and isinstance(b_, ConvOp) and b_.onech == "out" and a_.rank4 \
-                    and a_.post_act in (None, "linear"):
+            if not (isinstance(a_, BNOp) and isinstance(b_, ConvOp) and a_.rank4 and self.on_gpu
+                    and a_.post_act in (None, "linear")):
+                continue
+            # ... or in front of any other transposed conv: the patch-resident kernel applies it while staging
+            if b_.onech == "out" or (b_.onech is None and b_.kind == "conv2d_transpose" and not b_.g.depthwise):
                 a_.defer_to = b_
                 b_.in_bn = a_
         self.init_weights(seed)

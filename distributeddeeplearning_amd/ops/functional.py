@@ -49,11 +49,13 @@ def conv_fprop(x, wA, bias, g, act=None, alpha=0.3, mul=None, stats_out=None, bn
     return _cpu_mul(cpu_ref.conv_fprop(x, wA, bias, g, act, alpha), mul)
 
 
-def conv_dgrad(dy, wB, g, bias=None, act=None, alpha=0.3, mul=None, stats_out=None, bn_infer=None):
+def conv_dgrad(dy, wB, g, bias=None, act=None, alpha=0.3, mul=None, stats_out=None, bn_infer=None, in_affine=None):
     """`wB` is the core weight in [I][KH][KW][O] order (reduction channel contiguous);
-    depthwise: [KH][KW][C]."""
+    depthwise: [KH][KW][C].  `in_affine`: device only (a BatchNorm applied on load, ops/hip.py)."""
     if dy.is_cuda:
-        return hip_backend().conv_dgrad(dy, wB, g, bias, act, alpha, mul, stats_out, bn_infer)
+        return hip_backend().conv_dgrad(dy, wB, g, bias, act, alpha, mul, stats_out, bn_infer, in_affine=in_affine)
+    if in_affine is not None:
+        raise ValueError("conv_dgrad: in_affine exists on the device only")
     wA = wB if g.depthwise else wB.permute(3, 1, 2, 0)
     return _cpu_mul(cpu_ref.conv_dgrad(dy, wA, g, bias, act, alpha), mul)
 

@@ -83,7 +83,7 @@ _philox = _sig("ddl_philox_uniform", None, vp, cl, vp, cf, cf, vp)
 _igemm = _sig("ddl_igemm_conv", ci, vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci,
               ci, ci, ci, ci, cf, ci, ci, vp, vp)
 _pconv = _sig("ddl_pconv", ci, vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, cf,
-              ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, vp, vp, vp, vp, vp, cf, vp)
+              ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, vp, vp, vp, vp, vp, cf, vp, vp, ci, ci, vp)
 _pconv_lds = _sig("ddl_pconv_lds_bytes", ci, ci, ci, cl)
 _wgrad_ksplit = _sig("ddl_wgrad_ksplit", ci, ci, ci, ci, ci)
 _wgrad = _sig("ddl_conv_wgrad", ci, vp, vp, vp, vp, cl, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci,
@@ -1075,7 +1075,7 @@ def _pconv_units(pl, B):
 
 
 def _run_pconv(pl, src, wgt, bias, dst, g, B, Hs, Ws, Cs, Hd, Wd, Nd, Nw, ss, sd, act, alpha, mul=None, stats=None,
-               bn_infer=None):
+               bn_infer=None, in_affine=None):
     """`stats`: fp32 tensor of 2 * Nd * units elements that receives per-block column sums / sums of squares
     of the output (layout [2][Nd][units]) for the BatchNorm that follows.
     `bn_infer` = (gamma, beta, moving_mean, moving_var, eps): fold an inference-phase BatchNorm into the epilogue."""
@@ -1086,10 +1086,19 @@ def _run_pconv(pl, src, wgt, bias, dst, g, B, Hs, Ws, Cs, Hd, Wd, Nd, Nw, ss, sd
         for t, n in ((gamma, "gamma"), (beta, "beta"), (mm, "moving_mean"), (mv, "moving_var")):
             _chk_f32(t, Nw, n)
         bg, bb, bm, bvv = gamma.data_ptr(), beta.data_ptr(), mm.data_ptr(), mv.data_ptr()
+    isc = ish = None
+    igr, ict = 1, Cs
+    if in_affine is not None:           # (scale, shift, (images per group,), c_true): [groups][Cs] fp32 rows
+        sc_t, sh_t, (igr,), ict = in_affine
+        ngr = -(-B // igr)
+        _chk_f32(sc_t, ngr * Cs, "in_affine scale")
+        _chk_f32(sh_t, ngr * Cs, "in_affine shift")
+        isc, ish = sc_t.data_ptr(), sh_t.data_ptr()
     rc = _pconv(src.data_ptr(), wgt.data_ptr(), _p(bias), dst.data_ptr(), pl["classes"].data_ptr(),
                 pl["ktab"].data_ptr(), pl["ncls"], pl["nst"], B, Hs, Ws, Cs, Hd, Wd, Nd, Nw, ss[0], ss[1],
                 sd[0], sd[1], g.KH * g.KW, ACT_CODE[act], alpha, pl["IMG"], pl["BR"], pl["bands"],
-                pl["omin_h"], pl["omin_w"], pl["PH"], pl["PW"], pl["pitch"], pl["BN"], pl["FR"], _p(stats), bg, bb, bm, bvv, beps, _stream())
+                pl["omin_h"], pl["omin_w"], pl["PH"], pl["PW"], pl["pitch"], pl["BN"], pl["FR"], _p(stats), bg, bb, bm,
+                bvv, beps, isc, ish, igr, ict, _stream())
     if rc != 0:
         raise ValueError(f"pconv rejected its plan (rc={rc}): {g} B={B} "
                          f"{ {k: v for k, v in pl.items() if k not in ('classes', 'ktab')} }")
@@ -1164,13 +1173,18 @@ PCONV_STATS = os.environ.get("DDL_PCONV_STATS", "1") == "1"
 
 
 def _igemm_call(src, wgt, bias, dst, g, mode, B, Hs, Ws, Cs, Hd, Wd, Nd, Nw, ss, sd, act, alpha, mul=None,
-                stats_out=None, bn_infer=None):
+                stats_out=None, bn_infer=None, in_affine=None):
     """Dispatch one class-grid convolution: the patch-resident kernel with a tuned plan, or the
     global-gather kernel.  The first (non-captured) call of each problem times the candidates on the
     real operands and caches the winner -- these shapes are static for a whole training run."""
+    def materialise():                  # the global-gather kernel has no affine on load: apply the BatchNorm first
+        sc_t, sh_t, (igr,), ict = in_affine
+        return bn_apply(src, sc_t, sh_t, None, 0.3, ict, B // igr)
     args = (src, wgt, bias, dst, g)
     tail = (B, Hs, Ws, Cs, Hd, Wd, Nd, Nw, ss, sd, act, alpha)
     if CONV_IMPL != "pconv":
+        if in_affine is not None:
+            src = materialise()
         _run_igemm(src, wgt, bias, dst, g, mode, *tail)
         _mul_inplace(dst, mul)
         _done()
@@ -1224,8 +1238,10 @@ def _igemm_call(src, wgt, bias, dst, g, mode, B, Hs, Ws, Cs, Hd, Wd, Nd, Nw, ss,
             nb = _pconv_units(choice[1], B)
             stats = torch.empty(2 * Nd * nb, dtype=torch.float32, device=src.device)
             stats_out["part"], stats_out["nb"], stats_out["img"] = stats, nb, choice[1]["IMG"]
-        _run_pconv(choice[1], *args, *tail, mul=mul, stats=stats, bn_infer=bn_infer)
+        _run_pconv(choice[1], *args, *tail, mul=mul, stats=stats, bn_infer=bn_infer, in_affine=in_affine)
     else:
+        if in_affine is not None:
+            src = materialise()
         _run_igemm(src, wgt, bias, dst, g, mode, *tail, tile=choice[1])
         _mul_inplace(dst, mul)
     _done()
@@ -1316,7 +1332,10 @@ def conv_fprop(x, wA, bias, g: ConvGeom, act=None, alpha=0.3, mul=None, stats_ou
 
 
 def conv_dgrad(dy, wB, g: ConvGeom, bias=None, act=None, alpha=0.3, mul=None, stats_out=None, bn_infer=None,
-               out=None):
+               out=None, in_affine=None):
+    """`in_affine` = (scale, shift, groups, c_true): dy is read as bf16(dy * scale[grp] + shift[grp]) -- a BatchNorm
+    in front of a transposed convolution (which runs as this dgrad) applied on load by the patch-resident kernel
+    ([groups][Op] fp32 rows, the batch being `groups` equal parts; other kernels get it materialised first)."""
     _chk_act(dy, "dy")
     B = dy.shape[0]
     Ip, Op = pad8(g.I), pad8(g.O)
@@ -1329,6 +1348,16 @@ def conv_dgrad(dy, wB, g: ConvGeom, bias=None, act=None, alpha=0.3, mul=None, st
         if tuple(out.shape) != (B, g.H, g.W, Ip):
             raise ValueError(f"conv_dgrad: out {tuple(out.shape)} != {(B, g.H, g.W, Ip)}")
     dx = out if out is not None else torch.empty(B, g.H, g.W, Ip, dtype=torch.bfloat16, device=dy.device)
+    if in_affine is not None:
+        sc_t, sh_t, groups, ictrue = in_affine
+        if B % groups:
+            raise ValueError(f"conv_dgrad: batch {B} does not split into {groups} groups")
+        ranges0 = _batch_ranges(B, max(g.H * g.W * Ip, g.OH * g.OW * Op))
+        if g.depthwise or (_is_1x1(g) and GEMM_SK) or ranges0 is not None:
+            dy = bn_apply(dy, sc_t, sh_t, None, 0.3, ictrue, groups)        # no on-load path there
+            in_affine = None
+        else:
+            in_affine = (sc_t, sh_t, (B // groups,), ictrue)
     ranges = _batch_ranges(B, max(g.H * g.W * Ip, g.OH * g.OW * Op))
     if ranges is not None:
         for b0, b1 in ranges:
@@ -1358,7 +1387,7 @@ def conv_dgrad(dy, wB, g: ConvGeom, bias=None, act=None, alpha=0.3, mul=None, st
             _done()
             return dx
     _igemm_call(dy, wB, bias, dx, g, "dgrad", B, g.OH, g.OW, Op, g.H, g.W, Ip, min(wB.shape[0], g.I),
-                (1, 1), (g.sh, g.sw), act, alpha, mul, stats_out, bn_infer)
+                (1, 1), (g.sh, g.sw), act, alpha, mul, stats_out, bn_infer, in_affine)
     return dx
 
 
