@@ -798,8 +798,55 @@ __global__ void colsum_finalize_kernel(const float* __restrict__ part, int nbloc
     out[c] = (float)s0;
 }
 
+// Few rows, many channels (the generator's Dense 128 -> 6272 at batch 1000: [1000][6272]): the two-kernel scheme
+// spreads only ~4 row blocks over 4 column groups and then walks partials.  One pass instead: a block owns 8
+// channel vectors (64 channels), its 32 row lanes each sum every 32nd row (four loads in flight), a fixed-order LDS
+// fold over the lanes writes the final sums -- deterministic, no partials, one launch.
+__global__ __launch_bounds__(256) void colsum_fewrows_kernel(const uint4* __restrict__ dy, long rows, int cg,
+                                                             int c_out, float* __restrict__ out) {
+    __shared__ float red[32][8 * 8 + 1];
+    const int gl = threadIdx.x & 7, rl = threadIdx.x >> 3;
+    const int g = blockIdx.x * 8 + gl;
+    float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (g < cg) {
+        long r = rl;
+        for (; r + 96 < rows; r += 128) {
+            uint4 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = dy[(r + 32 * u) * cg + g];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                float f[8];
+                unpack8(v[u], f);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) s[j] += f[j];
+            }
+        }
+        for (; r < rows; r += 32) {
+            float f[8];
+            unpack8(dy[r * cg + g], f);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) s[j] += f[j];
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) red[rl][gl * 8 + j] = s[j];
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        const int c = blockIdx.x * 64 + threadIdx.x;
+        float t = 0.f;
+        for (int q = 0; q < 32; ++q) t += red[q][threadIdx.x];
+        if (c < c_out) out[c] = t;
+    }
+}
+
 DDL_API void ddl_bias_grad(const void* dy, long rows, int C, int c_out, float* part, float* out,
                            hipStream_t s) {
+    if (rows <= 8192 && C >= 1024) {
+        const int cg = C / 8;
+        colsum_fewrows_kernel<<<(cg + 7) / 8, 256, 0, s>>>((const uint4*)dy, rows, cg, c_out, out);
+        return;
+    }
     dim3 grid;
     colreduce_grid(rows, C, &grid);
     colreduce_kernel<2><<<grid, EW_BLOCK, 0, s>>>((const uint4*)dy, nullptr, nullptr, nullptr, nullptr, part,

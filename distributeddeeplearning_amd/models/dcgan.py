@@ -145,6 +145,10 @@ class GANTrainer:
         self.G = Network(generator_spec(cfg.size, cfg.base, cfg.noise_dim), device, cfg.seed + 1, bn_mode)
         self.D = Network(discriminator_spec(cfg.size, cfg.base), device, cfg.seed + 2, bn_mode)
         self.G.set_no_input_grad()      # nothing differentiates with respect to the noise
+        # weight-gradient chains as parallel branches of the captured step (models/network.py SideBranch)
+        br = os.environ.get("DDL_GAN_BRANCH", "0")
+        self.D.branch_wgrad = br in ("1", "D", "DG")
+        self.G.branch_wgrad = br in ("1", "G", "DG")
         ocfg = OptimConfig.tf_adam(cfg.lr, fresh_double=cfg.reference_exact)
         self.optG, self.optD = FlatOptimizer(self.G, ocfg), FlatOptimizer(self.D, ocfg)
         self._ocfg = ocfg

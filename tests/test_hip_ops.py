@@ -325,6 +325,16 @@ def test_activations(hip, kind):
     close(host(hip, dx, 11), cpu_ref.act_bwd(dy, host(hip, y, 11), kind), atol=2e-2)
 
 
+@pytest.mark.parametrize("rows,C", [(1000, 6272), (37, 1024), (8192, 1032)])
+def test_bias_grad_few_rows_many_channels(hip, rows, C):
+    """The single-pass column sum (few rows, >= 1024 channels: a wide Dense layer's bias gradient)."""
+    torch.manual_seed(8)
+    dy = r16(torch.randn(rows, C))
+    out = torch.zeros(C - 3, device="cuda")
+    hip.bias_grad(dy.bfloat16().cuda(), out)
+    close(out.cpu(), dy.sum(0)[:C - 3], rtol=1e-3, atol=1e-2)
+
+
 def test_bias_grad_and_pad(hip):
     torch.manual_seed(7)
     dy = r16(torch.randn(500, 7, 7, 19))
