@@ -474,13 +474,53 @@ struct DwArgs {
     unsigned total;
     FastDiv dcg, dOW, dOH, dW_, dH_, dsh, dsw;
     FastDiv dsh_hc[3], dsw_wc[3];     // dgrad: dividers by the class-grid height / width of parity ph / pw (strides <= 3)
+    // fprop / wgrad: the layer's input is x * in_scale[c] + in_shift[c] on real pixels and channels < in_ctrue -- a
+    // BatchNorm in front of the layer whose output tensor is never written (null = plain x).  A depthwise tap sum is
+    // linear per channel, so the affine is applied to the SUMS, not to every loaded pixel (a 3x3 stride-1 layer
+    // would redo the BatchNorm nine times per pixel and turn ALU-bound):
+    //   forward          sum_t w_t (s x_t + h) v_t  =  s * sum_t w_t x_t v_t  +  h * sum_t w_t v_t
+    //   weight gradient  sum_m g_m (s x_mt + h) v_mt =  s * sum_m g_m x_mt v_mt + h * sum_m g_m v_mt
+    // (v = tap inside the image: the zero padding applies to the BatchNorm's OUTPUT.)  fp32 throughout: the
+    // BatchNorm output is not rounded to bf16 on the way, unlike the materialised path.
+    const float* in_scale; const float* in_shift; int in_ctrue;
+    int all_valid;                    // no tap of any output pixel falls outside the image
 };
+__device__ __forceinline__ void dw_load_affine(const DwArgs& a, int gch, float (&sc)[8], float (&sh)[8]) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int c = gch * 8 + j;
+        const bool live = c < a.in_ctrue;
+        sc[j] = live ? a.in_scale[c] : 0.f;
+        sh[j] = live ? a.in_shift[c] : 0.f;
+    }
+}
 
-template <int K>
+// AFF: 0 = plain x; 1 = affine, every tap inside the image and the grid stride a multiple of the channel groups (a
+// lane keeps ONE channel group: scale and shift * sum_t w_t are computed once, in front of the loop); 2 = affine with
+// per-pixel live-tap sums (padded layers).  Separate instantiations: the plain path keeps its 84 registers.
+template <int K, int AFF>
 __global__ __launch_bounds__(256) void dw_fprop_fast_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ w,
                                                             const float* __restrict__ bias, bf16_t* __restrict__ y,
                                                             const DwArgs a) {
     const int cg = a.C / 8;
+    float sc[8], sf[8];
+    if (AFF == 1) {
+        const unsigned i0 = blockIdx.x * 256u + threadIdx.x;
+        const int gch0 = (int)(i0 - fdivu(i0, a.dcg) * cg);
+        float ws[8];
+        dw_load_affine(a, gch0, sc, sf);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) ws[j] = 0.f;
+#pragma unroll
+        for (int t = 0; t < K * K; ++t) {
+            float wf[8];
+            unpack8(*(const uint4*)(w + t * a.C + gch0 * 8), wf);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) ws[j] += wf[j];
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) sf[j] *= ws[j];
+    }
     for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < a.total; i += gridDim.x * 256u) {
         const unsigned p = fdivu(i, a.dcg);
         const int gch = (int)(i - p * cg);
@@ -490,6 +530,7 @@ __global__ __launch_bounds__(256) void dw_fprop_fast_kernel(const bf16_t* __rest
         const int oh = (int)(q - b * a.OH);
         const bf16_t* xb = x + (size_t)b * a.H * a.W * a.C + gch * 8;
         uint4 xv[K * K], wv[K * K];
+        unsigned vm = 0;
 #pragma unroll
         for (int kh = 0; kh < K; ++kh)
 #pragma unroll
@@ -499,10 +540,16 @@ __global__ __launch_bounds__(256) void dw_fprop_fast_kernel(const bf16_t* __rest
                 const uint4 ld = *(const uint4*)(xb + (v ? (ih * a.W + iw) * a.C : 0));
                 xv[kh * K + kw] = v ? ld : make_uint4(0, 0, 0, 0);
                 wv[kh * K + kw] = *(const uint4*)(w + (kh * K + kw) * a.C + gch * 8);
+                vm |= v ? (1u << (kh * K + kw)) : 0u;
             }
         float acc[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+        float ws[8];
+        if (AFF == 2) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) ws[j] = 0.f;
+        }
 #pragma unroll
         for (int t = 0; t < K * K; ++t) {
             float xf[8], wf[8];
@@ -510,6 +557,19 @@ __global__ __launch_bounds__(256) void dw_fprop_fast_kernel(const bf16_t* __rest
             unpack8(wv[t], wf);
 #pragma unroll
             for (int j = 0; j < 8; ++j) acc[j] = fmaf(xf[j], wf[j], acc[j]);
+            if (AFF == 2) {
+                const bool live = (vm >> t) & 1u;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) ws[j] += live ? wf[j] : 0.f;
+            }
+        }
+        if (AFF == 1) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[j] = fmaf(sc[j], acc[j], sf[j]);
+        } else if (AFF == 2) {
+            dw_load_affine(a, gch, sc, sf);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[j] = fmaf(sc[j], acc[j], sf[j] * ws[j]);
         }
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
@@ -584,7 +644,7 @@ __global__ __launch_bounds__(256) void dw_dgrad_fast_kernel(const bf16_t* __rest
 // their X pixels are neighbours.  One block per tap (nine dY reads) and one block for all nine taps (one
 // dY read, 72 accumulators: 771 vs 544 us per classifier step) were both measured slower: K x the
 // blocks with a small register footprint hide the gather latency, K x fewer dY reads cut the traffic.
-template <int K>
+template <int K, bool AFF>
 __global__ __launch_bounds__(256) void dw_wgrad_fast_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x,
                                                             float* __restrict__ part, const DwArgs a) {
     __shared__ float red[256][9];
@@ -595,14 +655,16 @@ __global__ __launch_bounds__(256) void dw_wgrad_fast_kernel(const bf16_t* __rest
     const int kh = blockIdx.y;
     const int offh = kh * a.dh - a.pt;
     const unsigned M = a.total;                  // B * OH * OW
-    float acc[K][8];
+    float acc[K][8], gs[AFF ? K : 1][8];        // gs: sums of dY over the pixels whose tap is live (on-load affine only)
 #pragma unroll
     for (int t = 0; t < K; ++t)
 #pragma unroll
-        for (int j = 0; j < 8; ++j) acc[t][j] = 0.f;
+        for (int j = 0; j < 8; ++j) { acc[t][j] = 0.f; if (AFF) gs[t][j] = 0.f; }
+    constexpr bool aff = AFF;
     if (rl < rpi && gch < cg) {
         const unsigned stride = gridDim.x * (unsigned)rpi;
-        auto one = [&](unsigned m, uint4& g4, uint4 (&x4)[K]) {
+        auto one = [&](unsigned m, uint4& g4, uint4 (&x4)[K], unsigned& vm) {
+            vm = 0;
             const unsigned q = fdivu(m, a.dOW);
             const int ow = (int)(m - q * a.OW);
             const unsigned b = fdivu(q, a.dOH);
@@ -617,15 +679,25 @@ __global__ __launch_bounds__(256) void dw_wgrad_fast_kernel(const bf16_t* __rest
                 const bool v = vh & ((unsigned)iw < (unsigned)a.W);
                 const uint4 ld = *(const uint4*)(xb + (v ? (ih * a.W + iw) * a.C : 0));
                 x4[kw] = v ? ld : make_uint4(0, 0, 0, 0);
+                vm |= v ? (1u << kw) : 0u;
             }
         };
-        auto fma = [&](const uint4& g4, const uint4 (&x4)[K]) {
+        auto fma = [&](const uint4& g4, const uint4 (&x4)[K], unsigned vm) {
             float gf[8];
             unpack8(g4, gf);
+            if (aff && a.all_valid) {           // every tap live: one dY sum serves all taps
+#pragma unroll
+                for (int j = 0; j < 8; ++j) gs[0][j] += gf[j];
+            }
 #pragma unroll
             for (int kw = 0; kw < K; ++kw) {
                 float xf[8];
                 unpack8(x4[kw], xf);
+                if (aff && !a.all_valid) {
+                    const bool live = (vm >> kw) & 1u;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) gs[kw][j] += live ? gf[j] : 0.f;
+                }
 #pragma unroll
                 for (int j = 0; j < 8; ++j) acc[kw][j] = fmaf(gf[j], xf[j], acc[kw][j]);
             }
@@ -633,15 +705,26 @@ __global__ __launch_bounds__(256) void dw_wgrad_fast_kernel(const bf16_t* __rest
         unsigned m = blockIdx.x * (unsigned)rpi + rl;
         for (; m + stride < M; m += 2 * stride) {
             uint4 gA, gB, xA[K], xB[K];
-            one(m, gA, xA);
-            one(m + stride, gB, xB);
-            fma(gA, xA);
-            fma(gB, xB);
+            unsigned vA, vB;
+            one(m, gA, xA, vA);
+            one(m + stride, gB, xB, vB);
+            fma(gA, xA, vA);
+            fma(gB, xB, vB);
         }
         for (; m < M; m += stride) {
             uint4 gA, xA[K];
-            one(m, gA, xA);
-            fma(gA, xA);
+            unsigned vA;
+            one(m, gA, xA, vA);
+            fma(gA, xA, vA);
+        }
+        if (aff) {                      // linear in the partial sums: applied per block, before the slab reduce
+            float sc[8], sf[8];
+            dw_load_affine(a, gch, sc, sf);
+#pragma unroll
+            for (int kw = 0; kw < K; ++kw)
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+                    acc[kw][j] = fmaf(sc[j], acc[kw][j], sf[j] * (a.all_valid ? gs[0][j] : gs[kw][j]));
         }
     }
 #pragma unroll
@@ -675,7 +758,18 @@ static void dw_fast_launch(int mode, const void* a_, const void* w, const float*
         unsigned g = (a.total + 255u) / 256u;
         if (g > 8192u) g = 8192u;
         if (mode == 0) {
-            dw_fprop_fast_kernel<K><<<g, 256, 0, s>>>((const bf16_t*)a_, (const bf16_t*)w, bias, (bf16_t*)out, a);
+            if (!a.in_scale) {
+                dw_fprop_fast_kernel<K, 0><<<g, 256, 0, s>>>((const bf16_t*)a_, (const bf16_t*)w, bias, (bf16_t*)out, a);
+            } else {
+                // a lane keeps its channel group if the grid stride is a multiple of the groups (or it runs one trip)
+                unsigned gi = g;
+                if ((gi * 256u) % (unsigned)cg && (unsigned long)gi * 256u < a.total && gi > (unsigned)cg) gi -= gi % (unsigned)cg;
+                const bool inv = (gi * 256u) % (unsigned)cg == 0 || (unsigned long)gi * 256u >= a.total;
+                if (a.all_valid && inv)
+                    dw_fprop_fast_kernel<K, 1><<<gi, 256, 0, s>>>((const bf16_t*)a_, (const bf16_t*)w, bias, (bf16_t*)out, a);
+                else
+                    dw_fprop_fast_kernel<K, 2><<<g, 256, 0, s>>>((const bf16_t*)a_, (const bf16_t*)w, bias, (bf16_t*)out, a);
+            }
         } else {
             const int classes = a.sh * a.sw;
             unsigned gx = (g + classes - 1) / classes;
@@ -684,21 +778,29 @@ static void dw_fast_launch(int mode, const void* a_, const void* w, const float*
                                                                       (bf16_t*)out, a);
         }
     } else {
-        dw_wgrad_fast_kernel<K><<<dim3(nb, K, (cg + 255) / 256), 256, 0, s>>>((const bf16_t*)a_, (const bf16_t*)w,
-                                                                              part, a);
+        if (a.in_scale)
+            dw_wgrad_fast_kernel<K, true><<<dim3(nb, K, (cg + 255) / 256), 256, 0, s>>>((const bf16_t*)a_,
+                                                                                        (const bf16_t*)w, part, a);
+        else
+            dw_wgrad_fast_kernel<K, false><<<dim3(nb, K, (cg + 255) / 256), 256, 0, s>>>((const bf16_t*)a_,
+                                                                                         (const bf16_t*)w, part, a);
     }
 }
 
 DDL_API int ddl_depthwise(int mode, const void* a, const void* w, const float* bias, void* out, float* part,
                           int B, int H, int W, int C, int OH, int OW, int KH, int KW, int sh, int sw, int dh,
-                          int dw, int pt, int pl, int c_true, int act, float alpha, hipStream_t s) {
+                          int dw, int pt, int pl, int c_true, int act, float alpha, const float* in_scale,
+                          const float* in_shift, int in_ctrue, hipStream_t s) {
     if (C % 8) return -1;
+    if (in_scale && mode == 1) return -1;
     const int cg = C / 8;
     const long in_elems = (long)B * H * W * C, out_elems = (long)B * OH * OW * C;
     if (KH == KW && KH <= 3 && in_elems < (1L << 31) && out_elems < (1L << 31) && sh <= 3 && sw <= 3) {
         DwArgs d;
         d.B = B; d.H = H; d.W = W; d.C = C; d.OH = OH; d.OW = OW; d.sh = sh; d.sw = sw; d.dh = dh; d.dw = dw;
         d.pt = pt; d.pl = pl; d.c_true = c_true; d.act = act; d.alpha = alpha;
+        d.in_scale = in_scale; d.in_shift = in_shift; d.in_ctrue = in_ctrue;
+        d.all_valid = pt == 0 && pl == 0 && (OH - 1) * sh + (KH - 1) * dh < H && (OW - 1) * sw + (KW - 1) * dw < W;
         d.total = (unsigned)(mode == 0 ? (long)B * OH * OW * cg : (mode == 1 ? (long)B * H * W * cg : (long)B * OH * OW));
         d.dcg = make_fastdiv(cg); d.dOW = make_fastdiv(OW); d.dOH = make_fastdiv(OH);
         d.dW_ = make_fastdiv(W); d.dH_ = make_fastdiv(H); d.dsh = make_fastdiv(sh); d.dsw = make_fastdiv(sw);
@@ -714,6 +816,7 @@ DDL_API int ddl_depthwise(int mode, const void* a, const void* w, const float* b
         if (mode == 2) ddl_slab_reduce(part, (float*)out, (long)KH * KW * C, (long)KH * KW * C, nb, s);
         return 0;
     }
+    if (in_scale) return -5;  // the generic kernels have no on-load affine: the caller materialises
     if (mode == 0) {          // fprop: a = x, out = y
         long total = (long)B * OH * OW * cg;
         long g = (total + 255) / 256;

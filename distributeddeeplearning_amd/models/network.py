@@ -299,6 +299,7 @@ class ConvOp(Op):
         if not training and bn is not None and bn.post_act in (None, "linear") and x.is_cuda:
             so, bi = {}, (bn.gamma, bn.beta, bn.moving_mean, bn.moving_var, bn.eps)
         aff, self.in_affine = self.in_affine, None
+        sink = {} if aff is not None else None      # filled when the dispatch had to materialise the BatchNorm output
         if self.kind == "dense":
             B = x.shape[0]
             x4 = x.reshape(B, 1, 1, -1)
@@ -306,9 +307,12 @@ class ConvOp(Op):
                              bn_infer=bi).reshape(B, -1)
         elif self.kind == "conv2d_transpose":
             y = F.conv_dgrad(x, self.w_main, g, self.bias, self.act, self.alpha, stats_out=so, bn_infer=bi,
-                             in_affine=aff)
+                             in_affine=aff, aff_sink=sink)
         else:
-            y = F.conv_fprop(x, self.w_main, self.bias, g, self.act, self.alpha, stats_out=so, bn_infer=bi)
+            y = F.conv_fprop(x, self.w_main, self.bias, g, self.act, self.alpha, stats_out=so, bn_infer=bi,
+                             in_affine=aff, aff_sink=sink)
+        if sink:                        # keep the materialised tensor: the weight gradient reads it as it is
+            x, aff = sink["x"], None
         if so and "part" in so:
             # per-group statistics need every producer block inside one batch group
             if bn.groups == 1 or (x.shape[0] % (so["img"] * bn.groups) == 0):
@@ -358,7 +362,14 @@ class ConvOp(Op):
         else:
             if need_dw:
                 def wg():
-                    F.conv_wgrad(x, dy, g, "A", out=self.gkernel)
+                    xx, xa = x, None
+                    if self.x_affine is not None:       # depthwise behind a BatchNorm applied on load
+                        sc, sh, groups, ctrue = self.x_affine
+                        if g.depthwise and groups == 1:
+                            xa = (sc.reshape(-1), sh.reshape(-1), ctrue)
+                        else:
+                            xx = F.hip_backend().bn_apply(x, sc, sh, None, 0.3, ctrue, groups)
+                    F.conv_wgrad(xx, dy, g, "A", out=self.gkernel, x_affine=xa)
                     self._bias_grad(dy)
                 _BR.run(wg, dy)
             if need_dx:
@@ -389,6 +400,7 @@ class BNOp(Op):
         self.groups = 1                # batch groups with their own batch statistics (set per forward pass)
         self.groups_used = 1
         self.defer_to = None           # ConvOp that applies this BN's affine on load (no output tensor of our own)
+        self.fp32_handoff = False      # ... and does so in fp32 (depthwise tap sums): no bf16 rounding of our output
         self.pre_bwd = None            # (partials, blocks, sums) of our backward reduction, left by the kernel that made dy
 
     def fwd(self, x, training):
@@ -551,11 +563,19 @@ class Network:
         # BN (no activation of its own) straight in front of a single-output-channel transposed conv on the taps
         # path: the conv's kernels apply the BN affine as they load x, the BN writes no tensor of its own
         for a_, b_ in zip(self.ops, self.ops[1:]):
-            if not (isinstance(a_, BNOp) and isinstance(b_, ConvOp) and a_.rank4 and self.on_gpu
+            if not (isinstance(a_, BNOp) and isinstance(b_, ConvOp) and a_.rank4
                     and a_.post_act in (None, "linear")):
                 continue
+            # in front of a depthwise layer the device applies the affine to fp32 tap sums: the BN output is never
+            # rounded to bf16 there, and the bf16-emulating oracle must not round it either (Network.forward)
+            a_.fp32_handoff = (BN_ON_LOAD and b_.onech is None and b_.g.depthwise and b_.kind != "conv2d_transpose"
+                               and b_.g.KH == b_.g.KW <= 3 and b_.g.sh <= 3 and b_.g.sw <= 3)
+            if not self.on_gpu:
+                continue
             # ... or in front of any other transposed conv: the patch-resident kernel applies it while staging
-            if b_.onech == "out" or (b_.onech is None and b_.kind == "conv2d_transpose" and not b_.g.depthwise):
+            # ... or in front of a depthwise layer: the stencil kernels (forward, weight gradient) apply it per loaded pixel
+            if (b_.onech == "out" or (b_.onech is None and b_.kind == "conv2d_transpose" and not b_.g.depthwise)
+                    or (b_.onech is None and b_.g.depthwise and b_.kind != "conv2d_transpose")):
                 a_.defer_to = b_
                 b_.in_bn = a_
         self.init_weights(seed)
@@ -850,7 +870,8 @@ class Network:
         try:
             for op in self.ops[start:stop]:
                 x = op.fwd(x, training)
-                if self.emulate_bf16 and not self.on_gpu and not isinstance(op, ViewOp):
+                if self.emulate_bf16 and not self.on_gpu and not isinstance(op, ViewOp) \
+                        and not (training and getattr(op, "fp32_handoff", False)):
                     x = x.bfloat16().float()
         finally:
             if out is not None:

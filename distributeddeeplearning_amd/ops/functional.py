@@ -38,34 +38,42 @@ def _cpu_mul(t, mul):
     return cpu_ref.act_bwd(t, y.reshape(t.shape), act, alpha)
 
 
-def conv_fprop(x, wA, bias, g, act=None, alpha=0.3, mul=None, stats_out=None, bn_infer=None):
+def conv_fprop(x, wA, bias, g, act=None, alpha=0.3, mul=None, stats_out=None, bn_infer=None, in_affine=None,
+               aff_sink=None):
     """`mul` = (y, act, alpha): result *= act'(y), the activation backward of the layer below (fused
     into the kernel epilogue on device).  `stats_out` (dict): on device, a kernel that can emit the
     output's per-channel partial sums for a following BatchNorm leaves them in stats_out["part"/"nb"];
     with `bn_infer` = (gamma, beta, moving_mean, moving_var, eps) a kernel that can fold that inference-phase
     BatchNorm into its epilogue does so and sets stats_out["affine"]."""
     if x.is_cuda:
-        return hip_backend().conv_fprop(x, wA, bias, g, act, alpha, mul, stats_out, bn_infer)
+        return hip_backend().conv_fprop(x, wA, bias, g, act, alpha, mul, stats_out, bn_infer, in_affine=in_affine,
+                                        aff_sink=aff_sink)
+    if in_affine is not None:
+        raise ValueError("conv_fprop: in_affine exists on the device only")
     return _cpu_mul(cpu_ref.conv_fprop(x, wA, bias, g, act, alpha), mul)
 
 
-def conv_dgrad(dy, wB, g, bias=None, act=None, alpha=0.3, mul=None, stats_out=None, bn_infer=None, in_affine=None):
+def conv_dgrad(dy, wB, g, bias=None, act=None, alpha=0.3, mul=None, stats_out=None, bn_infer=None, in_affine=None,
+               aff_sink=None):
     """`wB` is the core weight in [I][KH][KW][O] order (reduction channel contiguous);
     depthwise: [KH][KW][C].  `in_affine`: device only (a BatchNorm applied on load, ops/hip.py)."""
     if dy.is_cuda:
-        return hip_backend().conv_dgrad(dy, wB, g, bias, act, alpha, mul, stats_out, bn_infer, in_affine=in_affine)
+        return hip_backend().conv_dgrad(dy, wB, g, bias, act, alpha, mul, stats_out, bn_infer, in_affine=in_affine,
+                                        aff_sink=aff_sink)
     if in_affine is not None:
         raise ValueError("conv_dgrad: in_affine exists on the device only")
     wA = wB if g.depthwise else wB.permute(3, 1, 2, 0)
     return _cpu_mul(cpu_ref.conv_dgrad(dy, wA, g, bias, act, alpha), mul)
 
 
-def conv_wgrad(x, dy, g, layout="A", out=None):
+def conv_wgrad(x, dy, g, layout="A", out=None, x_affine=None):
     """Weight gradient of the core correlation, written in layout A=[O][KH][KW][I] or
     B=[I][KH][KW][O] (depthwise: [KH][KW][C]), fp32.  `out` (a view into the flat gradient
     buffer) is overwritten."""
     if x.is_cuda:
-        return hip_backend().conv_wgrad(x, dy, g, layout, out)
+        return hip_backend().conv_wgrad(x, dy, g, layout, out, x_affine=x_affine)
+    if x_affine is not None:
+        raise ValueError("conv_wgrad: x_affine exists on the device only")
     dw = cpu_ref.conv_wgrad(x, dy, g)
     if layout == "B" and not g.depthwise:
         dw = dw.permute(3, 1, 2, 0)

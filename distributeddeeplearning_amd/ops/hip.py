@@ -96,7 +96,7 @@ _wgrad2_lds = _sig("ddl_wgrad2_lds", ci, ci, ci, ci, ci, ci, ci, ci, ci, ci)
 _slab_reduce = _sig("ddl_slab_reduce", None, vp, vp, cl, cl, ci, vp)
 _dw_blocks = _sig("ddl_dw_wgrad_blocks", ci, cl, ci)
 _depthwise = _sig("ddl_depthwise", ci, ci, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci,
-                  ci, ci, ci, ci, cf, vp)
+                  ci, ci, ci, ci, cf, vp, vp, ci, vp)
 
 IGEMM_TILE = int(os.environ.get("DDL_IGEMM_TILE", "0"))     # 0 = heuristic; tuning knob
 CONV_IMPL = os.environ.get("DDL_CONV", "pconv")             # pconv (patch-resident, default) | igemm
@@ -1173,13 +1173,16 @@ PCONV_STATS = os.environ.get("DDL_PCONV_STATS", "1") == "1"
 
 
 def _igemm_call(src, wgt, bias, dst, g, mode, B, Hs, Ws, Cs, Hd, Wd, Nd, Nw, ss, sd, act, alpha, mul=None,
-                stats_out=None, bn_infer=None, in_affine=None):
+                stats_out=None, bn_infer=None, in_affine=None, aff_sink=None):
     """Dispatch one class-grid convolution: the patch-resident kernel with a tuned plan, or the
     global-gather kernel.  The first (non-captured) call of each problem times the candidates on the
     real operands and caches the winner -- these shapes are static for a whole training run."""
     def materialise():                  # the global-gather kernel has no affine on load: apply the BatchNorm first
         sc_t, sh_t, (igr,), ict = in_affine
-        return bn_apply(src, sc_t, sh_t, None, 0.3, ict, B // igr)
+        m = bn_apply(src, sc_t, sh_t, None, 0.3, ict, B // igr)
+        if aff_sink is not None:        # the caller keeps it (weight gradient) instead of rebuilding it
+            aff_sink["x"] = m
+        return m
     args = (src, wgt, bias, dst, g)
     tail = (B, Hs, Ws, Cs, Hd, Wd, Nd, Nw, ss, sd, act, alpha)
     if CONV_IMPL != "pconv":
@@ -1284,11 +1287,19 @@ def _mul_slice(mul, b0, b1):
     return None if mul is None else (mul[0][b0:b1], mul[1], mul[2])
 
 
-def conv_fprop(x, wA, bias, g: ConvGeom, act=None, alpha=0.3, mul=None, stats_out=None, bn_infer=None, out=None):
+def conv_fprop(x, wA, bias, g: ConvGeom, act=None, alpha=0.3, mul=None, stats_out=None, bn_infer=None, out=None,
+               in_affine=None, aff_sink=None):
     """`mul` = (y, act, alpha): multiply the (bf16) result by act'(y) -- the activation backward of the layer
     below, fused into the epilogue when this runs as a transposed conv's input gradient.
-    `out`: write into this contiguous [B, OH, OW, Op] tensor (a batch slice of a larger one)."""
+    `out`: write into this contiguous [B, OH, OW, Op] tensor (a batch slice of a larger one).
+    `in_affine` = (scale, shift, groups, c_true): x is read as bf16(x * scale + shift) -- a BatchNorm in front of
+    the layer applied on load by the depthwise stencil (one statistics group; everything else gets it materialised)."""
     _chk_act(x, "x")
+    if in_affine is not None and not (g.depthwise and in_affine[2] == 1):
+        x = bn_apply(x, in_affine[0], in_affine[1], None, 0.3, in_affine[3], in_affine[2])
+        in_affine = None
+        if aff_sink is not None:        # materialised: the caller keeps it for the weight gradient
+            aff_sink["x"] = x
     B = x.shape[0]
     Ip, Op = pad8(g.I), pad8(g.O)
     if tuple(x.shape[1:]) != (g.H, g.W, Ip):
@@ -1303,12 +1314,26 @@ def conv_fprop(x, wA, bias, g: ConvGeom, act=None, alpha=0.3, mul=None, stats_ou
     ranges = _batch_ranges(B, max(g.H * g.W * Ip, g.OH * g.OW * Op))
     if ranges is not None:
         for b0, b1 in ranges:           # no BN statistics / folded BN across slices: the caller runs its own pass
-            conv_fprop(x[b0:b1], wA, bias, g, act, alpha, _mul_slice(mul, b0, b1), None, None, y[b0:b1])
+            conv_fprop(x[b0:b1], wA, bias, g, act, alpha, _mul_slice(mul, b0, b1), None, None, y[b0:b1], in_affine)
         return y
     if g.depthwise:
         _chk_w(wA, (g.KH, g.KW, Ip), "depthwise kernel")
+        isc = ish = None
+        ict = 0
+        if in_affine is not None:
+            _chk_f32(in_affine[0], Ip, "in_affine scale")
+            _chk_f32(in_affine[1], Ip, "in_affine shift")
+            isc, ish, ict = in_affine[0].data_ptr(), in_affine[1].data_ptr(), int(in_affine[3])
         rc = _depthwise(0, x.data_ptr(), wA.data_ptr(), _p(bias), y.data_ptr(), None, B, g.H, g.W, Ip, g.OH, g.OW,
-                        g.KH, g.KW, g.sh, g.sw, g.dh, g.dw, g.pt, g.pl, g.O, ACT_CODE[act], alpha, _stream())
+                        g.KH, g.KW, g.sh, g.sw, g.dh, g.dw, g.pt, g.pl, g.O, ACT_CODE[act], alpha, isc, ish, ict,
+                        _stream())
+        if rc == -5:                    # outside the fast stencil's range: materialise the BatchNorm output after all
+            xm = bn_apply(x, in_affine[0], in_affine[1], None, 0.3, in_affine[3], 1)
+            if aff_sink is not None:
+                aff_sink["x"] = xm
+            rc = _depthwise(0, xm.data_ptr(), wA.data_ptr(), _p(bias), y.data_ptr(), None, B, g.H, g.W, Ip, g.OH,
+                            g.OW, g.KH, g.KW, g.sh, g.sw, g.dh, g.dw, g.pt, g.pl, g.O, ACT_CODE[act], alpha, None,
+                            None, 0, _stream())
         if rc:
             raise ValueError("depthwise fprop rejected")
         _mul_inplace(y, mul)
@@ -1332,7 +1357,7 @@ def conv_fprop(x, wA, bias, g: ConvGeom, act=None, alpha=0.3, mul=None, stats_ou
 
 
 def conv_dgrad(dy, wB, g: ConvGeom, bias=None, act=None, alpha=0.3, mul=None, stats_out=None, bn_infer=None,
-               out=None, in_affine=None):
+               out=None, in_affine=None, aff_sink=None):
     """`in_affine` = (scale, shift, groups, c_true): dy is read as bf16(dy * scale[grp] + shift[grp]) -- a BatchNorm
     in front of a transposed convolution (which runs as this dgrad) applied on load by the patch-resident kernel
     ([groups][Op] fp32 rows, the batch being `groups` equal parts; other kernels get it materialised first)."""
@@ -1356,6 +1381,8 @@ def conv_dgrad(dy, wB, g: ConvGeom, bias=None, act=None, alpha=0.3, mul=None, st
         if g.depthwise or (_is_1x1(g) and GEMM_SK) or ranges0 is not None:
             dy = bn_apply(dy, sc_t, sh_t, None, 0.3, ictrue, groups)        # no on-load path there
             in_affine = None
+            if aff_sink is not None:    # `aff_sink["x"]`: the materialised operand, kept by the caller
+                aff_sink["x"] = dy
         else:
             in_affine = (sc_t, sh_t, (B // groups,), ictrue)
     ranges = _batch_ranges(B, max(g.H * g.W * Ip, g.OH * g.OW * Op))
@@ -1368,7 +1395,7 @@ def conv_dgrad(dy, wB, g: ConvGeom, bias=None, act=None, alpha=0.3, mul=None, st
         if bias is not None or act not in (None, "linear"):
             raise ValueError("depthwise dgrad has no fused epilogue")
         rc = _depthwise(1, dy.data_ptr(), wB.data_ptr(), None, dx.data_ptr(), None, B, g.H, g.W, Ip, g.OH, g.OW,
-                        g.KH, g.KW, g.sh, g.sw, g.dh, g.dw, g.pt, g.pl, g.O, 0, 0.0, _stream())
+                        g.KH, g.KW, g.sh, g.sw, g.dh, g.dw, g.pt, g.pl, g.O, 0, 0.0, None, None, 0, _stream())
         if rc:
             raise ValueError("depthwise dgrad rejected")
         _mul_inplace(dx, mul)
@@ -1387,7 +1414,7 @@ def conv_dgrad(dy, wB, g: ConvGeom, bias=None, act=None, alpha=0.3, mul=None, st
             _done()
             return dx
     _igemm_call(dy, wB, bias, dx, g, "dgrad", B, g.OH, g.OW, Op, g.H, g.W, Ip, min(wB.shape[0], g.I),
-                (1, 1), (g.sh, g.sw), act, alpha, mul, stats_out, bn_infer, in_affine)
+                (1, 1), (g.sh, g.sw), act, alpha, mul, stats_out, bn_infer, in_affine, aff_sink)
     return dx
 
 
@@ -1545,15 +1572,25 @@ def conv_wgrad(x, dy, g: ConvGeom, layout="A", out=None, box=None, x_affine=None
     dev = x.device
     T = g.KH * g.KW
     if g.depthwise:
-        if x_affine is not None:
-            raise ValueError("conv_wgrad: x_affine is not available for depthwise layers")
         if out is None:
             out = torch.empty(g.KH, g.KW, Ip, dtype=torch.float32, device=dev)
         _chk_f32(out, T * Ip, "dW")
         nb = _dw_blocks(B * g.OH * g.OW, Ip)
         part = torch.empty(nb * T * Ip, dtype=torch.float32, device=dev)
+        xs = xh = None
+        xct = 0
+        if x_affine is not None:
+            _chk_f32(x_affine[0], Ip, "x_affine scale")
+            _chk_f32(x_affine[1], Ip, "x_affine shift")
+            xs, xh, xct = x_affine[0].data_ptr(), x_affine[1].data_ptr(), int(x_affine[2])
         rc = _depthwise(2, dy.data_ptr(), x.data_ptr(), None, out.data_ptr(), part.data_ptr(), B, g.H, g.W, Ip,
-                        g.OH, g.OW, g.KH, g.KW, g.sh, g.sw, g.dh, g.dw, g.pt, g.pl, g.O, 0, 0.0, _stream())
+                        g.OH, g.OW, g.KH, g.KW, g.sh, g.sw, g.dh, g.dw, g.pt, g.pl, g.O, 0, 0.0, xs, xh, xct,
+                        _stream())
+        if rc == -5:                    # generic stencil: no on-load affine
+            xm = bn_apply(x, x_affine[0], x_affine[1], None, 0.3, x_affine[2], 1)
+            rc = _depthwise(2, dy.data_ptr(), xm.data_ptr(), None, out.data_ptr(), part.data_ptr(), B, g.H, g.W, Ip,
+                            g.OH, g.OW, g.KH, g.KW, g.sh, g.sw, g.dh, g.dw, g.pt, g.pl, g.O, 0, 0.0, None, None, 0,
+                            _stream())
         if rc:
             raise ValueError("depthwise wgrad rejected")
         _done()
@@ -1578,7 +1615,7 @@ def conv_wgrad(x, dy, g: ConvGeom, layout="A", out=None, box=None, x_affine=None
     xs = xh = None
     xct = Ip
     if x_affine is not None:
-        if g.depthwise or plans:
+        if plans:
             raise ValueError("conv_wgrad: x_affine is only available on the streaming weight-gradient kernel")
         _chk_f32(x_affine[0], Ip, "x_affine scale")
         _chk_f32(x_affine[1], Ip, "x_affine shift")

@@ -152,6 +152,35 @@ def test_depthwise(hip, case):
     close(dw[..., :Cc], cpu_ref.conv_wgrad(x, dy, g), rtol=1e-2)
 
 
+@pytest.mark.parametrize("case", [(57, 57, 128, (3, 3), (2, 2), "valid"), (28, 28, 24, (3, 3), (1, 1), "valid"),
+                                  (10, 10, 128, (2, 2), (3, 3), "valid"), (13, 13, 40, (3, 3), (1, 1), "same"),
+                                  (9, 11, 8, (1, 1), (2, 2), "valid"), (12, 12, 20, (3, 3), (2, 2), "same")])
+def test_depthwise_input_affine(hip, case):
+    """A per-channel affine (a BatchNorm) in front of a depthwise layer, applied by the stencil kernels to their tap
+    sums: forward and weight gradient equal the layer run on the fp32 affine output, zero padding applied AFTER the
+    affine (padded cases run the per-pixel live-tap variant, channel counts that do not divide 256 the generic grid)."""
+    H, W, Cc, k, s, pad = case
+    g = G.depthwise_geom(H, W, Cc, k, s, (1, 1), pad)
+    B = 3 if H > 30 else 21
+    torch.manual_seed(7)
+    x = r16(torch.randn(B, H, W, Cc))
+    w = r16(torch.randn(k[0], k[1], Cc))
+    b = torch.randn(Cc)
+    sc, sh = torch.rand(Cc) + 0.5, torch.randn(Cc)
+    xa = x * sc + sh                                            # fp32, not rounded: what the kernels emulate
+    Cp = hip.pad8(Cc)
+    scp, shp = torch.zeros(Cp), torch.zeros(Cp)
+    scp[:Cc], shp[:Cc] = sc, sh
+    aff = (scp.cuda(), shp.cuda(), 1, Cc)
+    y = hip.conv_fprop(dev(hip, x), padw(hip, w), b.cuda(), g, "tanh", in_affine=aff)
+    close(host(hip, y, Cc), cpu_ref.conv_fprop(xa, w, b, g, "tanh"))
+    dy = r16(torch.randn(B, g.OH, g.OW, Cc))
+    dw = hip.conv_wgrad(dev(hip, x), dev(hip, dy), g, x_affine=(aff[0], aff[1], Cc)).cpu()
+    close(dw[..., :Cc], cpu_ref.conv_wgrad(xa, dy, g), rtol=1e-2)
+    if Cp != Cc:
+        assert float(dw[..., Cc:].abs().max()) == 0.0
+
+
 @pytest.mark.parametrize("case", [(14, 14, 64, 128, 5, 2), (9, 11, 24, 40, 3, 1)])
 @pytest.mark.parametrize("layout", ["A", "B"])
 def test_wgrad2_slab_orders_agree(hip, case, layout, monkeypatch):

@@ -201,3 +201,38 @@ def test_fused_head_batchnorm_matches_unfused_trainer(policy, monkeypatch):
     assert torch.equal(a[4], b[4])                                  # moving statistics
     for ga, gb in ((a[2], b[2]), (a[3], b[3])):
         assert float((ga - gb).norm() / gb.norm()) < 1e-2
+
+
+@pytest.mark.parametrize("i", [0, 1, 2, 4])
+def test_bn_on_load_matches_materialised_depthwise(i):
+    """A BatchNorm in front of a depthwise layer is applied by the stencil kernels (forward and weight gradient) to
+    their per-channel tap sums instead of writing its output.  The on-load path keeps the BatchNorm output in fp32
+    where the materialised path rounds it to bf16: outputs, gradients and moving statistics agree to that rounding.
+    Reference replicas model0/1/2/4 hold such pairs (/root/reference/DDL_Normal4.py random_layer: BatchNormalization
+    after every layer)."""
+    import os
+    from distributeddeeplearning_amd.models import network as N
+    from distributeddeeplearning_amd.utils import ckpt
+    ref = os.path.join(os.path.dirname(os.path.abspath(__file__)), "fixtures", "reference_models", f"model{i}")
+    if not os.path.isdir(ref):
+        pytest.skip("reference checkpoints not present on this box")
+    net = ckpt.load_model(ref, "cuda")
+    assert any(isinstance(op, N.BNOp) and op.defer_to is not None and op.defer_to.g.depthwise for op in net.ops)
+    torch.manual_seed(20 + i)
+    x = net.prepare_input(torch.randint(0, 256, (24, 28, 28, 1), dtype=torch.uint8).cuda())
+    s0 = net.S.clone()
+    res = {}
+    for on_load in (True, False):
+        N.BN_ON_LOAD = on_load
+        try:
+            net.S.copy_(s0)
+            y = net.forward(x, training=True)
+            net.G.zero_()
+            net.backward(torch.full_like(y, 0.01), need_input_grad=False)
+            torch.cuda.synchronize()
+            res[on_load] = (y.clone(), net.G.clone(), net.S.clone())
+        finally:
+            N.BN_ON_LOAD = True
+    errs = [float((a.float() - b.float()).norm() / (b.float().norm() + 1e-6)) for a, b in zip(res[True], res[False])]
+    print("ONLOAD_ERRS", i, errs)
+    assert all(e < tol for e, tol in zip(errs, (3e-2, 6e-2, 1e-2))), errs
