@@ -130,7 +130,10 @@ class EnsembleBench:
         self.chunk = getattr(self.members[0], "_chunk_S", 0) if use_graph else 0
         self.steps_per_call = self.chunk if self.chunk else 1
         on_gpu = self.device.type == "cuda"
-        self.streams = [torch.cuda.Stream() for _ in self.members] if (on_gpu and not self.serial) else None
+        self.streams = None
+        if on_gpu and not self.serial:  # K streams (hardware queues), members placed longest-first (models/classifier.py)
+            from .models.classifier import member_streams
+            self.streams, self.stream_pool = member_streams(self.members, self.device)
         g = torch.Generator().manual_seed(7 + self.rank)
         self.idx = [torch.randint(0, n_pool, (self.steps_per_call, self.batch), generator=g).to(self.device)
                     for _ in range(4)]
@@ -155,11 +158,12 @@ class EnsembleBench:
                 self._one(m, idx)
             return
         main = torch.cuda.current_stream()
-        for m, st in zip(self.members, self.streams):
+        for st in self.stream_pool:
             st.wait_stream(main)
+        for m, st in zip(self.members, self.streams):
             with torch.cuda.stream(st):
                 self._one(m, idx)
-        for st in self.streams:              # the step ends when every member's chunk has: bench timing stays honest
+        for st in self.stream_pool:          # the step ends when every member's chunk has: bench timing stays honest
             main.wait_stream(st)
 
     def describe(self):
@@ -168,7 +172,8 @@ class EnsembleBench:
                "optimizer_steps_per_member_per_bench_step": self.steps_per_call,
                "member_params": self.params,
                "step": "fwd + softmax-CE + bwd + optimizer, every member, "
-                       + ("members one after another" if self.streams is None else "members concurrent on their own streams"),
+                       + ("members one after another" if self.streams is None else
+                          f"members concurrent on {len(self.stream_pool)} streams, placed longest-first by measured step time"),
                "graph": self.args.graph}
         return {"metric": "ensemble32_train_images_per_sec",
                 "images_per_step_per_rank": self.batch * self.steps_per_call * self.n_members,

@@ -19,6 +19,7 @@ from __future__ import annotations
 
 import math
 import os
+import time
 from typing import Dict, List, Optional, Tuple
 
 import torch
@@ -193,6 +194,12 @@ class RandomModel:
             hipgraph.quiesce()
             self._chunk_graph, _ = hipgraph.capture(body, torch.cuda.graph_pool_handle())
             self._chunk_S = S
+            # one timed replay (state is restored below): the scheduler balances concurrent members by it
+            torch.cuda.current_stream().synchronize()
+            t0 = time.perf_counter()
+            self._chunk_graph.replay()
+            torch.cuda.current_stream().synchronize()
+            self.chunk_ms = (time.perf_counter() - t0) * 1e3
         net.P.copy_(keep[0])
         net.S.copy_(keep[1])
         for t, k in ((opt.m, keep[2]), (opt.v, keep[3])):
@@ -417,6 +424,35 @@ class ReplicaGroupStep:
         return self.losses[-1]
 
 
+ENS_STREAMS = int(os.environ.get("DDL_ENS_STREAMS", "4"))     # streams for concurrent members (0 = one per member)
+
+
+def member_streams(models: List[RandomModel], device, k: int = None):
+    """HIP streams for members trained side by side on one GPU: (per-member stream list, distinct streams).
+
+    One stream per member looks natural, but the runtime folds the streams onto its four hardware queues in
+    creation order, so with ten members of very different cost one queue ends up with the three slowest and the
+    generation waits for it.  Instead: `k` streams (default 4, one per hardware queue), members placed longest-first
+    on the least-loaded stream by the measured time of one replay of their step graph (`RandomModel.prepare`;
+    parameter counts where a member has no multi-step graph).  Measured on MI355X
+    (`bench.py --config ensemble32`, 10 members): ddl_ray 472k -> 785k img/s, ddl_normal3 242k -> 328k, ddl 74k -> 87k."""
+    k = ENS_STREAMS if k is None else k
+    if k <= 0 or k >= len(models):
+        streams = [torch.cuda.Stream(device=device) for _ in models]
+        return streams, streams
+    cost = [getattr(m, "chunk_ms", None) for m in models]       # measured by RandomModel.prepare
+    if any(c is None for c in cost):
+        cost = [float(m.net.num_params(True)) for m in models]
+    pool = [torch.cuda.Stream(device=device) for _ in range(k)]
+    load = [0.0] * k
+    assign = [None] * len(models)
+    for i in sorted(range(len(models)), key=lambda i: -cost[i]):
+        q = min(range(k), key=lambda j: load[j])
+        assign[i] = pool[q]
+        load[q] += cost[i]
+    return assign, pool
+
+
 def train_concurrently(models: List[RandomModel], verbose: bool = False) -> None:
     """Train several ensemble members of ONE GPU at the same time (the reference trains its members one after
     another in a single process, /root/reference/DDL.py:142-144, or one per Ray actor).
@@ -453,7 +489,9 @@ def train_concurrently(models: List[RandomModel], verbose: bool = False) -> None
         return
     gens = [m._train_gen() for m in rest] + ([mlp_fast.train_group_gen(group, verbose)] if group else [])
     names = [f"member {m.number}" for m in rest] + ([f"MLP group of {len(group)}"] if group else [])
-    streams = [torch.cuda.Stream(device=models[0].device) for _ in gens]
+    streams, _ = member_streams(rest, models[0].device)
+    if group:                           # the MLP group's one persistent launch per epoch: a stream of its own
+        streams = list(streams) + [torch.cuda.Stream(device=models[0].device)]
     waiting = [None] * len(gens)
     active = list(range(len(gens)))
     while active:
