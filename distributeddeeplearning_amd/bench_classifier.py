@@ -65,12 +65,42 @@ class ClassifierBench:
         if self.dp is not None and not self.local_sgd:
             mode = "eager" if not use_graph else ("full" if self.args.graph == "full" else "segments")
             self.group = ReplicaGroupStep(self.members, self.dp, self.idx[0], mode)
+        # one GPU, no collectives: the five replicas are independent -- their step graphs go to separate streams,
+        # placed longest-first (models/classifier.py member_streams), so one replica's latency-bound tail layers run
+        # beside another's bandwidth-bound front layers
+        self.streams = None
+        import os
+        if (self.dp is None and use_graph and self.device.type == "cuda"
+                and os.environ.get("DDL_CLS_CONCURRENT", "1") == "1"):
+            from .models.classifier import member_streams
+            for m in self.members:
+                for _ in range(3):
+                    m.train_step(self.idx[0])           # warm-up + capture
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(3):
+                    m.train_step(self.idx[0])
+                torch.cuda.synchronize()
+                m.chunk_ms = (time.perf_counter() - t0) * 1e3 / 3
+            k = int(os.environ.get("DDL_CLS_STREAMS", "4"))
+            self.streams, self.stream_pool = member_streams(self.members, self.device, k)
+            self.replica_ms = [round(m.chunk_ms, 3) for m in self.members]
 
     def step(self):
         idx = self.idx[self.t % len(self.idx)]
         self.t += 1
         if self.group is not None:
             self.loss = self.group.step(idx)
+            return self.loss
+        if self.streams is not None:
+            main = torch.cuda.current_stream()
+            for st in self.stream_pool:
+                st.wait_stream(main)
+            for m, st in zip(self.members, self.streams):
+                with torch.cuda.stream(st):
+                    self.loss = m.train_step(idx)
+            for st in self.stream_pool:
+                main.wait_stream(st)
             return self.loss
         for m in self.members:
             self.loss = m.train_step(idx)
