@@ -309,8 +309,18 @@ DDL_API int ddl_colreduce_blocks(long rows, int C) {
 }
 
 // BN forward statistics -> per-channel affine (scale, shift), saved (mean, invstd), moving update.
-__device__ __forceinline__ void bn_stats_emit(int c, double s0, double s1, long rows, const float* __restrict__ gamma,
-                                              const float* __restrict__ beta, float* __restrict__ mm,
+// The channel's parameters are loaded by the caller BEFORE it walks the partials (BnChanParams): these kernels are a
+// chain of dependent round trips, and the parameter fetch used to be one more at the very end.
+struct BnChanParams { float gamma, beta, mm, mv; };
+__device__ __forceinline__ BnChanParams bn_chan_params(int c, int C, const float* __restrict__ gamma,
+                                                       const float* __restrict__ beta, const float* __restrict__ mm,
+                                                       const float* __restrict__ mv) {
+    BnChanParams p{0.f, 0.f, 0.f, 0.f};
+    if (c < C) { p.gamma = gamma[c]; p.beta = beta[c]; p.mm = mm[c]; p.mv = mv[c]; }
+    return p;
+}
+__device__ __forceinline__ void bn_stats_emit(int c, double s0, double s1, long rows, BnChanParams& pr,
+                                              float* __restrict__ mm,
                                               float* __restrict__ mv, float momentum, float eps, int bessel,
                                               int update_moving, float* __restrict__ scale, float* __restrict__ shift,
                                               float* __restrict__ mean_out, float* __restrict__ invstd_out) {
@@ -318,15 +328,17 @@ __device__ __forceinline__ void bn_stats_emit(int c, double s0, double s1, long 
     double var = s1 / (double)rows - mean * mean;
     if (var < 0) var = 0;
     float is = rsqrtf((float)var + eps);
-    float sc = gamma[c] * is;
+    float sc = pr.gamma * is;
     scale[c] = sc;
-    shift[c] = beta[c] - (float)mean * sc;
+    shift[c] = pr.beta - (float)mean * sc;
     mean_out[c] = (float)mean;
     invstd_out[c] = is;
     if (update_moving) {
         double v = bessel && rows > 1 ? var * ((double)rows / (double)(rows - 1)) : var;
-        mm[c] = mm[c] * momentum + (float)mean * (1.f - momentum);
-        mv[c] = mv[c] * momentum + (float)v * (1.f - momentum);
+        pr.mm = pr.mm * momentum + (float)mean * (1.f - momentum);      // (groups: one update per group, in order)
+        pr.mv = pr.mv * momentum + (float)v * (1.f - momentum);
+        mm[c] = pr.mm;
+        mv[c] = pr.mv;
     }
 }
 
@@ -339,11 +351,12 @@ __global__ void bn_stats_finalize_kernel(const float* __restrict__ part, int nbl
     // `nblocks` partials and `rows` rows PER batch group; outputs are [groups][C]; the moving statistics take one
     // momentum update per group, in group order (as calling the layer once per half would)
     int c = FIN_CHANNEL();
+    BnChanParams pr = bn_chan_params(c, C, gamma, beta, mm, mv);
     for (int z = 0; z < groups; ++z) {
         double s0, s1;
         reduce_partials(part, nblocks, C, c, true, s0, s1, nblocks * groups, z * nblocks);
         if (c < C && FIN_LEADER())
-            bn_stats_emit(c, s0, s1, rows, gamma, beta, mm, mv, momentum, eps, bessel, update_moving, scale + z * C,
+            bn_stats_emit(c, s0, s1, rows, pr, mm, mv, momentum, eps, bessel, update_moving, scale + z * C,
                           shift + z * C, mean_out + z * C, invstd_out + z * C);
     }
 }
@@ -358,6 +371,7 @@ __global__ __launch_bounds__(256) void bn_stats_finalize_wide_kernel(
     __shared__ double red[2][4];
     const int c = blockIdx.x;
     const size_t nbt = (size_t)nblocks * groups;
+    BnChanParams pr = bn_chan_params(c, C, gamma, beta, mm, mv);
     for (int z = 0; z < groups; ++z) {
         const float* p0 = part + (size_t)c * nbt + (size_t)z * nblocks;
         const float* p1 = part + ((size_t)C + c) * nbt + (size_t)z * nblocks;
@@ -379,7 +393,7 @@ __global__ __launch_bounds__(256) void bn_stats_finalize_wide_kernel(
         if (threadIdx.x == 0) {
             const double s0 = ((red[0][0] + red[0][1]) + red[0][2]) + red[0][3];
             const double s1 = ((red[1][0] + red[1][1]) + red[1][2]) + red[1][3];
-            bn_stats_emit(c, s0, s1, rows, gamma, beta, mm, mv, momentum, eps, bessel, update_moving, scale + z * C,
+            bn_stats_emit(c, s0, s1, rows, pr, mm, mv, momentum, eps, bessel, update_moving, scale + z * C,
                           shift + z * C, mean_out + z * C, invstd_out + z * C);
         }
     }
@@ -547,8 +561,8 @@ struct BnBwdAcc { double dbeta = 0, dgamma = 0, dbias = 0; };
 template <int NS>
 __device__ __forceinline__ void bn_bwd_group(int c, int z, int C, const double (&o)[NS], long rows, int train_stats,
                                              float* __restrict__ c1, float* __restrict__ c2,
-                                             const float* __restrict__ mean, const float* __restrict__ invstd,
-                                             const float* __restrict__ gamma, int c_bias, BnBwdAcc<NS>& acc) {
+                                             float mean_zc, float invstd_zc, float gamma_c, int c_bias,
+                                             BnBwdAcc<NS>& acc) {
     acc.dbeta += o[0];
     acc.dgamma += o[1];
     const float f1 = train_stats ? (float)(o[0] / (double)rows) : 0.f;
@@ -557,9 +571,10 @@ __device__ __forceinline__ void bn_bwd_group(int c, int z, int C, const double (
     c2[z * C + c] = f2;
     if (NS == 5 && c < c_bias) {
         // same k0/k1/k2 as bn_bwd_apply (fp32 there); combined in fp64 here
-        const double is = invstd[z * C + c], gi = (double)gamma[c] * is;
+        // (mean / invstd / gamma were fetched by the caller before it walked the partials)
+        const double is = invstd_zc, gi = (double)gamma_c * is;
         const double k0 = gi, k1 = -gi * is * (double)f2,
-                     k2 = -gi * ((double)f1 - (double)mean[z * C + c] * is * (double)f2);
+                     k2 = -gi * ((double)f1 - (double)mean_zc * is * (double)f2);
         acc.dbias += k0 * o[NS - 3] + k1 * o[NS - 2] + k2 * o[NS - 1];
     }
 }
@@ -581,11 +596,14 @@ __global__ void bn_bwd_finalize_kernel(const float* __restrict__ part, int nbloc
                                        int groups) {
     int c = FIN_CHANNEL();
     BnBwdAcc<NS> acc;
+    const bool kb = NS == 5 && c < c_bias && c < C;
+    const float gamma_c = kb ? gamma[c] : 0.f;
     for (int z = 0; z < groups; ++z) {
+        const float mean_zc = kb ? mean[z * C + c] : 0.f, invstd_zc = kb ? invstd[z * C + c] : 0.f;
         double o[NS];
         reduce_partials_n<NS, NS>(part, nblocks, C, c, o, nblocks * groups, z * nblocks);
         if (c < C && FIN_LEADER())
-            bn_bwd_group<NS>(c, z, C, o, rows, train_stats, c1, c2, mean, invstd, gamma, c_bias, acc);
+            bn_bwd_group<NS>(c, z, C, o, rows, train_stats, c1, c2, mean_zc, invstd_zc, gamma_c, c_bias, acc);
     }
     if (c >= C || !FIN_LEADER()) return;
     bn_bwd_store<NS>(c, acc, dgamma, dbeta, dbias, c_bias);
@@ -603,7 +621,10 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_wide_kernel(
     const int c = blockIdx.x;
     const size_t nbt = (size_t)nblocks * groups;
     BnBwdAcc<NS> total;
+    const bool kb = NS == 5 && c < c_bias;
+    const float gamma_c = kb ? gamma[c] : 0.f;
     for (int z = 0; z < groups; ++z) {
+        const float mean_zc = kb ? mean[z * C + c] : 0.f, invstd_zc = kb ? invstd[z * C + c] : 0.f;
         const float* pz = part + (size_t)z * nblocks;
         double acc[NS];
 #pragma unroll
@@ -639,7 +660,7 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_wide_kernel(
             double o[NS];
 #pragma unroll
             for (int k = 0; k < NS; ++k) o[k] = ((red[k][0] + red[k][1]) + red[k][2]) + red[k][3];
-            bn_bwd_group<NS>(c, z, C, o, rows, train_stats, c1, c2, mean, invstd, gamma, c_bias, total);
+            bn_bwd_group<NS>(c, z, C, o, rows, train_stats, c1, c2, mean_zc, invstd_zc, gamma_c, c_bias, total);
         }
     }
     if (threadIdx.x == 0) bn_bwd_store<NS>(c, total, dgamma, dbeta, dbias, c_bias);
