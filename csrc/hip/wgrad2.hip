@@ -7,7 +7,7 @@
 // bounds it.  Here a block is a persistent worker over a range of *units* (IMG images or a row band
 // of one image).  Per unit it stages the dY tile and the X patch (zero halo) into LDS once; then
 // EVERY tap is computed out of LDS: wave w owns taps {gw, gw + G, ...} (gw = global wave index among
-// the G = 4 x tap-groups waves that share this unit), keeps their [TN x TC] accumulators in registers
+// the G = NW x tap-groups waves that share this unit; NW = 4 or 8 waves per block), keeps their [TN x TC] accumulators in registers
 // for its whole life, and walks all 32-pixel slices of the unit -- the dY fragments of a slice are
 // read once and reused for all of the wave's taps.  Both operands are pixel-major (k-strided for an
 // MFMA fragment); ds_read_b64_tr_b16 transposes them on the LDS read, each lane pointing at its own
