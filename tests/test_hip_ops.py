@@ -724,6 +724,7 @@ def test_autotune_choices_export_import_and_persist(hip, tmp_path, monkeypatch):
     w = padw(hip, r16(torch.randn(64, 5, 5, 32) * 0.05))
     dy = dev(hip, r16(torch.randn(40, 7, 7, 64)))
     monkeypatch.setenv("DDL_AUTOTUNE_CACHE", str(tmp_path / "tune.json"))
+    monkeypatch.setattr(hip, "AUTOTUNE", True)          # (the suite also runs with DDL_AUTOTUNE=0)
     y0 = hip.conv_fprop(x, w, None, g)
     dw0 = hip.conv_wgrad(x, dy, g, "A")
     table = hip.export_choices()
