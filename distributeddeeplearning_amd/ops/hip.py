@@ -923,6 +923,8 @@ def _pconv_plan(g: ConvGeom, mode: str, B: int, Cs: int, Nd: int, ss, device, bu
             FR = fr or PCONV_FR or (8 if (BN <= 32 and rows_unit >= 320) else 4)
             if BN == 128:
                 FR = 4
+            elif not (fr or PCONV_FR) and 32 <= Nd <= 64 and rows_unit <= 128:
+                FR = 2                  # a 256-row pass over <= 128 rows wastes half the MFMAs (what the autotuner picks)
             ktab = np.zeros((total_stages * 8, 2), dtype=np.int32)
             cdesc = np.zeros(len(classes), dtype=[("ph", "<i4"), ("pw", "<i4"), ("Hc", "<i4"), ("Wc", "<i4"),
                                                   ("nst", "<i4"), ("soff", "<i4"), ("invWc", "<f4"), ("pad", "<f4")])
@@ -1497,7 +1499,11 @@ def _wgrad2_plans(g: ConvGeom, B: int, Cx: int, Ny: int, n_lim: int, c_lim: int)
         opts = _W2_COMBOS[(tn, tc)]
         ngroups = -(-T // (4 * max(opts)))
         need = -(-T // (4 * ngroups))
-        first = _wgrad2_one_plan(g, B, Cx, Ny, n_lim, c_lim, tn, tc, min(o for o in opts if o >= need))
+        first = None
+        if W2_NW8 and (tn, tc) in _W2_COMBOS8:      # the autotuner's usual winner first: it is the untuned default
+            first = _wgrad2_one_plan(g, B, Cx, Ny, n_lim, c_lim, tn, tc, _W2_COMBOS8[(tn, tc)], 150, NW=8)
+        if first is None:
+            first = _wgrad2_one_plan(g, B, Cx, Ny, n_lim, c_lim, tn, tc, min(o for o in opts if o >= need))
         if first is not None:
             plans.append(first)
         tiles = {(tn, tc)}
@@ -1507,7 +1513,7 @@ def _wgrad2_plans(g: ConvGeom, B: int, Cx: int, Ny: int, n_lim: int, c_lim: int)
             tiles.add((32, 32))
         elif tn == 32 and tc == 64:
             tiles.add((32, 32))
-        seen = {tuple(sorted(first.items()))} if first else set()
+        seen = {tuple(sorted((k, v) for k, v in first.items() if k != "budget"))} if first else set()
         for (a_, b_) in sorted(tiles):
             for tpw in _W2_COMBOS[(a_, b_)]:
                 for kb in (150, 76, 50, 36):
