@@ -495,31 +495,36 @@ __device__ __forceinline__ void dw_load_affine(const DwArgs& a, int gch, float (
     }
 }
 
-// AFF: 0 = plain x; 1 = affine, every tap inside the image and the grid stride a multiple of the channel groups (a
-// lane keeps ONE channel group: scale and shift * sum_t w_t are computed once, in front of the loop); 2 = affine with
-// per-pixel live-tap sums (padded layers).  Separate instantiations: the plain path keeps its 84 registers.
+// AFF: 0 = plain x; 1 = affine, every tap inside the image (scale and shift * sum_t w_t of each channel group are
+// computed once per block, in front of the loop); 2 = affine with per-pixel live-tap sums (padded layers, > 512
+// channels).  Separate instantiations: the plain path keeps its 84 registers.
 template <int K, int AFF>
-__global__ __launch_bounds__(256) void dw_fprop_fast_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ w,
+__global__ __launch_bounds__(256, (AFF == 1 && K == 3) ? 5 : 1) void dw_fprop_fast_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ w,
                                                             const float* __restrict__ bias, bf16_t* __restrict__ y,
                                                             const DwArgs a) {
     const int cg = a.C / 8;
     float sc[8], sf[8];
+    // AFF 1: (scale, shift * sum_t w_t) of every channel group in an LDS table, read back at the end of a trip -- held
+    // in registers across the loop they cost one wave of occupancy (101 vs 84 registers)
+    __shared__ __attribute__((aligned(16))) float saff[AFF == 1 ? 64 * 16 : 4];
     if (AFF == 1) {
-        const unsigned i0 = blockIdx.x * 256u + threadIdx.x;
-        const int gch0 = (int)(i0 - fdivu(i0, a.dcg) * cg);
-        float ws[8];
-        dw_load_affine(a, gch0, sc, sf);
+        if ((int)threadIdx.x < cg) {
+            const int g0 = threadIdx.x;
+            float ws[8];
+            dw_load_affine(a, g0, sc, sf);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) ws[j] = 0.f;
+            for (int j = 0; j < 8; ++j) ws[j] = 0.f;
 #pragma unroll
-        for (int t = 0; t < K * K; ++t) {
-            float wf[8];
-            unpack8(*(const uint4*)(w + t * a.C + gch0 * 8), wf);
+            for (int t = 0; t < K * K; ++t) {
+                float wf[8];
+                unpack8(*(const uint4*)(w + t * a.C + g0 * 8), wf);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) ws[j] += wf[j];
+                for (int j = 0; j < 8; ++j) ws[j] += wf[j];
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { saff[g0 * 16 + j] = sc[j]; saff[g0 * 16 + 8 + j] = sf[j] * ws[j]; }
         }
-#pragma unroll
-        for (int j = 0; j < 8; ++j) sf[j] *= ws[j];
+        __syncthreads();
     }
     for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < a.total; i += gridDim.x * 256u) {
         const unsigned p = fdivu(i, a.dcg);
@@ -564,8 +569,12 @@ __global__ __launch_bounds__(256) void dw_fprop_fast_kernel(const bf16_t* __rest
             }
         }
         if (AFF == 1) {
+            const float4* r = (const float4*)&saff[gch * 16];
+            const float4 s0 = r[0], s1 = r[1], h0 = r[2], h1 = r[3];
+            const float sv[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
+            const float hv[8] = {h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w};
 #pragma unroll
-            for (int j = 0; j < 8; ++j) acc[j] = fmaf(sc[j], acc[j], sf[j]);
+            for (int j = 0; j < 8; ++j) acc[j] = fmaf(sv[j], acc[j], hv[j]);
         } else if (AFF == 2) {
             dw_load_affine(a, gch, sc, sf);
 #pragma unroll
@@ -761,12 +770,8 @@ static void dw_fast_launch(int mode, const void* a_, const void* w, const float*
             if (!a.in_scale) {
                 dw_fprop_fast_kernel<K, 0><<<g, 256, 0, s>>>((const bf16_t*)a_, (const bf16_t*)w, bias, (bf16_t*)out, a);
             } else {
-                // a lane keeps its channel group if the grid stride is a multiple of the groups (or it runs one trip)
-                unsigned gi = g;
-                if ((gi * 256u) % (unsigned)cg && (unsigned long)gi * 256u < a.total && gi > (unsigned)cg) gi -= gi % (unsigned)cg;
-                const bool inv = (gi * 256u) % (unsigned)cg == 0 || (unsigned long)gi * 256u >= a.total;
-                if (a.all_valid && inv)
-                    dw_fprop_fast_kernel<K, 1><<<gi, 256, 0, s>>>((const bf16_t*)a_, (const bf16_t*)w, bias, (bf16_t*)out, a);
+                if (a.all_valid && cg <= 64)
+                    dw_fprop_fast_kernel<K, 1><<<g, 256, 0, s>>>((const bf16_t*)a_, (const bf16_t*)w, bias, (bf16_t*)out, a);
                 else
                     dw_fprop_fast_kernel<K, 2><<<g, 256, 0, s>>>((const bf16_t*)a_, (const bf16_t*)w, bias, (bf16_t*)out, a);
             }
