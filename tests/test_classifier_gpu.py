@@ -142,3 +142,24 @@ def test_persistent_mlp_kernel_matches_cpu_oracle(opt_name, n_train):
         pg = g.predict(dg.test_x).cpu()
         pc = c.predict(dc.test_x)
         assert (pg - pc).abs().max().item() < 5e-2
+
+
+def test_member_streams_places_longest_first_on_least_loaded_stream():
+    """Concurrent ensemble members share `k` streams (one per hardware queue): sorted by measured step time, each goes
+    to the stream with the least work so far -- no stream ends up with the three slowest members."""
+    from distributeddeeplearning_amd.models.classifier import member_streams
+
+    class _M:
+        def __init__(self, ms):
+            self.chunk_ms = ms
+    costs = [9.0, 1.0, 8.0, 2.0, 7.0, 3.0, 6.0, 1.5, 0.5, 4.0]
+    members = [_M(c) for c in costs]
+    assign, pool = member_streams(members, torch.device("cuda"), 4)
+    assert len(pool) == 4 and len(assign) == len(members) and all(s in pool for s in assign)
+    load = {id(s): 0.0 for s in pool}
+    for m, s in zip(members, assign):
+        load[id(s)] += m.chunk_ms
+    assert max(load.values()) <= 1.15 * (sum(costs) / 4)           # longest-first: near the balanced optimum
+    assert len({id(assign[i]) for i in (0, 2, 4, 6)}) == 4           # the four slowest on four different streams
+    one_each, pool1 = member_streams(members, torch.device("cuda"), 0)
+    assert len(pool1) == len(members)
