@@ -988,7 +988,11 @@ _CHOICE_DIRTY = False
 
 def _lib_stamp() -> str:
     st = _LIB_PATH.stat()
-    return f"{st.st_size}-{int(st.st_mtime)}"
+    # PLAN_SCHEMA: bumped whenever the Python side changes what a recorded choice means (candidate order, plan fields)
+    return f"{st.st_size}-{int(st.st_mtime)}-s{PLAN_SCHEMA}"
+
+
+PLAN_SCHEMA = 3
 
 
 def _cache_path() -> Optional[Path]:
