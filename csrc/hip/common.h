@@ -72,6 +72,48 @@ __device__ __forceinline__ float act_grad_y(float y, int kind, float alpha) {
     }
 }
 
+// The switches above cost a chain of scalar compares and branches PER ELEMENT when `kind` is a run-time value (131
+// s_cbranch in bn_apply_cs for 8 elements per lane: the streaming kernels were branch-bound, not bandwidth-bound).
+// Kernels therefore take their activation codes as template parameters -- act_apply_k<K> folds the switch at compile
+// time; K = -1 keeps the run-time code -- and the host picks the instantiation (ACT1_DISPATCH / ACT2_DISPATCH).
+template <int K>
+__device__ __forceinline__ float act_apply_k(float x, int kind, float alpha) {
+    return act_apply(x, K >= 0 ? K : kind, alpha);
+}
+template <int K>
+__device__ __forceinline__ float act_grad_y_k(float y, int kind, float alpha) {
+    return act_grad_y(y, K >= 0 ? K : kind, alpha);
+}
+// CALL(A): one activation code.
+#define ACT1_DISPATCH(act, CALL)                                                                                   \
+    do {                                                                                                           \
+        switch (act) {                                                                                             \
+            case 0: CALL(0); break; case 1: CALL(1); break; case 2: CALL(2); break; case 3: CALL(3); break;        \
+            case 4: CALL(4); break; case 5: CALL(5); break; case 6: CALL(6); break; case 7: CALL(7); break;        \
+            default: CALL(-1); break;                                                                              \
+        }                                                                                                          \
+    } while (0)
+// CALL(A, P): two codes; every network here has at least one of them linear (conv(act) -> BN, or conv -> BN ->
+// act), so those 15 combinations are compiled and anything else runs the run-time instantiation.
+#define ACT2_DISPATCH(act, prev, CALL)                                                                             \
+    do {                                                                                                           \
+        if ((prev) == 0) {                                                                                         \
+            switch (act) {                                                                                         \
+                case 0: CALL(0, 0); break; case 1: CALL(1, 0); break; case 2: CALL(2, 0); break;                   \
+                case 3: CALL(3, 0); break; case 4: CALL(4, 0); break; case 5: CALL(5, 0); break;                   \
+                case 6: CALL(6, 0); break; case 7: CALL(7, 0); break; default: CALL(-1, -1); break;                \
+            }                                                                                                      \
+        } else if ((act) == 0) {                                                                                   \
+            switch (prev) {                                                                                        \
+                case 1: CALL(0, 1); break; case 2: CALL(0, 2); break; case 3: CALL(0, 3); break;                   \
+                case 4: CALL(0, 4); break; case 5: CALL(0, 5); break; case 6: CALL(0, 6); break;                   \
+                case 7: CALL(0, 7); break; default: CALL(-1, -1); break;                                           \
+            }                                                                                                      \
+        } else {                                                                                                   \
+            CALL(-1, -1);                                                                                          \
+        }                                                                                                          \
+    } while (0)
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

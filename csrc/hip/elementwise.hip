@@ -19,6 +19,7 @@ static inline int ew_grid(long n_groups) {
 }
 
 // ------------------------------------------------------------------------------ activations
+template <int A>
 __global__ void act_fwd_kernel(const uint4* __restrict__ x, uint4* __restrict__ y, long n8, int cg,
                                int c_true, int kind, float alpha) {
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n8; i += (long)gridDim.x * blockDim.x) {
@@ -26,11 +27,12 @@ __global__ void act_fwd_kernel(const uint4* __restrict__ x, uint4* __restrict__ 
         unpack8(x[i], f);
         int c0 = (int)(i % cg) * 8;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) f[j] = (c0 + j < c_true) ? act_apply(f[j], kind, alpha) : 0.f;
+        for (int j = 0; j < 8; ++j) f[j] = (c0 + j < c_true) ? act_apply_k<A>(f[j], kind, alpha) : 0.f;
         y[i] = pack8(f);
     }
 }
 
+template <int A>
 __global__ void act_bwd_kernel(const uint4* __restrict__ dy, const uint4* __restrict__ y,
                                uint4* __restrict__ dx, long n8, int kind, float alpha) {
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n8; i += (long)gridDim.x * blockDim.x) {
@@ -38,7 +40,7 @@ __global__ void act_bwd_kernel(const uint4* __restrict__ dy, const uint4* __rest
         unpack8(dy[i], g);
         unpack8(y[i], v);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) g[j] *= act_grad_y(v[j], kind, alpha);
+        for (int j = 0; j < 8; ++j) g[j] *= act_grad_y_k<A>(v[j], kind, alpha);
         dx[i] = pack8(g);
     }
 }
@@ -46,13 +48,17 @@ __global__ void act_bwd_kernel(const uint4* __restrict__ dy, const uint4* __rest
 DDL_API void ddl_act_fwd(const void* x, void* y, long rows, int C, int c_true, int kind, float alpha,
                          hipStream_t s) {
     long n8 = rows * (C / 8);
-    act_fwd_kernel<<<ew_grid(n8), EW_BLOCK, 0, s>>>((const uint4*)x, (uint4*)y, n8, C / 8, c_true, kind, alpha);
+#define CALL(A) act_fwd_kernel<A><<<ew_grid(n8), EW_BLOCK, 0, s>>>((const uint4*)x, (uint4*)y, n8, C / 8, c_true, kind, alpha)
+    ACT1_DISPATCH(kind, CALL);
+#undef CALL
 }
 
 DDL_API void ddl_act_bwd(const void* dy, const void* y, void* dx, long n, int kind, float alpha,
                          hipStream_t s) {
     long n8 = n / 8;
-    act_bwd_kernel<<<ew_grid(n8), EW_BLOCK, 0, s>>>((const uint4*)dy, (const uint4*)y, (uint4*)dx, n8, kind, alpha);
+#define CALL(A) act_bwd_kernel<A><<<ew_grid(n8), EW_BLOCK, 0, s>>>((const uint4*)dy, (const uint4*)y, (uint4*)dx, n8, kind, alpha)
+    ACT1_DISPATCH(kind, CALL);
+#undef CALL
 }
 
 // ------------------------------------------------------------------------------ column reductions
@@ -69,7 +75,7 @@ DDL_API void ddl_act_bwd(const void* dy, const void* y, void* dx, long n, int ki
 // loads in flight per lane), which is what a streaming reduction needs at 1-4 blocks per CU.
 template <int MODE> struct CrSums { static constexpr int N = MODE == 3 ? 5 : 2; };
 
-template <int MODE>
+template <int MODE, int A = -1, int P = -1>
 __global__ __launch_bounds__(EW_BLOCK) void colreduce_kernel(
     const uint4* __restrict__ a, const uint4* __restrict__ b, const uint4* __restrict__ yv,
     const float* __restrict__ mean, const float* __restrict__ invstd, float* __restrict__ part,
@@ -100,7 +106,7 @@ __global__ __launch_bounds__(EW_BLOCK) void colreduce_kernel(
 #pragma unroll
             for (int j = 0; j < 8; ++j) { mu[j] = mean[g * 8 + j]; is[j] = invstd[g * 8 + j]; }
         }
-        const bool has_y = (MODE == 1 || MODE == 3) && act != ACT_LINEAR;
+        const bool has_y = (MODE == 1 || MODE == 3) && (A >= 0 ? A : act) != ACT_LINEAR;
         auto accum = [&](const uint4& ua, const uint4& ub, const uint4& uy) {
             float v[8];
             unpack8(ua, v);
@@ -113,14 +119,14 @@ __global__ __launch_bounds__(EW_BLOCK) void colreduce_kernel(
                 if (has_y) {
                     unpack8(uy, yy);
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) v[j] *= act_grad_y(yy[j], act, alpha);
+                    for (int j = 0; j < 8; ++j) v[j] *= act_grad_y_k<A>(yy[j], act, alpha);
                 }
 #pragma unroll
                 for (int j = 0; j < 8; ++j) { s[0][j] += v[j]; s[1][j] += v[j] * (x[j] - mu[j]) * is[j]; }
                 if (MODE == 3) {
 #pragma unroll
                     for (int j = 0; j < 8; ++j) {
-                        const float ad = act_grad_y(x[j], prev_act, prev_alpha);
+                        const float ad = act_grad_y_k<P>(x[j], prev_act, prev_alpha);
                         s[NS - 3][j] += ad * v[j];
                         s[NS - 2][j] += ad * x[j];
                         s[NS - 1][j] += ad;
@@ -472,6 +478,7 @@ __device__ __forceinline__ void bn_affine8(const float* __restrict__ scale, cons
     }
 }
 
+template <int A>
 __global__ void bn_apply_kernel(const uint4* __restrict__ x, uint4* __restrict__ y,
                                 const float* __restrict__ scale, const float* __restrict__ shift, long n8,
                                 int cg, int c_true, int act, float alpha, const float* __restrict__ mm,
@@ -487,13 +494,14 @@ __global__ void bn_apply_kernel(const uint4* __restrict__ x, uint4* __restrict__
         bn_affine8(scale, shift, mm, mv, eps, c0, sc, sh);
 #pragma unroll
         for (int j = 0; j < 8; ++j)
-            f[j] = (c0 + j < c_true) ? act_apply(fmaf(f[j], sc[j], sh[j]), act, alpha) : 0.f;
+            f[j] = (c0 + j < c_true) ? act_apply_k<A>(fmaf(f[j], sc[j], sh[j]), act, alpha) : 0.f;
         y[i] = pack8(f);
     }
 }
 
 // Channel-stationary variant (cg divides 256): a thread keeps ONE 8-channel group for its whole
 // life, so scale/shift are loaded once and the loop body is load -> 8 fma/act -> store.
+template <int A>
 __global__ __launch_bounds__(EW_BLOCK) void bn_apply_cs_kernel(const uint4* __restrict__ x, uint4* __restrict__ y,
                                                                const float* __restrict__ scale,
                                                                const float* __restrict__ shift, long rows, int cg,
@@ -511,7 +519,7 @@ __global__ __launch_bounds__(EW_BLOCK) void bn_apply_cs_kernel(const uint4* __re
         unpack8(x[r * cg + g], f);
 #pragma unroll
         for (int j = 0; j < 8; ++j)
-            f[j] = (c0 + j < c_true) ? act_apply(fmaf(f[j], sc[j], sh[j]), act, alpha) : 0.f;
+            f[j] = (c0 + j < c_true) ? act_apply_k<A>(fmaf(f[j], sc[j], sh[j]), act, alpha) : 0.f;
         y[r * cg + g] = pack8(f);
     }
 }
@@ -529,14 +537,17 @@ static void bn_apply_launch(const void* x, void* y, const float* scale, const fl
     long n8 = rows * (C / 8);                  // `rows` per batch group
     if (cs_ok(C / 8)) {
         int gx = cs_grid(rows * groups, C / 8) / groups;
-        bn_apply_cs_kernel<<<dim3(gx < 1 ? 1 : gx, groups), EW_BLOCK, 0, s>>>((const uint4*)x, (uint4*)y, scale, shift,
-                                                                              rows, C / 8, c_true, act, alpha, mm, mv,
-                                                                              eps);
+#define CALL(A) bn_apply_cs_kernel<A><<<dim3(gx < 1 ? 1 : gx, groups), EW_BLOCK, 0, s>>>( \
+        (const uint4*)x, (uint4*)y, scale, shift, rows, C / 8, c_true, act, alpha, mm, mv, eps)
+        ACT1_DISPATCH(act, CALL);
+#undef CALL
         return;
     }
     int gx = ew_grid(n8 * groups) / groups;
-    bn_apply_kernel<<<dim3(gx < 1 ? 1 : gx, groups), EW_BLOCK, 0, s>>>((const uint4*)x, (uint4*)y, scale, shift, n8,
-                                                                       C / 8, c_true, act, alpha, mm, mv, eps);
+#define CALL(A) bn_apply_kernel<A><<<dim3(gx < 1 ? 1 : gx, groups), EW_BLOCK, 0, s>>>( \
+    (const uint4*)x, (uint4*)y, scale, shift, n8, C / 8, c_true, act, alpha, mm, mv, eps)
+    ACT1_DISPATCH(act, CALL);
+#undef CALL
 }
 
 // `groups` batch groups of `rows` rows each, scale / shift [groups][C]
@@ -666,6 +677,7 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_wide_kernel(
     if (threadIdx.x == 0) bn_bwd_store<NS>(c, total, dgamma, dbeta, dbias, c_bias);
 }
 
+template <int A, int P>
 __global__ void bn_bwd_apply_kernel(const uint4* __restrict__ dy, const uint4* __restrict__ x,
                                     const uint4* __restrict__ yv, uint4* __restrict__ dx,
                                     const float* __restrict__ mean, const float* __restrict__ invstd,
@@ -683,10 +695,10 @@ __global__ void bn_bwd_apply_kernel(const uint4* __restrict__ dy, const uint4* _
         float g[8], xv[8], yy[8];
         unpack8(dy[i], g);
         unpack8(x[i], xv);
-        if (act != ACT_LINEAR) {
+        if ((A >= 0 ? A : act) != ACT_LINEAR) {
             unpack8(yv[i], yy);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) g[j] *= act_grad_y(yy[j], act, alpha);
+            for (int j = 0; j < 8; ++j) g[j] *= act_grad_y_k<A>(yy[j], act, alpha);
         }
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
@@ -694,13 +706,14 @@ __global__ void bn_bwd_apply_kernel(const uint4* __restrict__ dy, const uint4* _
             float is = invstd[c];
             float xhat = (xv[j] - mean[c]) * is;
             float d = gamma[c] * is * (g[j] - c1[c] - xhat * c2[c]);
-            if (prev_act != ACT_LINEAR) d *= act_grad_y(xv[j], prev_act, prev_alpha);
+            if ((P >= 0 ? P : prev_act) != ACT_LINEAR) d *= act_grad_y_k<P>(xv[j], prev_act, prev_alpha);
             g[j] = d;
         }
         dx[i] = pack8(g);
     }
 }
 
+template <int A, int P>
 __global__ __launch_bounds__(EW_BLOCK) void bn_bwd_apply_cs_kernel(
     const uint4* __restrict__ dy, const uint4* __restrict__ x, const uint4* __restrict__ yv, uint4* __restrict__ dx,
     const float* __restrict__ mean, const float* __restrict__ invstd, const float* __restrict__ gamma,
@@ -728,15 +741,15 @@ __global__ __launch_bounds__(EW_BLOCK) void bn_bwd_apply_cs_kernel(
         float gr[8], xv[8], yy[8];
         unpack8(dy[i], gr);
         unpack8(x[i], xv);
-        if (act != ACT_LINEAR) {
+        if ((A >= 0 ? A : act) != ACT_LINEAR) {
             unpack8(yv[i], yy);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) gr[j] *= act_grad_y(yy[j], act, alpha);
+            for (int j = 0; j < 8; ++j) gr[j] *= act_grad_y_k<A>(yy[j], act, alpha);
         }
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             float d = fmaf(k0[j], gr[j], fmaf(k1[j], xv[j], k2[j]));
-            if (prev_act != ACT_LINEAR) d *= act_grad_y(xv[j], prev_act, prev_alpha);
+            if ((P >= 0 ? P : prev_act) != ACT_LINEAR) d *= act_grad_y_k<P>(xv[j], prev_act, prev_alpha);
             gr[j] = d;
         }
         dx[i] = pack8(gr);
@@ -775,8 +788,10 @@ DDL_API void ddl_bn_bwd(const void* dy, const void* x, const void* y, void* dx, 
                                                                       dbeta, c1, c2, mean, invstd, gamma, nullptr,
                                                                       0, groups);
     } else if (dbias) {
-        colreduce_kernel<3><<<grid, EW_BLOCK, 0, s>>>((const uint4*)dy, (const uint4*)x, (const uint4*)y, mean,
-                                                      invstd, part, rows, C, act, alpha, prev_act, prev_alpha);
+#define CALL(A, P) colreduce_kernel<3, A, P><<<grid, EW_BLOCK, 0, s>>>( \
+        (const uint4*)dy, (const uint4*)x, (const uint4*)y, mean, invstd, part, rows, C, act, alpha, prev_act, prev_alpha)
+        ACT2_DISPATCH(act, prev_act, CALL);
+#undef CALL
         if ((int)grid.x > fin_wide_min())
             bn_bwd_finalize_wide_kernel<5><<<C, 256, 0, s>>>(part, grid.x, C, rows, train_stats, dgamma, dbeta, c1, c2,
                                                               mean, invstd, gamma, dbias, c_bias, groups);
@@ -785,8 +800,10 @@ DDL_API void ddl_bn_bwd(const void* dy, const void* x, const void* y, void* dx, 
                                                                       dbeta, c1, c2, mean, invstd, gamma, dbias,
                                                                       c_bias, groups);
     } else {
-        colreduce_kernel<1><<<grid, EW_BLOCK, 0, s>>>((const uint4*)dy, (const uint4*)x, (const uint4*)y, mean,
-                                                      invstd, part, rows, C, act, alpha, 0, 0.f);
+#define CALL(A) colreduce_kernel<1, A, 0><<<grid, EW_BLOCK, 0, s>>>( \
+        (const uint4*)dy, (const uint4*)x, (const uint4*)y, mean, invstd, part, rows, C, act, alpha, 0, 0.f)
+        ACT1_DISPATCH(act, CALL);
+#undef CALL
         if ((int)grid.x > fin_wide_min())
             bn_bwd_finalize_wide_kernel<2><<<C, 256, 0, s>>>(part, grid.x, C, rows, train_stats, dgamma, dbeta, c1, c2,
                                                               mean, invstd, gamma, nullptr, 0, groups);
@@ -798,15 +815,19 @@ DDL_API void ddl_bn_bwd(const void* dy, const void* x, const void* y, void* dx, 
     long n8 = rows * (C / 8);
     if (cs_ok(C / 8)) {
         int gx = cs_grid(rows * groups, C / 8) / groups;
-        bn_bwd_apply_cs_kernel<<<dim3(gx < 1 ? 1 : gx, groups), EW_BLOCK, 0, s>>>(
-            (const uint4*)dy, (const uint4*)x, (const uint4*)y, (uint4*)dx, mean, invstd, gamma, c1, c2, rows, C / 8,
-            act, alpha, prev_act, prev_alpha);
+#define CALL(A, P) bn_bwd_apply_cs_kernel<A, P><<<dim3(gx < 1 ? 1 : gx, groups), EW_BLOCK, 0, s>>>( \
+        (const uint4*)dy, (const uint4*)x, (const uint4*)y, (uint4*)dx, mean, invstd, gamma, c1, c2, rows, C / 8, act, alpha, \
+        prev_act, prev_alpha)
+        ACT2_DISPATCH(act, prev_act, CALL);
+#undef CALL
         return;
     }
     int gx = ew_grid(n8 * groups) / groups;
-    bn_bwd_apply_kernel<<<dim3(gx < 1 ? 1 : gx, groups), EW_BLOCK, 0, s>>>(
-        (const uint4*)dy, (const uint4*)x, (const uint4*)y, (uint4*)dx, mean, invstd, gamma, c1, c2, n8, C / 8, act,
-        alpha, prev_act, prev_alpha);
+#define CALL(A, P) bn_bwd_apply_kernel<A, P><<<dim3(gx < 1 ? 1 : gx, groups), EW_BLOCK, 0, s>>>( \
+    (const uint4*)dy, (const uint4*)x, (const uint4*)y, (uint4*)dx, mean, invstd, gamma, c1, c2, n8, C / 8, act, alpha, \
+    prev_act, prev_alpha)
+    ACT2_DISPATCH(act, prev_act, CALL);
+#undef CALL
 }
 
 // bias gradient = per-channel column sum of dY

@@ -123,7 +123,8 @@ struct HeadBn {
     int C, rows_per_group, act; float alpha;
 };
 
-template <int VM, bool BNF>
+// BACT: the fused BatchNorm's activation as a compile-time code (-1: run-time bn.act), see common.h act_apply_k
+template <int VM, bool BNF, int BACT = -1>
 __global__ __launch_bounds__(HEAD_ROWS * 64) void dense1_bce_kernel(
     const uint4* __restrict__ x, const bf16_t* __restrict__ w, const float* __restrict__ bias,
     float label_first, float label_second, int n_first, int M, int K, uint4* __restrict__ dx,
@@ -166,7 +167,7 @@ __global__ __launch_bounds__(HEAD_ROWS * 64) void dense1_bce_kernel(
 #pragma unroll
                     for (int j = 0; j < 8; ++j) {
                         xr[v][j] = f[v][j];
-                        f[v][j] = bf2f(f2bf(act_apply(fmaf(f[v][j], sc[j], sh[j]), bn.act, bn.alpha)));
+                        f[v][j] = bf2f(f2bf(act_apply_k<BACT>(fmaf(f[v][j], sc[j], sh[j]), bn.act, bn.alpha)));
                     }
                 }
 #pragma unroll
@@ -192,7 +193,7 @@ __global__ __launch_bounds__(HEAD_ROWS * 64) void dense1_bce_kernel(
                     if (BNF) {
 #pragma unroll
                         for (int j = 0; j < 8; ++j) {
-                            o[j] = bf2f(f2bf(bf2f(f2bf(o[j])) * act_grad_y(f[v][j], bn.act, bn.alpha)));
+                            o[j] = bf2f(f2bf(bf2f(f2bf(o[j])) * act_grad_y_k<BACT>(f[v][j], bn.act, bn.alpha)));
                             s0[j] += o[j];
                             s1[j] += o[j] * (xr[v][j] - mu[j]) * is[j];
                         }
@@ -329,7 +330,11 @@ DDL_API int ddl_dense1_bce(const void* x, const void* w, const float* bias, floa
     dim3 grid(nb, groups);
 #define HEAD_ARGS (const uint4*)x, (const bf16_t*)w, bias, label_first, label_second, n_first, M, K, (uint4*)dx, \
                   dw_part, logits, rowloss, dlogit, want_dx, want_dw, bn
-    if (fuse) dense1_bce_kernel<4, true><<<grid, HEAD_ROWS * 64, 0, s>>>(HEAD_ARGS);
+    if (fuse) {
+#define CALL(A) dense1_bce_kernel<4, true, A><<<grid, HEAD_ROWS * 64, 0, s>>>(HEAD_ARGS)
+        ACT1_DISPATCH(bn_act, CALL);
+#undef CALL
+    }
     else if (K <= 4 * 64 * 8) dense1_bce_kernel<4, false><<<grid, HEAD_ROWS * 64, 0, s>>>(HEAD_ARGS);
     else dense1_bce_kernel<HEAD_VMAX, false><<<grid, HEAD_ROWS * 64, 0, s>>>(HEAD_ARGS);
 #undef HEAD_ARGS
