@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 
 typedef uint16_t bf16_t;   // raw bfloat16 bits; activations/weights are bf16, accumulation fp32
 
@@ -83,6 +84,21 @@ __device__ __forceinline__ float act_apply_k(float x, int kind, float alpha) {
 template <int K>
 __device__ __forceinline__ float act_grad_y_k(float y, int kind, float alpha) {
     return act_grad_y(y, K >= 0 ? K : kind, alpha);
+}
+// In-kernel form for epilogues: f(std::integral_constant<int, kind>) -- one branch chain per call instead of one per
+// element inside it (the body is compiled once per activation).
+template <typename F>
+__device__ __forceinline__ void act_switch(int kind, F&& f) {
+    switch (kind) {
+        case ACT_RELU: f(std::integral_constant<int, ACT_RELU>{}); break;
+        case ACT_SIGMOID: f(std::integral_constant<int, ACT_SIGMOID>{}); break;
+        case ACT_SOFTPLUS: f(std::integral_constant<int, ACT_SOFTPLUS>{}); break;
+        case ACT_TANH: f(std::integral_constant<int, ACT_TANH>{}); break;
+        case ACT_SOFTSIGN: f(std::integral_constant<int, ACT_SOFTSIGN>{}); break;
+        case ACT_LEAKY: f(std::integral_constant<int, ACT_LEAKY>{}); break;
+        case ACT_TANH01: f(std::integral_constant<int, ACT_TANH01>{}); break;
+        default: f(std::integral_constant<int, ACT_LINEAR>{}); break;
+    }
 }
 // CALL(A): one activation code.
 #define ACT1_DISPATCH(act, CALL)                                                                                   \

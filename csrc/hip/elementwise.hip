@@ -1163,6 +1163,7 @@ __global__ __launch_bounds__(256) void col2im_1ch_kernel(const bf16_t* __restric
     __syncthreads();
     const float b0 = bias ? bias[0] : 0.f;
     const float invW = 1.0f / (float)g.W;
+    auto fold = [&](auto KA) {                  // the loop compiled per activation (common.h act_switch)
     for (int i = threadIdx.x; i < (h1 - h0) * g.W; i += 256) {
         int hl = fdiv_small(i, invW), w = i - hl * g.W, h = h0 + hl;
         float acc = 0.f;
@@ -1180,12 +1181,14 @@ __global__ __launch_bounds__(256) void col2im_1ch_kernel(const bf16_t* __restric
                 acc += bf2f(*(const bf16_t*)(row + ow * pitch + kw * 2));
             }
         }
-        float v = act_apply(acc + b0, act, alpha);
+        float v = act_apply_k<decltype(KA)::value>(acc + b0, act, alpha);
         const long pix = ((long)b * g.H + h) * g.W + w;
         // fused activation backward of the layer below: (bf16 result) * act'(its saved output), rounded once more
         if (mul_y) v = bf2f(f2bf(v)) * act_grad_y(bf2f(mul_y[pix * 8]), mul_act, mul_alpha);
         img[pix] = make_uint4((uint32_t)f2bf(v), 0, 0, 0);   // channel 0 real, 7 lanes zero
     }
+    };
+    act_switch(act, fold);
 }
 
 DDL_API int ddl_im2col_1ch(const void* img, void* col, int B, int H, int W, int Ci, int OH, int OW, int KH, int KW,

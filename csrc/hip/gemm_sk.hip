@@ -93,18 +93,22 @@ __global__ __launch_bounds__(256) void gemm_sk_kernel(const GemmSkArgs a) {
         // ---- bias + activation (switch hoisted), padding channels forced to zero
         const int act = a.act;
         const float alpha = a.alpha;
+        auto epi = [&](auto KA) {
 #pragma unroll
-        for (int t = 0; t < NT; ++t)
+            for (int t = 0; t < NT; ++t)
 #pragma unroll
-            for (int j = 0; j < FRG; ++j)
+                for (int j = 0; j < FRG; ++j)
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    float v = acc[t][j][e] + bv[t][e];
-                    if (SLOW) v = act_apply(v, act, alpha);
-                    else if (act == ACT_RELU) v = fmaxf(v, 0.f);
-                    else if (act == ACT_LEAKY) v = v > 0.f ? v : alpha * v;
-                    acc[t][j][e] = (n0 + 16 * t + 4 * fq + e < a.Nw) ? v : 0.f;
-                }
+                    for (int e = 0; e < 4; ++e) {
+                        float v = acc[t][j][e] + bv[t][e];
+                        if (SLOW) v = act_apply_k<decltype(KA)::value>(v, act, alpha);
+                        else if (act == ACT_RELU) v = fmaxf(v, 0.f);
+                        else if (act == ACT_LEAKY) v = v > 0.f ? v : alpha * v;
+                        acc[t][j][e] = (n0 + 16 * t + 4 * fq + e < a.Nw) ? v : 0.f;
+                    }
+        };
+        if (SLOW) act_switch(act, epi);             // one branch chain per 64-row slab, not one per element
+        else epi(std::integral_constant<int, -1>{});
         // ---- transposed store: 16 rows at a time through the wave's LDS scratch
 #pragma unroll
         for (int j = 0; j < FRG; ++j) {

@@ -209,6 +209,21 @@ __global__ __launch_bounds__(256) void igemm_conv_kernel(const ConvArgs a) {
         return;
     }
     // ---- epilogue: lane holds channels nb..nb+3 (nb = 4*fq) of pixel fr in each 16x16 tile
+    // bias + activation in place first, under ONE activation dispatch (a run-time switch per element is a chain of
+    // scalar branches per element, common.h); channels beyond the weight rows are zero
+    act_switch(a.act, [&](auto KA) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int n = n0 + wn * WN + 16 * t + 4 * fq + e;
+                const bool live = n < a.Nw;
+                const float bn_ = (live && a.bias) ? a.bias[n] : 0.f;
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[t][j][e] = live ? act_apply_k<decltype(KA)::value>(acc[t][j][e] + bn_, a.act, a.alpha) : 0.f;
+            }
+    });
     const bool vec_ok = (a.Nd & 3) == 0;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -222,18 +237,7 @@ __global__ __launch_bounds__(256) void igemm_conv_kernel(const ConvArgs a) {
         for (int t = 0; t < NT; ++t) {
             int nb = n0 + wn * WN + 16 * t + 4 * fq;
             if (nb >= a.Nd) continue;
-            float v[4];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                int n = nb + e;
-                float x = acc[t][j][e];
-                if (n < a.Nw) {
-                    if (a.bias) x += a.bias[n];
-                    v[e] = act_apply(x, a.act, a.alpha);
-                } else {
-                    v[e] = 0.f;
-                }
-            }
+            const float v[4] = {acc[t][j][0], acc[t][j][1], acc[t][j][2], acc[t][j][3]};
             if (vec_ok) {
                 *(uint2*)(drow + nb) = make_uint2(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]));
             } else {
@@ -400,6 +404,21 @@ __global__ __launch_bounds__(256) void igemm_conv_kernel_k32(const ConvArgs a) {
         return;
     }
     // ---- epilogue: lane holds channels nb..nb+3 (nb = 4*fq) of pixel fr in each 16x16 tile
+    // bias + activation in place first, under ONE activation dispatch (a run-time switch per element is a chain of
+    // scalar branches per element, common.h); channels beyond the weight rows are zero
+    act_switch(a.act, [&](auto KA) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int n = n0 + wn * WN + 16 * t + 4 * fq + e;
+                const bool live = n < a.Nw;
+                const float bn_ = (live && a.bias) ? a.bias[n] : 0.f;
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[t][j][e] = live ? act_apply_k<decltype(KA)::value>(acc[t][j][e] + bn_, a.act, a.alpha) : 0.f;
+            }
+    });
     const bool vec_ok = (a.Nd & 3) == 0;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -413,18 +432,7 @@ __global__ __launch_bounds__(256) void igemm_conv_kernel_k32(const ConvArgs a) {
         for (int t = 0; t < NT; ++t) {
             int nb = n0 + wn * WN + 16 * t + 4 * fq;
             if (nb >= a.Nd) continue;
-            float v[4];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                int n = nb + e;
-                float x = acc[t][j][e];
-                if (n < a.Nw) {
-                    if (a.bias) x += a.bias[n];
-                    v[e] = act_apply(x, a.act, a.alpha);
-                } else {
-                    v[e] = 0.f;
-                }
-            }
+            const float v[4] = {acc[t][j][0], acc[t][j][1], acc[t][j][2], acc[t][j][3]};
             if (vec_ok) {
                 *(uint2*)(drow + nb) = make_uint2(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]));
             } else {

@@ -162,24 +162,28 @@ __global__ __launch_bounds__(MLP_T) void mlp_persistent_kernel(const MlpMember* 
                 for (int j = 0; j < NPT; ++j)
                     if (n0 + j < N) red[(kq * MLP_B + b) * MLP_MAXN + n0 + j] = acc[j];
                 __syncthreads();
-                for (int e = t; e < MLP_B * N; e += MLP_T) {
-                    const int b2 = e / N, n = e - b2 * N;
-                    float z = P[L.b_off + n];
+                act_switch(L.act, [&](auto KA) {        // loops compiled per activation: no branch chain per element
+                    for (int e = t; e < MLP_B * N; e += MLP_T) {
+                        const int b2 = e / N, n = e - b2 * N;
+                        float z = P[L.b_off + n];
 #pragma unroll
-                    for (int q = 0; q < MLP_KQ; ++q) z += red[(q * MLP_B + b2) * MLP_MAXN + n];
-                    Al[b2 * MLP_LD + n] = b2 < rows ? act_apply(z, L.act, L.alpha) : 0.f;
-                }
+                        for (int q = 0; q < MLP_KQ; ++q) z += red[(q * MLP_B + b2) * MLP_MAXN + n];
+                        Al[b2 * MLP_LD + n] = b2 < rows ? act_apply_k<decltype(KA)::value>(z, L.act, L.alpha) : 0.f;
+                    }
+                });
             } else {
                 const MlpLayer& Lp = mb.L[l - 1];
                 const float* Hp = H + (l - 1) * MLP_B * MLP_LD;
                 const int K = Lp.N;
                 const int b = t & 31;
-                for (int n = t >> 5; n < N; n += MLP_T / 32) {
-                    const float* w = P + L.w_off + (size_t)n * L.Kp;
-                    float z = P[L.b_off + n];
-                    for (int k = 0; k < K; ++k) z = fmaf(Hp[b * MLP_LD + k], w[k], z);
-                    Al[b * MLP_LD + n] = b < rows ? act_apply(z, L.act, L.alpha) : 0.f;
-                }
+                act_switch(L.act, [&](auto KA) {
+                    for (int n = t >> 5; n < N; n += MLP_T / 32) {
+                        const float* w = P + L.w_off + (size_t)n * L.Kp;
+                        float z = P[L.b_off + n];
+                        for (int k = 0; k < K; ++k) z = fmaf(Hp[b * MLP_LD + k], w[k], z);
+                        Al[b * MLP_LD + n] = b < rows ? act_apply_k<decltype(KA)::value>(z, L.act, L.alpha) : 0.f;
+                    }
+                });
             }
             __syncthreads();
             if (L.has_bn) {
@@ -262,26 +266,30 @@ __global__ __launch_bounds__(MLP_T) void mlp_persistent_kernel(const MlpMember* 
                         coef[MLP_MAXN + t] = dg;
                     }
                     __syncthreads();
-                    for (int e = t; e < MLP_B * N; e += MLP_T) {
-                        const int b = e / N, n = e - b * N;
-                        const float is = istd_s[l * MLP_MAXN + n];
-                        const float a = Al[b * MLP_LD + n];
-                        const float xh = (a - mean_s[l * MLP_MAXN + n]) * is;
-                        float d = P[L.g_off + n] * is *
-                                  (Dz[b * MLP_LD + n] - coef[n] * inv_rows - xh * coef[MLP_MAXN + n] * inv_rows);
-                        d *= act_grad_y(a, L.act, L.alpha);
-                        Dz[b * MLP_LD + n] = b < rows ? d : 0.f;
-                    }
+                    act_switch(L.act, [&](auto KA) {
+                        for (int e = t; e < MLP_B * N; e += MLP_T) {
+                            const int b = e / N, n = e - b * N;
+                            const float is = istd_s[l * MLP_MAXN + n];
+                            const float a = Al[b * MLP_LD + n];
+                            const float xh = (a - mean_s[l * MLP_MAXN + n]) * is;
+                            float d = P[L.g_off + n] * is *
+                                      (Dz[b * MLP_LD + n] - coef[n] * inv_rows - xh * coef[MLP_MAXN + n] * inv_rows);
+                            d *= act_grad_y_k<decltype(KA)::value>(a, L.act, L.alpha);
+                            Dz[b * MLP_LD + n] = b < rows ? d : 0.f;
+                        }
+                    });
                     __syncthreads();
                     if (t < N) {                     // gamma / beta: every reader of the old values is past the barrier
                         opt_at(opt, P, Mo, Vo, L.g_off + t, coef[MLP_MAXN + t]);
                         opt_at(opt, P, Mo, Vo, L.be_off + t, coef[t]);
                     }
                 } else {
-                    for (int e = t; e < MLP_B * N; e += MLP_T) {
-                        const int b = e / N, n = e - b * N;
-                        Dz[b * MLP_LD + n] *= act_grad_y(Al[b * MLP_LD + n], L.act, L.alpha);
-                    }
+                    act_switch(L.act, [&](auto KA) {
+                        for (int e = t; e < MLP_B * N; e += MLP_T) {
+                            const int b = e / N, n = e - b * N;
+                            Dz[b * MLP_LD + n] *= act_grad_y_k<decltype(KA)::value>(Al[b * MLP_LD + n], L.act, L.alpha);
+                        }
+                    });
                     __syncthreads();
                 }
             }

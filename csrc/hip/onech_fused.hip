@@ -138,6 +138,7 @@ __global__ __launch_bounds__(256) void tapfold_kernel(const TapFoldArgs a) {
     // ---- fold (identical to col2im_1ch_kernel)
     const float b0 = a.bias ? a.bias[0] : 0.f;
     const float invW = 1.0f / (float)a.W;
+    auto fold = [&](auto KA) {
     for (int i = tid; i < (h1 - h0) * a.W; i += 256) {
         int hl = tf_fdiv(i, invW), w = i - hl * a.W, h = h0 + hl;
         float acc = 0.f;
@@ -155,11 +156,13 @@ __global__ __launch_bounds__(256) void tapfold_kernel(const TapFoldArgs a) {
                 acc += bf2f(*(const bf16_t*)(row + ow * TF_ZP + kw * 2));
             }
         }
-        float v = act_apply(acc + b0, a.act, a.alpha);
+        float v = act_apply_k<decltype(KA)::value>(acc + b0, a.act, a.alpha);
         const long pix = ((long)b * a.H + h) * a.W + w;
         if (a.mul_y) v = bf2f(f2bf(v)) * act_grad_y(bf2f(a.mul_y[pix * 8]), a.mul_act, a.mul_alpha);
         a.img[pix] = make_uint4((uint32_t)f2bf(v), 0, 0, 0);
     }
+    };
+    act_switch(a.act, fold);                    // the loop compiled per activation: no branch chain per pixel
 }
 
 template <int KS, int SH, int SW>
@@ -349,7 +352,9 @@ __global__ __launch_bounds__(256) void tapconv_1ch_kernel(const TapConvArgs a) {
 #pragma unroll
         for (int t = 0; t < NT; ++t)
             acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[t], xf, (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
-        if (p < npix) {
+        // one activation dispatch per fragment (common.h: a run-time switch per element is a branch chain per element):
+        // the slow epilogue's own activation, or -- RED 5 -- the activation in front of the BatchNorm being reduced
+        auto tile = [&](auto KA, auto KP) {
             bf16_t* dst = a.y + ((size_t)b * npix + p) * a.Np;
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
@@ -357,7 +362,7 @@ __global__ __launch_bounds__(256) void tapconv_1ch_kernel(const TapConvArgs a) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     float x = acc[t][e] + bv[t][e];
-                    if (SLOW) x = act_apply(x, act, alpha);
+                    if (SLOW) x = act_apply_k<decltype(KA)::value>(x, act, alpha);
                     else if (act == ACT_RELU) x = fmaxf(x, 0.f);
                     else if (act == ACT_LEAKY) x = x > 0.f ? x : alpha * x;
                     v[e] = (16 * t + 4 * fq + e < a.n_lim) ? x : 0.f;
@@ -374,7 +379,7 @@ __global__ __launch_bounds__(256) void tapconv_1ch_kernel(const TapConvArgs a) {
                             rs[0][t][e] += g;
                             rs[1][t][e] += g * (xv[e] - rmu[t][e]) * ris[t][e];
                             if (RED == 5) {
-                                const float ad = act_grad_y(xv[e], a.r_prev_act, a.r_prev_alpha);
+                                const float ad = act_grad_y_k<decltype(KP)::value>(xv[e], a.r_prev_act, a.r_prev_alpha);
                                 rs[RED - 3][t][e] += ad * g;
                                 rs[RED - 2][t][e] += ad * xv[e];
                                 rs[RED - 1][t][e] += ad;
@@ -383,6 +388,12 @@ __global__ __launch_bounds__(256) void tapconv_1ch_kernel(const TapConvArgs a) {
                     }
                 }
             }
+        };
+        if (p < npix) {
+            using Dyn = std::integral_constant<int, -1>;
+            if (RED == 5) act_switch(a.r_prev_act, [&](auto KP) { tile(Dyn{}, KP); });
+            else if (SLOW) act_switch(act, [&](auto KA) { tile(KA, Dyn{}); });
+            else tile(Dyn{}, Dyn{});
         }
     }
     if (RED) {

@@ -296,12 +296,15 @@ __global__ __launch_bounds__(256, (BN * FR >= 512 ? 1 : 2)) void pconv_kernel(co
                 const float alpha = a.alpha;
                 if (SLOW) {
                     // fully unrolled: runtime-indexed accumulators would be demoted to scratch memory
+                    act_switch(act, [&](auto KA) {
 #pragma unroll
-                    for (int t = 0; t < NT; ++t)
+                        for (int t = 0; t < NT; ++t)
 #pragma unroll
-                        for (int j = 0; j < FR; ++j)
+                            for (int j = 0; j < FR; ++j)
 #pragma unroll
-                            for (int e = 0; e < 4; ++e) acc[t][j][e] = act_apply(acc[t][j][e] + bv[t][e], act, alpha);
+                                for (int e = 0; e < 4; ++e)
+                                    acc[t][j][e] = act_apply_k<decltype(KA)::value>(acc[t][j][e] + bv[t][e], act, alpha);
+                    });
                 } else if (act == ACT_LINEAR) {
 #pragma unroll
                     for (int t = 0; t < NT; ++t)

@@ -364,8 +364,13 @@ __global__ void dw_fprop_kernel(const bf16_t* __restrict__ x, const bf16_t* __re
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             int c = gch * 8 + j;
-            acc[j] = c < c_true ? act_apply(acc[j] + (bias ? bias[c] : 0.f), act, alpha) : 0.f;
+            acc[j] = acc[j] + ((bias && c < c_true) ? bias[c] : 0.f);
         }
+        act_switch(act, [&](auto KA) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                acc[j] = gch * 8 + j < c_true ? act_apply_k<decltype(KA)::value>(acc[j], act, alpha) : 0.f;
+        });
         *(uint4*)(y + i * 8) = pack8(acc);
     }
 }
@@ -526,6 +531,7 @@ __global__ __launch_bounds__(256, (AFF == 1 && K == 3) ? 5 : 1) void dw_fprop_fa
         }
         __syncthreads();
     }
+    auto run = [&](auto KA) {                   // the loop compiled per activation (common.h act_switch)
     for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < a.total; i += gridDim.x * 256u) {
         const unsigned p = fdivu(i, a.dcg);
         const int gch = (int)(i - p * cg);
@@ -583,10 +589,12 @@ __global__ __launch_bounds__(256, (AFF == 1 && K == 3) ? 5 : 1) void dw_fprop_fa
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const int c = gch * 8 + j;
-            acc[j] = c < a.c_true ? act_apply(acc[j] + (bias ? bias[c] : 0.f), a.act, a.alpha) : 0.f;
+            acc[j] = c < a.c_true ? act_apply_k<decltype(KA)::value>(acc[j] + (bias ? bias[c] : 0.f), a.act, a.alpha) : 0.f;
         }
         *(uint4*)(y + (size_t)i * 8) = pack8(acc);
     }
+    };
+    act_switch(a.act, run);
 }
 
 // Input gradient by output-parity class (blockIdx.y = ph * sw + pw): dx pixels (ph + sh*i, pw + sw*j) of one
