@@ -946,28 +946,36 @@ template <> __device__ __forceinline__ float load_as_float<float>(const float* p
 template <> __device__ __forceinline__ float load_as_float<uint8_t>(const uint8_t* p, long i) { return (float)p[i]; }
 template <> __device__ __forceinline__ float load_as_float<bf16_t>(const bf16_t* p, long i) { return bf2f(p[i]); }
 
+// One lane per 8 output channels (one 16-byte store); the sample gather and the divisions are per row, not per element
+// (the element-per-lane form spent its time in 64-bit div / mod: 10.8 us for a 512 x 28 x 28 batch).
 template <typename T>
 __global__ void pad_channels_kernel(const T* __restrict__ src, const long* __restrict__ index,
                                     bf16_t* __restrict__ dst, long rows, int pix_per_sample, int c_in,
                                     int c_true, int Cp, float scale) {
-    const long total = rows * Cp;
+    const int cg = Cp / 8;
+    const long total = rows * cg;
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        int c = (int)(i % Cp);
-        long r = i / Cp;
-        float v = 0.f;
-        if (c < c_true) {
-            long sr = r;
-            if (index) { long smp = r / pix_per_sample; sr = index[smp] * pix_per_sample + (r - smp * pix_per_sample); }
-            v = load_as_float<T>(src, sr * c_in + (c_in == 1 ? 0 : c)) * scale;
+        const long r = cg == 1 ? i : i / cg;
+        const int g = cg == 1 ? 0 : (int)(i - r * cg);
+        long sr = r;
+        if (index) {
+            const long smp = rows < (1L << 31) ? (long)((unsigned)r / (unsigned)pix_per_sample) : r / pix_per_sample;
+            sr = index[smp] * pix_per_sample + (r - smp * pix_per_sample);
         }
-        dst[i] = f2bf(v);
+        float f[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int c = g * 8 + j;
+            f[j] = c < c_true ? load_as_float<T>(src, sr * c_in + (c_in == 1 ? 0 : c)) * scale : 0.f;
+        }
+        ((uint4*)dst)[i] = pack8(f);
     }
 }
 
 // dtype: 0 = fp32, 1 = u8, 2 = bf16.  `index` (optional, int64 per sample) gathers samples.
 DDL_API void ddl_pad_channels(const void* src, int dtype, const long* index, void* dst, long rows,
                               int pix_per_sample, int c_in, int c_true, int Cp, float scale, hipStream_t s) {
-    long total = rows * Cp;
+    long total = rows * (Cp / 8);
     int grid = ew_grid(total);
     if (dtype == 0)
         pad_channels_kernel<float><<<grid, EW_BLOCK, 0, s>>>((const float*)src, index, (bf16_t*)dst, rows,
