@@ -244,7 +244,8 @@ struct TapConvArgs {
     int r_prev_act; float r_prev_alpha; int red_off;
 };
 
-template <int NT, bool SLOW, int RED>
+// PACT (RED 5): the activation in front of the reduced BatchNorm as a compile-time code (-1: a.r_prev_act at run time)
+template <int NT, bool SLOW, int RED, int PACT = -1>
 __global__ __launch_bounds__(256) void tapconv_1ch_kernel(const TapConvArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     bf16_t* sI = (bf16_t*)smem;                 // [PH][PW] zero-haloed plane
@@ -352,9 +353,9 @@ __global__ __launch_bounds__(256) void tapconv_1ch_kernel(const TapConvArgs a) {
 #pragma unroll
         for (int t = 0; t < NT; ++t)
             acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[t], xf, (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
-        // one activation dispatch per fragment (common.h: a run-time switch per element is a branch chain per element):
-        // the slow epilogue's own activation, or -- RED 5 -- the activation in front of the BatchNorm being reduced
-        auto tile = [&](auto KA, auto KP) {
+        // one activation dispatch per fragment for the slow epilogue (common.h: a run-time switch per element is a
+        // branch chain per element); the RED 5 activation is a template parameter (a dispatch in here cost 38 registers)
+        auto tile = [&](auto KA) {
             bf16_t* dst = a.y + ((size_t)b * npix + p) * a.Np;
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
@@ -379,7 +380,7 @@ __global__ __launch_bounds__(256) void tapconv_1ch_kernel(const TapConvArgs a) {
                             rs[0][t][e] += g;
                             rs[1][t][e] += g * (xv[e] - rmu[t][e]) * ris[t][e];
                             if (RED == 5) {
-                                const float ad = act_grad_y_k<decltype(KP)::value>(xv[e], a.r_prev_act, a.r_prev_alpha);
+                                const float ad = act_grad_y_k<PACT>(xv[e], a.r_prev_act, a.r_prev_alpha);
                                 rs[RED - 3][t][e] += ad * g;
                                 rs[RED - 2][t][e] += ad * xv[e];
                                 rs[RED - 1][t][e] += ad;
@@ -390,10 +391,8 @@ __global__ __launch_bounds__(256) void tapconv_1ch_kernel(const TapConvArgs a) {
             }
         };
         if (p < npix) {
-            using Dyn = std::integral_constant<int, -1>;
-            if (RED == 5) act_switch(a.r_prev_act, [&](auto KP) { tile(Dyn{}, KP); });
-            else if (SLOW) act_switch(act, [&](auto KA) { tile(KA, Dyn{}); });
-            else tile(Dyn{}, Dyn{});
+            if (SLOW) act_switch(act, tile);
+            else tile(std::integral_constant<int, -1>{});
         }
     }
     if (RED) {
@@ -452,9 +451,11 @@ DDL_API int ddl_tapconv_1ch(const void* img, const void* w, const float* bias, v
     if (smem > 64 * 1024 || (long)OH * OW >= (1L << 21) || (long)H * W >= (1L << 21)) return 1;
     const bool fast = act == ACT_LINEAR || act == ACT_RELU || act == ACT_LEAKY;
     if (rx && !fast) return 1;
+#define TC_CALL5(A) tapconv_1ch_kernel<TC_NT, false, 5, A><<<B, 256, smem, s>>>(a)
+#define TC_RED5(NT_) { constexpr int TC_NT = NT_; ACT1_DISPATCH(r_prev_act, TC_CALL5); }
 #define TC_CASE(NT_) \
     if (NT == NT_) { \
-        if (rx && r_sums == 5) tapconv_1ch_kernel<NT_, false, 5><<<B, 256, smem, s>>>(a); \
+        if (rx && r_sums == 5) { TC_RED5(NT_) } \
         else if (rx) tapconv_1ch_kernel<NT_, false, 2><<<B, 256, smem, s>>>(a); \
         else if (fast) tapconv_1ch_kernel<NT_, false, 0><<<B, 256, smem, s>>>(a); \
         else tapconv_1ch_kernel<NT_, true, 0><<<B, 256, smem, s>>>(a); \
@@ -462,5 +463,7 @@ DDL_API int ddl_tapconv_1ch(const void* img, const void* w, const float* bias, v
     }
     TC_CASE(1) TC_CASE(2) TC_CASE(3) TC_CASE(4)
 #undef TC_CASE
+#undef TC_RED5
+#undef TC_CALL5
     return 1;
 }
