@@ -1223,7 +1223,12 @@ def _igemm_call(src, wgt, bias, dst, g, mode, B, Hs, Ws, Cs, Hd, Wd, Nd, Nw, ss,
             for kind, pl in cands:
                 fn = (lambda pl=pl: (_run_igemm(src, wgt, bias, dst, g, mode, *tail, tile=pl), _mul_inplace(dst, mul))) \
                     if kind == "igemm" else (lambda pl=pl: _run_pconv(pl, src, wgt, bias, dst, g, *tail, mul=mul))
-                timed.append((_time_us(fn), kind, pl))
+                t_us = _time_us(fn)
+                if kind == "igemm" and stats_out is not None and PCONV_STATS and mul is None:
+                    # a BatchNorm behind this layer: pconv's epilogue emits its statistics, the gather kernel leaves
+                    # them to a pass over the output (launch + streaming read)
+                    t_us += 4.0 + B * Hd * Wd * Nd * 2 / 3.0e6
+                timed.append((t_us, kind, pl))
             timed.sort(key=lambda t: t[0])
             choice = (timed[0][1], timed[0][2])
             _record_choice(kstr, ["igemm", choice[1]] if choice[0] == "igemm" else
