@@ -73,6 +73,12 @@ __device__ __forceinline__ float act_grad_y(float y, int kind, float alpha) {
     }
 }
 
+// linear / relu / leaky as ONE branch-free form: x > 0 ? x : slope * x (+ 0 so that relu gives +0, as fmaxf does)
+__device__ __forceinline__ float act_slope(int kind, float alpha) {
+    return kind == ACT_RELU ? 0.f : (kind == ACT_LEAKY ? alpha : 1.f);
+}
+__device__ __forceinline__ float act_apply_slope(float x, float slope) { return x > 0.f ? x : slope * x + 0.f; }
+
 // The switches above cost a chain of scalar compares and branches PER ELEMENT when `kind` is a run-time value (131
 // s_cbranch in bn_apply_cs for 8 elements per lane: the streaming kernels were branch-bound, not bandwidth-bound).
 // Kernels therefore take their activation codes as template parameters -- act_apply_k<K> folds the switch at compile

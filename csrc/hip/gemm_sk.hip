@@ -93,6 +93,7 @@ __global__ __launch_bounds__(256) void gemm_sk_kernel(const GemmSkArgs a) {
         // ---- bias + activation (switch hoisted), padding channels forced to zero
         const int act = a.act;
         const float alpha = a.alpha;
+        const float slope = act_slope(act, alpha);
         auto epi = [&](auto KA) {
 #pragma unroll
             for (int t = 0; t < NT; ++t)
@@ -102,8 +103,7 @@ __global__ __launch_bounds__(256) void gemm_sk_kernel(const GemmSkArgs a) {
                     for (int e = 0; e < 4; ++e) {
                         float v = acc[t][j][e] + bv[t][e];
                         if (SLOW) v = act_apply_k<decltype(KA)::value>(v, act, alpha);
-                        else if (act == ACT_RELU) v = fmaxf(v, 0.f);
-                        else if (act == ACT_LEAKY) v = v > 0.f ? v : alpha * v;
+                        else v = act_apply_slope(v, slope);
                         acc[t][j][e] = (n0 + 16 * t + 4 * fq + e < a.Nw) ? v : 0.f;
                     }
         };

@@ -307,6 +307,7 @@ __global__ __launch_bounds__(256) void tapconv_1ch_kernel(const TapConvArgs a) {
     const float invOW = 1.0f / (float)a.OW;
     const int act = a.act;
     const float alpha = a.alpha;
+    const float slope = act_slope(act, alpha);
     float rs[RED ? RED : 1][NT][4], rmu[RED ? NT : 1][4], ris[RED ? NT : 1][4];
     if (RED) {
 #pragma unroll
@@ -364,8 +365,7 @@ __global__ __launch_bounds__(256) void tapconv_1ch_kernel(const TapConvArgs a) {
                 for (int e = 0; e < 4; ++e) {
                     float x = acc[t][e] + bv[t][e];
                     if (SLOW) x = act_apply_k<decltype(KA)::value>(x, act, alpha);
-                    else if (act == ACT_RELU) x = fmaxf(x, 0.f);
-                    else if (act == ACT_LEAKY) x = x > 0.f ? x : alpha * x;
+                    else x = act_apply_slope(x, slope);
                     v[e] = (16 * t + 4 * fq + e < a.n_lim) ? x : 0.f;
                 }
                 if (16 * t + 4 * fq < a.Np) {
