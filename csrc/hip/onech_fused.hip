@@ -138,10 +138,45 @@ __global__ __launch_bounds__(256) void tapfold_kernel(const TapFoldArgs a) {
     // ---- fold (identical to col2im_1ch_kernel)
     const float b0 = a.bias ? a.bias[0] : 0.f;
     const float invW = 1.0f / (float)a.W;
+    // Branch-free fold for the compile-time strides with kernels up to 5x5 (stride 1) / 6x6 (stride 2): every candidate
+    // tap is read (clamped address) and masked, rows / columns validated once per pixel -- the generic loop below is a
+    // divergent branch per tap with a dependent 2-byte LDS read behind it (the fold was 40 us of the step's two
+    // tapfold launches).  Same taps in the same order: same bits.
+    constexpr bool FASTS = (SH == 1 && SW == 1) || (SH == 2 && SW == 2);
+    const bool fast_fold = FASTS && a.dh == 1 && a.dw == 1 && a.KH <= (SH == 1 ? 5 : 6) && a.KW <= (SW == 1 ? 5 : 6);
     auto fold = [&](auto KA) {
     for (int i = tid; i < (h1 - h0) * a.W; i += 256) {
         int hl = tf_fdiv(i, invW), w = i - hl * a.W, h = h0 + hl;
         float acc = 0.f;
+        if (FASTS && fast_fold) {
+            constexpr int NI = SH == 1 ? 5 : 3, ST = SH == 1 ? 1 : 2;
+            const int hh = h + a.pt, ww = w + a.pl;
+            const int ph = ST == 1 ? 0 : (hh & 1), pw = ST == 1 ? 0 : (ww & 1);
+            const int ohb = (ST == 1 ? hh : (hh >> 1)) - oh_lo, owb = ST == 1 ? ww : (ww >> 1);
+            const int nz = oh_hi - oh_lo + 1;
+            int roff[NI], coff[NI];
+            bool rv[NI], cv[NI];
+#pragma unroll
+            for (int q = 0; q < NI; ++q) {
+                const int kh = ph + ST * q, ol = ohb - q;
+                rv[q] = (kh < a.KH) & ((unsigned)ol < (unsigned)nz);
+                roff[q] = ol * a.OW * TF_ZP + kh * a.KW * 2;
+                const int kw = pw + ST * q, oc = owb - q;
+                cv[q] = (kw < a.KW) & ((unsigned)oc < (unsigned)a.OW);
+                coff[q] = oc * TF_ZP + kw * 2;
+            }
+            float tv[NI * NI];
+#pragma unroll
+            for (int q = 0; q < NI; ++q)
+#pragma unroll
+                for (int r = 0; r < NI; ++r) {
+                    const bool ok = rv[q] & cv[r];
+                    const bf16_t z = *(const bf16_t*)(sZ + (ok ? roff[q] + coff[r] : 0));
+                    tv[q * NI + r] = ok ? bf2f(z) : 0.f;
+                }
+#pragma unroll
+            for (int t = 0; t < NI * NI; ++t) acc += tv[t];
+        } else
         for (int kh = 0; kh < a.KH; ++kh) {
             int th = h + a.pt - kh * a.dh;
             if (th < 0 || th % sh) continue;
