@@ -44,6 +44,9 @@ struct PConvArgs {
     // part[2][Nd][gridDim.x] like the column-reduction kernels' partials -- the BatchNorm that follows reads
     // its batch statistics from here instead of making a pass over the output tensor.
     float* stats;
+    // MULY instantiation: dst = bf16(bf16(conv) * (y > 0 ? 1 : mul_slope)) -- linear / relu / leaky of the layer below,
+    // the same two roundings as the separate act_bwd pass (bit-identical)
+    const bf16_t* mul_y; float mul_slope;
     // AFFINE instantiation: an inference-phase BatchNorm right behind this layer, folded into the epilogue:
     // out = act(conv + bias) * k + (beta - moving_mean * k), k = gamma * rsqrt(moving_var + eps)
     const float* bn_gamma; const float* bn_beta; const float* bn_mean; const float* bn_var; float bn_eps;
@@ -63,10 +66,11 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 // SLOW = the activation is one of the transcendental ones (sigmoid / softplus / tanh / softsign /
 // tanh01): only that instantiation carries their (fully unrolled) code.
-// EPI: 0 = plain epilogue, 1 = STATS (batch-statistics partials for a following BN), 2 = AFFINE (inference BN folded in)
+// EPI: 0 = plain epilogue, 1 = STATS (batch-statistics partials for a following BN), 2 = AFFINE (inference BN folded in),
+// 3 = MULY (result *= act'(y) of the layer below, y laid out like dst: the activation backward fused into an input gradient)
 template <int BN, int FR, bool SLOW, int EPI>
 __global__ __launch_bounds__(256, (BN * FR >= 512 ? 1 : 2)) void pconv_kernel(const PConvArgs a) {
-    constexpr bool STATS = EPI == 1, AFFINE = EPI == 2;
+    constexpr bool STATS = EPI == 1, AFFINE = EPI == 2, MULY = EPI == 3;
     constexpr int NT = BN / 16;                        // 16-channel MFMA tiles per wave
     constexpr int RW = (BN * 8 + 255) / 256;           // 16-B weight units staged per thread per stage
     constexpr int PASS = 4 * FR * 16;                  // rows per pass (4 waves x FR fragments x 16 px)
@@ -338,6 +342,27 @@ __global__ __launch_bounds__(256, (BN * FR >= 512 ? 1 : 2)) void pconv_kernel(co
 #pragma unroll
                             for (int e = 0; e < 4; ++e) acc[t][j][e] = fmaf(acc[t][j][e], bnk[t][e], bnh[t][e]);
                 }
+                // MULY: this lane's y vectors of every fragment it will store, fetched now so that their latency is
+                // covered by the transposes (fetched inside the store loop they cost what the separate pass cost)
+                constexpr int UPL = (16 * (BN / 8) + 63) / 64;      // 16-byte store units per lane per fragment
+                uint4 ymul[MULY ? FR : 1][MULY ? UPL : 1];
+                if (MULY) {
+#pragma unroll
+                    for (int j = 0; j < FR; ++j)
+#pragma unroll
+                        for (int k = 0; k < UPL; ++k) {
+                            const int u = lane + 64 * k;
+                            const int px = u / (BN / 8), c8 = u - px * (BN / 8);
+                            const int m = ms + (wave * FR + j) * 16 + px;
+                            const int mm = m < Mloc ? m : 0;
+                            const int img = fdiv(mm, inv_rows), rem = mm - img * per_img_rows;
+                            const int il = fdiv(rem, cd.inv_Wc), jl = rem - il * cd.Wc;
+                            const int b = b0 + img;
+                            const bool ok = u < 16 * (BN / 8) && m < Mloc && b < a.B && n0 + c8 * 8 < a.Nd;
+                            const long pix = (long)(b * a.Hd + cd.ph + a.sdh * (i0 + il)) * a.Wd + cd.pw + a.sdw * jl;
+                            ymul[j][k] = ok ? *(const uint4*)(a.mul_y + pix * a.Nd + n0 + c8 * 8) : make_uint4(0, 0, 0, 0);
+                        }
+                }
                 // channels >= Nw (padding lanes) must be exactly zero
                 const int nlim = a.Nw - n0 - 4 * fq;       // channel 16t + e is real iff 16t + e < nlim
 #pragma unroll
@@ -373,12 +398,24 @@ __global__ __launch_bounds__(256, (BN * FR >= 512 ? 1 : 2)) void pconv_kernel(co
                     __builtin_amdgcn_wave_barrier();
                     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 #pragma unroll
-                    for (int u = lane; u < 16 * (BN / 8); u += 64) {
+                    for (int k = 0; k < UPL; ++k) {
+                        const int u = lane + 64 * k;
+                        if (u >= 16 * (BN / 8)) break;
                         int px = u / (BN / 8), c8 = u - px * (BN / 8);
                         int p = sPix[px];
                         int n = n0 + c8 * 8;
-                        if (p >= 0 && n < a.Nd)
-                            *(uint4*)(a.dst + (long)p * a.Nd + n) = *(const uint4*)(sE + px * EROW + c8 * 16);
+                        if (p >= 0 && n < a.Nd) {
+                            uint4 o = *(const uint4*)(sE + px * EROW + c8 * 16);
+                            if (MULY) {
+                                float f[8], yy[8];
+                                unpack8(o, f);
+                                unpack8(ymul[j][k], yy);
+#pragma unroll
+                                for (int e = 0; e < 8; ++e) f[e] *= yy[e] > 0.f ? 1.f : a.mul_slope;
+                                o = pack8(f);
+                            }
+                            *(uint4*)(a.dst + (long)p * a.Nd + n) = o;
+                        }
                     }
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                     __builtin_amdgcn_wave_barrier();
@@ -443,6 +480,8 @@ static int launch_pconv(PConvArgs& a, int units, size_t smem, hipStream_t s) {
     const bool fast = a.act == ACT_LINEAR || a.act == ACT_RELU || a.act == ACT_LEAKY;
     if (a.stats)
         return fast ? launch_pconv2<BN, FR, false, 1>(a, units, smem, s) : launch_pconv2<BN, FR, true, 1>(a, units, smem, s);
+    if (a.mul_y)
+        return fast ? launch_pconv2<BN, FR, false, 3>(a, units, smem, s) : -4;
     if (a.bn_gamma)
         return fast ? launch_pconv2<BN, FR, false, 2>(a, units, smem, s) : launch_pconv2<BN, FR, true, 2>(a, units, smem, s);
     return fast ? launch_pconv2<BN, FR, false, 0>(a, units, smem, s) : launch_pconv2<BN, FR, true, 0>(a, units, smem, s);
@@ -464,7 +503,7 @@ DDL_API int ddl_pconv(const void* src, const void* wgt, const float* bias, void*
                       int IMG, int BR, int bands, int omin_h, int omin_w, int PH, int PW, int pitch, int BN, int FR,
                       float* stats, const float* bn_gamma, const float* bn_beta, const float* bn_mean,
                       const float* bn_var, float bn_eps, const float* in_scale, const float* in_shift,
-                      int in_group_rows, int in_ctrue, hipStream_t s) {
+                      int in_group_rows, int in_ctrue, const void* mul_y, float mul_slope, hipStream_t s) {
     if (Cs % 8 != 0 || Cs <= 0 || Nd <= 0 || Nd % 8 != 0 || n_classes <= 0 || B <= 0 || IMG <= 0 || BR <= 0) return -1;
     if (pitch % 16 != 0 || pitch < Cs * 2) return -1;
     if ((long)B * Hs * Ws * Cs >= (1L << 31) || (long)B * Hd * Wd * Nd >= (1L << 31)) return -3;
@@ -474,6 +513,8 @@ DDL_API int ddl_pconv(const void* src, const void* wgt, const float* bias, void*
     a.classes = (const PClass*)classes; a.ktab = (const int2*)ktab;
     a.stats = stats;
     if (stats && bn_gamma) return -1;
+    if (mul_y && (stats || bn_gamma)) return -1;
+    a.mul_y = (const bf16_t*)mul_y; a.mul_slope = mul_slope;
     a.bn_gamma = bn_gamma; a.bn_beta = bn_beta; a.bn_mean = bn_mean; a.bn_var = bn_var; a.bn_eps = bn_eps;
     if (in_scale && (!in_shift || in_group_rows <= 0 || Cs > 2048 || B >= (1 << 23))) return -1;
     a.in_scale = in_scale; a.in_shift = in_shift; a.in_group_rows = in_scale ? in_group_rows : 1; a.in_ctrue = in_ctrue;

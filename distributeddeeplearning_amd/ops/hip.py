@@ -83,7 +83,7 @@ _philox = _sig("ddl_philox_uniform", None, vp, cl, vp, cf, cf, vp)
 _igemm = _sig("ddl_igemm_conv", ci, vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci,
               ci, ci, ci, ci, cf, ci, ci, vp, vp)
 _pconv = _sig("ddl_pconv", ci, vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, cf,
-              ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, vp, vp, vp, vp, vp, cf, vp, vp, ci, ci, vp)
+              ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, vp, vp, vp, vp, vp, cf, vp, vp, ci, ci, vp, cf, vp)
 _pconv_lds = _sig("ddl_pconv_lds_bytes", ci, ci, ci, cl)
 _wgrad_ksplit = _sig("ddl_wgrad_ksplit", ci, ci, ci, ci, ci)
 _wgrad = _sig("ddl_conv_wgrad", ci, vp, vp, vp, vp, cl, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci,
@@ -1080,6 +1080,9 @@ def _pconv_units(pl, B):
     return -(-B // pl["IMG"]) * pl["bands"]
 
 
+PCONV_MULY = os.environ.get("DDL_PCONV_MULY", "1") == "1"
+
+
 def _run_pconv(pl, src, wgt, bias, dst, g, B, Hs, Ws, Cs, Hd, Wd, Nd, Nw, ss, sd, act, alpha, mul=None, stats=None,
                bn_infer=None, in_affine=None):
     """`stats`: fp32 tensor of 2 * Nd * units elements that receives per-block column sums / sums of squares
@@ -1092,6 +1095,14 @@ def _run_pconv(pl, src, wgt, bias, dst, g, B, Hs, Ws, Cs, Hd, Wd, Nd, Nw, ss, sd
         for t, n in ((gamma, "gamma"), (beta, "beta"), (mm, "moving_mean"), (mv, "moving_var")):
             _chk_f32(t, Nw, n)
         bg, bb, bm, bvv = gamma.data_ptr(), beta.data_ptr(), mm.data_ptr(), mv.data_ptr()
+    # act'(y) of the layer below for linear / relu / leaky: its own epilogue instantiation, y prefetched ahead of the
+    # transposes (fetched inside the store loop, and with a run-time activation switch per element, the fusion once
+    # cost as much as the separate pass it replaced); other activations, or a statistics / BatchNorm epilogue: own pass
+    my, ms = None, 0.0
+    if (PCONV_MULY and mul is not None and stats is None and bn_infer is None and mul[1] in (None, "linear", "relu", "leaky")
+            and ACT_CODE[act] in (0, 1, 6) and tuple(mul[0].shape) == tuple(dst.shape) and mul[0].is_contiguous()):
+        my = mul[0].data_ptr()
+        ms = 1.0 if mul[1] in (None, "linear") else (0.0 if mul[1] == "relu" else float(mul[2]))
     isc = ish = None
     igr, ict = 1, Cs
     if in_affine is not None:           # (scale, shift, (images per group,), c_true): [groups][Cs] fp32 rows
@@ -1104,13 +1115,12 @@ def _run_pconv(pl, src, wgt, bias, dst, g, B, Hs, Ws, Cs, Hd, Wd, Nd, Nw, ss, sd
                 pl["ktab"].data_ptr(), pl["ncls"], pl["nst"], B, Hs, Ws, Cs, Hd, Wd, Nd, Nw, ss[0], ss[1],
                 sd[0], sd[1], g.KH * g.KW, ACT_CODE[act], alpha, pl["IMG"], pl["BR"], pl["bands"],
                 pl["omin_h"], pl["omin_w"], pl["PH"], pl["PW"], pl["pitch"], pl["BN"], pl["FR"], _p(stats), bg, bb, bm,
-                bvv, beps, isc, ish, igr, ict, _stream())
+                bvv, beps, isc, ish, igr, ict, my, ms, _stream())
     if rc != 0:
         raise ValueError(f"pconv rejected its plan (rc={rc}): {g} B={B} "
                          f"{ {k: v for k, v in pl.items() if k not in ('classes', 'ktab')} }")
-    # measured: act'(y) inside pconv's store loop costs as much as the separate pass it replaces (the y load sits
-    # between the LDS transpose and the store) and slows every other pconv launch by ~1 %: kept as its own pass
-    _mul_inplace(dst, mul)
+    if my is None:
+        _mul_inplace(dst, mul)
 
 
 def _run_igemm(src, wgt, bias, dst, g, mode, B, Hs, Ws, Cs, Hd, Wd, Nd, Nw, ss, sd, act, alpha, tile=None):
