@@ -36,6 +36,9 @@ struct ConvArgs {
     int act; float alpha;
     int max_taps;
     int ksplit; float* slab;   // split-K (single-class problems, Dense with huge K): fp32 partials [split][M][Nd]
+    // optional: dst = bf16(bf16(conv) * (y > 0 ? 1 : mul_slope)), y laid out like dst -- act'(y) of the layer below
+    // (linear / relu / leaky) fused into an input gradient; the same two roundings as the separate act_bwd pass
+    const bf16_t* mul_y; float mul_slope;
 };
 
 #define BK 64                 // K elements per LDS stage
@@ -225,6 +228,32 @@ __global__ __launch_bounds__(256) void igemm_conv_kernel(const ConvArgs a) {
             }
     });
     const bool vec_ok = (a.Nd & 3) == 0;
+    if (a.mul_y && vec_ok) {            // uniform.  All y loads first (one round trip), then the multiplies
+        uint2 yv[NT][4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int m = m0 + wm * 64 + 16 * j + fr;
+            const int mm = m < cd.M ? m : 0;
+            const int b = mm / HW, rem = mm - b * HW;
+            const int i = rem / cd.Wc, jj = rem - i * cd.Wc;
+            const long pix = ((long)b * a.Hd + cd.ph + (long)a.sdh * i) * a.Wd + cd.pw + (long)a.sdw * jj;
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const int nb = n0 + wn * WN + 16 * t + 4 * fq;
+                yv[t][j] = (m < cd.M && nb < a.Nd) ? *(const uint2*)(a.mul_y + pix * a.Nd + nb) : make_uint2(0, 0);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const float y4[4] = {__uint_as_float(yv[t][j].x << 16), __uint_as_float(yv[t][j].x & 0xffff0000u),
+                                     __uint_as_float(yv[t][j].y << 16), __uint_as_float(yv[t][j].y & 0xffff0000u)};
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    acc[t][j][e] = bf2f(f2bf(acc[t][j][e])) * (y4[e] > 0.f ? 1.f : a.mul_slope);
+            }
+    }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         int m = m0 + wm * 64 + 16 * j + fr;
@@ -420,6 +449,32 @@ __global__ __launch_bounds__(256) void igemm_conv_kernel_k32(const ConvArgs a) {
             }
     });
     const bool vec_ok = (a.Nd & 3) == 0;
+    if (a.mul_y && vec_ok) {            // uniform.  All y loads first (one round trip), then the multiplies
+        uint2 yv[NT][4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int m = m0 + wm * 64 + 16 * j + fr;
+            const int mm = m < cd.M ? m : 0;
+            const int b = mm / HW, rem = mm - b * HW;
+            const int i = rem / cd.Wc, jj = rem - i * cd.Wc;
+            const long pix = ((long)b * a.Hd + cd.ph + (long)a.sdh * i) * a.Wd + cd.pw + (long)a.sdw * jj;
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const int nb = n0 + wn * WN + 16 * t + 4 * fq;
+                yv[t][j] = (m < cd.M && nb < a.Nd) ? *(const uint2*)(a.mul_y + pix * a.Nd + nb) : make_uint2(0, 0);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const float y4[4] = {__uint_as_float(yv[t][j].x << 16), __uint_as_float(yv[t][j].x & 0xffff0000u),
+                                     __uint_as_float(yv[t][j].y << 16), __uint_as_float(yv[t][j].y & 0xffff0000u)};
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    acc[t][j][e] = bf2f(f2bf(acc[t][j][e])) * (y4[e] > 0.f ? 1.f : a.mul_slope);
+            }
+    }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         int m = m0 + wm * 64 + 16 * j + fr;
@@ -493,7 +548,8 @@ static int launch_igemm(const ConvArgs& a, int n_classes, int max_M, hipStream_t
 DDL_API int ddl_igemm_conv(const void* src, const void* wgt, const float* bias, void* dst, const void* classes,
                            const void* taps, int n_classes, int max_M, int max_taps, int B, int Hs, int Ws,
                            int Cs, int Hd, int Wd, int Nd, int Nw, int ssh, int ssw, int sdh, int sdw, int Ttot,
-                           int act, float alpha, int tile, int ksplit, float* slab, hipStream_t s) {
+                           int act, float alpha, int tile, int ksplit, float* slab, const void* mul_y,
+                           float mul_slope, hipStream_t s) {
     if (Cs % 8 != 0 || Cs <= 0 || Nd <= 0 || n_classes <= 0 || max_M <= 0) return -1;
     if ((long)B * Hs * Ws * Cs >= (1L << 31) || (long)B * Hd * Wd * Nd >= (1L << 31) ||
         (long)Nw * Ttot * Cs >= (1L << 31)) return -3;
@@ -503,6 +559,8 @@ DDL_API int ddl_igemm_conv(const void* src, const void* wgt, const float* bias, 
     a.B = B; a.Hs = Hs; a.Ws = Ws; a.Cs = Cs; a.Hd = Hd; a.Wd = Wd; a.Nd = Nd; a.Nw = Nw;
     a.ssh = ssh; a.ssw = ssw; a.sdh = sdh; a.sdw = sdw; a.Ttot = Ttot; a.act = act; a.alpha = alpha;
     a.max_taps = max_taps;
+    a.mul_y = (ksplit > 1 || (Nd & 3)) ? nullptr : (const bf16_t*)mul_y; a.mul_slope = mul_slope;
+    if (mul_y && !a.mul_y) return -5;       // the caller runs the separate pass
     a.ksplit = 1; a.slab = nullptr;
     if (ksplit > 1) {
         // split-K needs one class whose destination pixel index equals the row index (fprop, unit dst stride,

@@ -81,7 +81,7 @@ _relayout_both = _sig("ddl_relayout_both", None, vp, vp, vp, ci, vp, vp, ci, cl,
 _gemm_sk = _sig("ddl_gemm_sk", ci, vp, vp, vp, vp, cl, ci, ci, ci, ci, cf, vp)
 _philox = _sig("ddl_philox_uniform", None, vp, cl, vp, cf, cf, vp)
 _igemm = _sig("ddl_igemm_conv", ci, vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci,
-              ci, ci, ci, ci, cf, ci, ci, vp, vp)
+              ci, ci, ci, ci, cf, ci, ci, vp, vp, cf, vp)
 _pconv = _sig("ddl_pconv", ci, vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, cf,
               ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, vp, vp, vp, vp, vp, cf, vp, vp, ci, ci, vp, cf, vp)
 _pconv_lds = _sig("ddl_pconv_lds_bytes", ci, ci, ci, cl)
@@ -1081,6 +1081,7 @@ def _pconv_units(pl, B):
 
 
 PCONV_MULY = os.environ.get("DDL_PCONV_MULY", "1") == "1"
+IGEMM_MULY = os.environ.get("DDL_IGEMM_MULY", "1") == "1"
 
 
 def _run_pconv(pl, src, wgt, bias, dst, g, B, Hs, Ws, Cs, Hd, Wd, Nd, Nw, ss, sd, act, alpha, mul=None, stats=None,
@@ -1123,7 +1124,16 @@ def _run_pconv(pl, src, wgt, bias, dst, g, B, Hs, Ws, Cs, Hd, Wd, Nd, Nw, ss, sd
         _mul_inplace(dst, mul)
 
 
-def _run_igemm(src, wgt, bias, dst, g, mode, B, Hs, Ws, Cs, Hd, Wd, Nd, Nw, ss, sd, act, alpha, tile=None):
+def _mul_slope(mul, dst):
+    """(y pointer, slope) when `mul` = act'(y) of a linear / relu / leaky layer can ride in a conv epilogue, else None."""
+    if (IGEMM_MULY and mul is not None and mul[1] in (None, "linear", "relu", "leaky")
+            and tuple(mul[0].shape) == tuple(dst.shape) and mul[0].is_contiguous()):
+        return mul[0].data_ptr(), (1.0 if mul[1] in (None, "linear") else (0.0 if mul[1] == "relu" else float(mul[2])))
+    return None
+
+
+def _run_igemm(src, wgt, bias, dst, g, mode, B, Hs, Ws, Cs, Hd, Wd, Nd, Nw, ss, sd, act, alpha, tile=None, mul=None):
+    """`mul` = (y, act, alpha): result *= act'(y) -- in the kernel's epilogue for linear / relu / leaky, else as a pass."""
     ct, tt, ncls, maxM, maxT = _tables(g, mode, B, src.device)
     # split-K: a Dense / 1x1 fprop with few output tiles and a very long reduction (model0's 86528 -> 10
     # head at batch 512 is TWO 256-row blocks walking 2704 k-steps each) is spread over the K axis
@@ -1135,12 +1145,21 @@ def _run_igemm(src, wgt, bias, dst, g, mode, B, Hs, Ws, Cs, Hd, Wd, Nd, Nw, ss, 
             ksplit = max(1, min(nsteps // 8, 512 // blocks))
             if ksplit > 1:
                 slab = torch.empty(ksplit * maxM * Nd, dtype=torch.float32, device=src.device)
+    _ms = _mul_slope(mul, dst) if ACT_CODE[act] in (0, 1, 6) else None
     rc = _igemm(src.data_ptr(), wgt.data_ptr(), _p(bias), dst.data_ptr(), ct.data_ptr(), tt.data_ptr(), ncls,
                 maxM, maxT, B, Hs, Ws, Cs, Hd, Wd, Nd, Nw, ss[0], ss[1], sd[0], sd[1], g.KH * g.KW,
                 ACT_CODE[act], alpha, IGEMM_TILE if tile is None else tile, ksplit if slab is not None else 1,
-                _p(slab), _stream())
+                _p(slab), *( (None, 0.0) if _ms is None else _ms ), _stream())
+    if rc == -5:                        # no fused multiply for this shape: plain launch, separate pass
+        _ms = None
+        rc = _igemm(src.data_ptr(), wgt.data_ptr(), _p(bias), dst.data_ptr(), ct.data_ptr(), tt.data_ptr(), ncls,
+                    maxM, maxT, B, Hs, Ws, Cs, Hd, Wd, Nd, Nw, ss[0], ss[1], sd[0], sd[1], g.KH * g.KW,
+                    ACT_CODE[act], alpha, IGEMM_TILE if tile is None else tile, ksplit if slab is not None else 1,
+                    _p(slab), None, 0.0, _stream())
     if rc != 0:
         raise ValueError(f"igemm_conv rejected the problem (rc={rc}): {g} mode={mode} B={B}")
+    if _ms is None:
+        _mul_inplace(dst, mul)
 
 
 AUTOTUNE_COLD = os.environ.get("DDL_AUTOTUNE_COLD", "0") == "1"
@@ -1204,8 +1223,7 @@ def _igemm_call(src, wgt, bias, dst, g, mode, B, Hs, Ws, Cs, Hd, Wd, Nd, Nw, ss,
     if CONV_IMPL != "pconv":
         if in_affine is not None:
             src = materialise()
-        _run_igemm(src, wgt, bias, dst, g, mode, *tail)
-        _mul_inplace(dst, mul)
+        _run_igemm(src, wgt, bias, dst, g, mode, *tail, mul=mul)
         _done()
         return
     slow = ACT_CODE[act] not in (0, 1, 6)
@@ -1231,7 +1249,7 @@ def _igemm_call(src, wgt, bias, dst, g, mode, B, Hs, Ws, Cs, Hd, Wd, Nd, Nw, ss,
                     [("pconv", pl) for pl in _pconv_candidates(g, mode, B, Cs, Nd, ss, src.device)]
             timed = []
             for kind, pl in cands:
-                fn = (lambda pl=pl: (_run_igemm(src, wgt, bias, dst, g, mode, *tail, tile=pl), _mul_inplace(dst, mul))) \
+                fn = (lambda pl=pl: _run_igemm(src, wgt, bias, dst, g, mode, *tail, tile=pl, mul=mul)) \
                     if kind == "igemm" else (lambda pl=pl: _run_pconv(pl, src, wgt, bias, dst, g, *tail, mul=mul))
                 t_us = _time_us(fn)
                 if kind == "igemm" and stats_out is not None and PCONV_STATS and mul is None:
@@ -1266,8 +1284,7 @@ def _igemm_call(src, wgt, bias, dst, g, mode, B, Hs, Ws, Cs, Hd, Wd, Nd, Nw, ss,
     else:
         if in_affine is not None:
             src = materialise()
-        _run_igemm(src, wgt, bias, dst, g, mode, *tail, tile=choice[1])
-        _mul_inplace(dst, mul)
+        _run_igemm(src, wgt, bias, dst, g, mode, *tail, tile=choice[1], mul=mul)
     _done()
 
 

@@ -94,6 +94,36 @@ def test_conv_fprop_dgrad_wgrad(hip, case, B):
     close(dwB[..., :O], dw_ref.permute(3, 1, 2, 0), rtol=1e-2)
 
 
+@pytest.mark.parametrize("impl", ["pconv", "igemm"])
+@pytest.mark.parametrize("prev", ["relu", "leaky", "linear", "tanh"])
+def test_dgrad_fused_act_grad_is_bit_identical_to_the_separate_pass(hip, impl, prev, monkeypatch):
+    """dX * act'(y) of the layer below rides in the data-gradient kernel's epilogue for linear / relu / leaky (pconv
+    EPI = 3, the gather kernel's pre-store pass); it must give the bits of the unfused kernel + the elementwise
+    multiply (bf16 round, multiply, bf16 round), and other activations must still take the separate pass."""
+    g = G.conv2d_geom(14, 14, 32, 64, (5, 5), (2, 2), (1, 1), "same")
+    B = 37
+    torch.manual_seed(5)
+    w = r16(torch.randn(64, 5, 5, 32) / math.sqrt(5 * 5 * 32))
+    wB = padw(hip, w.permute(3, 1, 2, 0).contiguous())
+    dy = dev(hip, r16(torch.randn(B, g.OH, g.OW, 64)))
+    y = torch.randn(B, 14, 14, 32).bfloat16().cuda()
+    if prev == "tanh":
+        y = torch.tanh(y.float()).bfloat16()
+    monkeypatch.setattr(hip, "CONV_IMPL", impl)
+    monkeypatch.setattr(hip, "AUTOTUNE", False)
+    monkeypatch.setattr(hip, "_CONV_CHOICE", {})
+    monkeypatch.setattr(hip, "_CHOICE_SPEC", {})
+    outs = []
+    for fused in (True, False):
+        monkeypatch.setattr(hip, "PCONV_MULY", fused)
+        monkeypatch.setattr(hip, "IGEMM_MULY", fused)
+        outs.append(hip.conv_dgrad(dy, wB, g, mul=(y, prev, 0.2)))
+    assert torch.equal(outs[0], outs[1])
+    plain = hip.conv_dgrad(dy, wB, g).float()
+    ref = (plain * cpu_ref.act_grad_from_y(y.float().cpu(), prev, 0.2).cuda()).cpu()
+    close(outs[0].float().cpu(), ref, atol=1e-2)
+
+
 CONVT_CASES = [
     # H, W, Cin, filters, k, s, d, padding, act   (layer view)
     (7, 7, 128, 64, (5, 5), (2, 2), (1, 1), "same", "relu"),         # G2
