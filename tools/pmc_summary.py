@@ -1,6 +1,7 @@
 """Summarise rocprofv3 --pmc runs of bench.py (eager): per kernel, mean counter values per dispatch over the
 last `--last N` dispatches of each run (whole timed steps: warm-up and plan autotuning come first), HBM traffic
-and the derived rates.  usage: pmc_summary.py [--last N] <run dir> [<run dir> ...]"""
+and the derived rates; with `--steps S` (N = S whole steps) also the HBM bytes of one step.
+usage: pmc_summary.py [--last N] [--steps S] <run dir> [<run dir> ...]"""
 import csv
 import glob
 import os
@@ -16,6 +17,8 @@ def short(name):
 
 
 LAST = 285
+STEPS = 0
+TOTALS = defaultdict(float)         # counter -> sum over the window (first run that collected it)
 
 
 def load(d):
@@ -39,21 +42,29 @@ def load(d):
     ids = ids[-LAST:]
     agg = defaultdict(lambda: defaultdict(float))
     cnt = defaultdict(int)
+    run_tot = defaultdict(float)
     for did in ids:
         k, dur = meta[did]
         cnt[k] += 1
         for c, v in by_disp[did].items():
             agg[k][c] += v
+            run_tot[c] += v
         if dur is not None:
             agg[k]["_us"] += dur
+    for c, v in run_tot.items():
+        TOTALS.setdefault(c, v)
     return {k: {c: v / cnt[k] for c, v in cs.items()} | {"_calls": cnt[k]} for k, cs in agg.items()}
 
 
 def main():
     global LAST
     argv = sys.argv[1:]
-    if argv and argv[0] == "--last":
-        LAST = int(argv[1])
+    global STEPS
+    while argv and argv[0] in ("--last", "--steps"):
+        if argv[0] == "--last":
+            LAST = int(argv[1])
+        else:
+            STEPS = int(argv[1])
         argv = argv[2:]
     merged = defaultdict(dict)
     for d in argv:
@@ -84,8 +95,12 @@ def main():
         wt = 100 * m["SQ_WAIT_ANY"] / m["SQ_WAVE_CYCLES"] if m.get("SQ_WAVE_CYCLES") else None
         print(f"| `{k}` | {m['_calls']} | {us:.1f} | {f(rd, '.2f')} | {f(wr, '.2f')} | {f(gbs, '.0f')} | {f(mf, '.2f')} | "
               f"{f(lc, '.1f')} | {f(wt, '.0f')} | {f(m.get('SQ_WAVES'), '.0f')} |")
-    print("\n`-`: the plan autotuner (timed under counter collection, so noisier than usual) picked a different "
-          "kernel variant for that problem in the run that collected the counter.")
+    if STEPS and "FETCH_SIZE" in TOTALS and "WRITE_SIZE" in TOTALS:
+        rd, wr = TOTALS["FETCH_SIZE"] / 1024 / STEPS, TOTALS["WRITE_SIZE"] / 1024 / STEPS
+        print(f"\n**HBM traffic per step** ({LAST // STEPS} dispatches): read {rd:.0f} MB + write {wr:.0f} MB = "
+              f"{(rd + wr) / 1000:.2f} GB")
+    print("\n`-`: not defined for that kernel (no LDS traffic), or the counter's run used a different kernel variant "
+          "for that problem (tools/pmc_step.sh tunes the plans once, without counters, so that all passes agree).")
 
 if __name__ == "__main__":
     main()
