@@ -101,7 +101,7 @@ __global__ __launch_bounds__(256) void tapfold_kernel(const TapFoldArgs a) {
                 const int k = ks * 32 + fq * 8;
                 const bool ok = (p < npix) & (k < a.C);
                 const unsigned off = ok ? (xb + (unsigned)(p * a.C + k)) * 2u : 0xFFFFFFF0u;
-                u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(rsX, off, 0, 0);
+                u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(rsX, off, 0, 2);     // nt: read once
                 if (aff) {
                     float f[8];
                     unpack8(make_uint4(v[0], v[1], v[2], v[3]), f);
