@@ -1057,7 +1057,8 @@ DDL_API void ddl_affine(const void* x, void* y, long rows, int C, int c_true, fl
 // a single-channel image (with the layer's bias + activation fused in).
 //   im2col : col[b][oh][ow][t] = img[b][oh*sh + kh*dh - pt][ow*sw + kw*dw - pl][0]      (0 outside / t >= T)
 //   col2im : img[b][h][w][0]   = act(bias + sum_t col[b][(h + pt - kh*dh)/sh][(w + pl - kw*dw)/sw][t])
-struct OneChGeom { int H, W, OH, OW, KH, KW, sh, sw, dh, dw, pt, pl, T, Tp, Ci; };
+struct OneChGeom { int H, W, OH, OW, KH, KW, sh, sw, dh, dw, pt, pl, T, Tp, Ci;
+                   int ones; };   // im2col: padding tap T holds 1.0 (the weight gradient's bias column, wgrad.hip)
 
 // Generic fallback (planes too large for LDS): one thread per 8 taps, gathers straight from global memory.
 __global__ void im2col_1ch_generic_kernel(const bf16_t* __restrict__ img, uint4* __restrict__ col, long n_units,
@@ -1080,6 +1081,8 @@ __global__ void im2col_1ch_generic_kernel(const bf16_t* __restrict__ img, uint4*
                 int kh = t / g.KW, kw = t - kh * g.KW;
                 int ih = oh * g.sh + kh * g.dh - g.pt, iw = ow * g.sw + kw * g.dw - g.pl;
                 if ((unsigned)ih < (unsigned)g.H && (unsigned)iw < (unsigned)g.W) v = base[((long)ih * g.W + iw) * g.Ci];
+            } else if (g.ones && t == g.T) {
+                v = 0x3F80u;
             }
             w[j >> 1] |= v << ((j & 1) * 16);
         }
@@ -1105,7 +1108,7 @@ __global__ __launch_bounds__(256) void im2col_1ch_kernel(const bf16_t* __restric
     const float invPW = 1.0f / (float)PW;
     for (int t = threadIdx.x; t < g.Tp; t += 256) {
         int kh = t / g.KW, kw = t - kh * g.KW;
-        tap[t] = t < g.T ? kh * g.dh * PW + kw * g.dw : -1;
+        tap[t] = t < g.T ? kh * g.dh * PW + kw * g.dw : ((g.ones && t == g.T) ? -2 : -1);
     }
     for (int i = threadIdx.x; i < nimg * psz; i += 256) {
         const int im = fdiv_small(i, 1.0f / (float)psz), e = i - im * psz;
@@ -1130,7 +1133,7 @@ __global__ __launch_bounds__(256) void im2col_1ch_kernel(const bf16_t* __restric
         for (int j = 0; j < 8; ++j) {
             const int off = tap[t8 * 8 + j];
             uint32_t v = src[off < 0 ? 0 : off];
-            v = off < 0 ? 0u : v;
+            v = off < 0 ? (off == -2 ? 0x3F80u : 0u) : v;
             w[j >> 1] |= v << ((j & 1) * 16);
         }
         out[u] = make_uint4(w[0], w[1], w[2], w[3]);
@@ -1200,9 +1203,9 @@ __global__ __launch_bounds__(256) void col2im_1ch_kernel(const bf16_t* __restric
 }
 
 DDL_API int ddl_im2col_1ch(const void* img, void* col, int B, int H, int W, int Ci, int OH, int OW, int KH, int KW,
-                           int sh, int sw, int dh, int dw, int pt, int pl, int Tp, hipStream_t s) {
-    if (Tp % 8 || Tp < KH * KW || Ci <= 0) return -1;
-    OneChGeom g{H, W, OH, OW, KH, KW, sh, sw, dh, dw, pt, pl, KH * KW, Tp, Ci};
+                           int sh, int sw, int dh, int dw, int pt, int pl, int Tp, int ones, hipStream_t s) {
+    if (Tp % 8 || Tp < KH * KW || Ci <= 0 || (ones && Tp == KH * KW)) return -1;
+    OneChGeom g{H, W, OH, OW, KH, KW, sh, sw, dh, dw, pt, pl, KH * KW, Tp, Ci, ones ? 1 : 0};
     // zero-haloed plane covering every tap position: rows -pt .. (OH-1)*sh + (KH-1)*dh - pt
     const long PH = (long)(OH - 1) * sh + (long)(KH - 1) * dh + 1, PW = (long)(OW - 1) * sw + (long)(KW - 1) * dw + 1;
     const long psz = PH * PW, per_img = (long)OH * OW * (Tp / 8);

@@ -30,6 +30,9 @@ struct WgradArgs {
     // optional per-channel affine on X as it is staged (a BatchNorm in front of the layer that is never
     // materialised): X' = bf16(X * x_scale[c] + x_shift[c]) on real pixels, padding stays zero
     const float* x_scale; const float* x_shift; int x_ctrue;
+    // optional (1x1 problems): column `bias_col` of X (>= c_lim, a column of ones written by im2col_1ch) lands at
+    // out[bias_off + n] -- the bias gradient sum_m dY[m][n] rides in the same MFMAs; -1 = off
+    int bias_col; long bias_off;
 };
 
 // floor(x / d) for 0 <= x < 2^31 with d's magic pair (host: magic_div)
@@ -210,7 +213,10 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a) {
 #pragma unroll
         for (int w = 0; w < 4; ++w) s += ((const float*)(smem + w * PER_WAVE))[idx];
         int n = n0 + idx / TC, c = c0 + idx % TC;
-        if (n < a.n_lim && c < a.c_lim) out[n * a.sn + tap * a.st + c * a.sc] = s;
+        if (n < a.n_lim) {
+            if (c < a.c_lim) out[n * a.sn + tap * a.st + c * a.sc] = s;
+            else if (c == a.bias_col) out[a.bias_off + n] = s;
+        }
     }
 }
 
@@ -297,8 +303,12 @@ DDL_API int ddl_wgrad_ksplit(int M, int taps, int n_lim, int c_lim) {
 DDL_API int ddl_conv_wgrad(const void* dy, const void* x, float* out, float* slab, long numel, int ksplit, int B,
                            int OH, int OW, int Ny, int H, int W, int Cx, int KH, int KW, int sh, int sw, int dh,
                            int dw, int pt, int pl, int n_lim, int c_lim, long sn, long st, long sc,
-                           const float* x_scale, const float* x_shift, int x_ctrue, hipStream_t s) {
+                           const float* x_scale, const float* x_shift, int x_ctrue, int bias_col, long bias_off,
+                           hipStream_t s) {
     if (Ny % 8 || Cx % 8 || ksplit < 1) return -1;
+    if (bias_col >= 0 && (KH * KW != 1 || bias_col < c_lim || bias_col >= Cx || bias_off < 0 ||
+                          bias_off + n_lim > numel || x_scale))
+        return -4;
     if (x_scale && !x_shift) return -1;
     long M = (long)B * OH * OW;
     if (M >= (1L << 31) || M * Ny >= (1L << 31) || (long)B * H * W * Cx >= (1L << 31)) return -3;
@@ -306,6 +316,7 @@ DDL_API int ddl_conv_wgrad(const void* dy, const void* x, float* out, float* sla
     a.dy = (const bf16_t*)dy; a.x = (const bf16_t*)x;
     a.slab = ksplit == 1 ? out : slab;
     a.x_scale = x_scale; a.x_shift = x_shift; a.x_ctrue = x_ctrue;
+    a.bias_col = bias_col >= 0 ? bias_col : -1; a.bias_off = bias_off;
     a.B = B; a.OH = OH; a.OW = OW; a.Ny = Ny; a.H = H; a.W = W; a.Cx = Cx;
     a.KH = KH; a.KW = KW; a.sh = sh; a.sw = sw; a.dh = dh; a.dw = dw; a.pt = pt; a.pl = pl;
     a.n_lim = n_lim; a.c_lim = c_lim; a.sn = sn; a.st = st; a.sc = sc;

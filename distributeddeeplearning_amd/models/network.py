@@ -32,6 +32,7 @@ from .ir import LayerSpec, ModelSpec
 
 ONECH = os.environ.get("DDL_ONECH", "1") == "1"      # single-channel conv fast path (device)
 BN_BWD_FUSE = os.environ.get("DDL_BN_BWD_FUSE", "1") == "1"       # BN backward column sums from the kernel that makes dy
+BIAS_IN_WGRAD = os.environ.get("DDL_BIAS_IN_WGRAD", "1") == "1"   # one-channel input conv: bias gradient out of the weight-gradient launch
 BN_ON_LOAD = os.environ.get("DDL_BN_ON_LOAD", "1") == "1"         # BN in front of a 1-channel ConvT applied on load
 FUSE_ACT_BWD = os.environ.get("DDL_FUSE_ACT_BWD", "1") == "1"   # act'(y) of the layer below in the dgrad epilogue
 BRANCH = os.environ.get("DDL_BRANCH", "1") == "1"    # weight-gradient branch on a side stream (captured steps)
@@ -214,6 +215,22 @@ class ConvOp(Op):
         self._gbias_is_zero = False
         F.bias_grad(dy, out=self.gbias)
 
+    def _bias_tail(self, T):
+        """(offset, flat view over [kernel gradient | alignment gap | bias gradient]) when this layer's bias gradient
+        is a plain column sum of dY and can be produced by the weight-gradient launch itself, else None."""
+        bn = self.next_bn
+        if not BIAS_IN_WGRAD or T % 8 == 0 or self.gbias is None or self.gkernel is None:
+            return None
+        if bn is not None and ((bn.used_batch_stats and self.act in (None, "linear")) or bn.bias_grad_for is self):
+            return None                 # zero by construction / written by the BatchNorm's backward (_bias_grad)
+        gk, gb = self.gkernel, self.gbias
+        if gk.untyped_storage().data_ptr() != gb.untyped_storage().data_ptr() or not gk.is_contiguous():
+            return None
+        off = gb.storage_offset() - gk.storage_offset()
+        if off < gk.numel() or off - gk.numel() > 4096 or (off + gb.numel()) % 4 or gb.numel() != self.g.O:
+            return None
+        return off, torch.as_strided(gk, (off + gb.numel(),), (1,))
+
     def _fwd_onech(self, x, training):
         g, g1, hip = self.g, self.g1, F.hip_backend()
         if self.onech == "in":          # direct conv from the 1-channel image (or im2col -> 1x1 conv)
@@ -245,11 +262,21 @@ class ConvOp(Op):
         if self.onech == "in":
             if need_dw:                 # dW[n][t] -> canonical [O][KH][KW][8] slot (n, t, channel 0)
                 def wg():
+                    # The bias gradient (column sums of dY) rides in the same MFMAs: the taps tensor gets a column of
+                    # ones in its first padding tap and the kernel routes that column of dW to the bias slot, which
+                    # sits behind the kernel's in the flat gradient buffer (one launch covers both).
+                    tail = self._bias_tail(T) if self.x is None else None
                     if self.x is None:
-                        self.x = hip.im2col_1ch(self.x_img, g)
-                    hip.conv_wgrad(self.x, dy, g1, "A", out=self.gkernel,
-                                   box=(g.O, T, T * 8, 0, 8, self.gkernel.numel()), slab_holder=self._slabs)
-                    self._bias_grad(dy)
+                        self.x = hip.im2col_1ch(self.x_img, g, ones=tail is not None)
+                    if tail is not None:
+                        off, flat = tail
+                        hip.conv_wgrad(self.x, dy, g1, "A", out=flat, box=(g.O, T, T * 8, 0, 8, flat.numel()),
+                                       slab_holder=self._slabs, bias_tail=(T, off))
+                        self._gbias_is_zero = False
+                    else:
+                        hip.conv_wgrad(self.x, dy, g1, "A", out=self.gkernel,
+                                       box=(g.O, T, T * 8, 0, 8, self.gkernel.numel()), slab_holder=self._slabs)
+                        self._bias_grad(dy)
                 _BR.run(wg, dy)
             if need_dx:
                 dx = hip.tapfold_1ch(dy, self.w_tapT.reshape(T, -1), g, mul=mul)

@@ -69,7 +69,7 @@ _optim_step = _sig("ddl_optim_step", None, vp, vp, vp, vp, vp, vp, cl, ci, cf, c
 _step_inc = _sig("ddl_step_inc", None, vp, vp)
 _scale_emit = _sig("ddl_scale_emit", None, vp, vp, cl, cf, vp)
 _avg_delta = _sig("ddl_avg_delta", None, vp, vp, vp, vp, cl, cf, vp)
-_im2col = _sig("ddl_im2col_1ch", ci, vp, vp, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, vp)
+_im2col = _sig("ddl_im2col_1ch", ci, vp, vp, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, vp)
 _col2im = _sig("ddl_col2im_1ch", ci, vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, cf, vp, ci,
                cf, vp)
 _tapfold = _sig("ddl_tapfold_1ch", ci, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, cf, vp, ci,
@@ -87,7 +87,7 @@ _pconv = _sig("ddl_pconv", ci, vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, c
 _pconv_lds = _sig("ddl_pconv_lds_bytes", ci, ci, ci, cl)
 _wgrad_ksplit = _sig("ddl_wgrad_ksplit", ci, ci, ci, ci, ci)
 _wgrad = _sig("ddl_conv_wgrad", ci, vp, vp, vp, vp, cl, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci,
-              ci, ci, ci, ci, cl, cl, cl, vp, vp, ci, vp)
+              ci, ci, ci, ci, cl, cl, cl, vp, vp, ci, ci, cl, vp)
 _wgrad2 = _sig("ddl_conv_wgrad2", ci, vp, vp, vp, cl, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci,
                cl, cl, cl, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, vp)
 _wgrad2_frag_elems = _sig("ddl_wgrad2_frag_elems", cl, ci, ci, ci, ci, ci, ci, ci)
@@ -402,8 +402,10 @@ def relayout_gather(net, launch=True):
     _done()
 
 
-def im2col_1ch(img, g: ConvGeom, out=None):
-    """[B][g.H][g.W][Ci] (channel 0 is the image) -> taps-as-channels [B][g.OH][g.OW][pad8(KH*KW)]."""
+def im2col_1ch(img, g: ConvGeom, out=None, ones=False):
+    """[B][g.H][g.W][Ci] (channel 0 is the image) -> taps-as-channels [B][g.OH][g.OW][pad8(KH*KW)].
+    `ones`: the first padding tap (column KH*KW, needs KH*KW < pad8(KH*KW)) holds 1.0 instead of 0 -- the column the
+    streaming weight gradient turns into the bias gradient (`conv_wgrad(bias_tail=...)`)."""
     _chk_act(img, "img")
     B = img.shape[0]
     if tuple(img.shape[1:3]) != (g.H, g.W):
@@ -413,10 +415,10 @@ def im2col_1ch(img, g: ConvGeom, out=None):
     ranges = _batch_ranges(B, max(g.OH * g.OW * Tp, g.H * g.W * img.shape[-1]))
     if ranges is not None:
         for b0, b1 in ranges:
-            im2col_1ch(img[b0:b1], g, col[b0:b1])
+            im2col_1ch(img[b0:b1], g, col[b0:b1], ones)
         return col
     rc = _im2col(img.data_ptr(), col.data_ptr(), B, g.H, g.W, img.shape[-1], g.OH, g.OW, g.KH, g.KW, g.sh, g.sw,
-                 g.dh, g.dw, g.pt, g.pl, Tp, _stream())
+                 g.dh, g.dw, g.pt, g.pl, Tp, 1 if ones else 0, _stream())
     if rc:
         raise ValueError("im2col_1ch rejected")
     _done()
@@ -1590,11 +1592,13 @@ def _box_slab(holder, n, box, device):
     return slab
 
 
-def conv_wgrad(x, dy, g: ConvGeom, layout="A", out=None, box=None, x_affine=None, slab_holder=None):
+def conv_wgrad(x, dy, g: ConvGeom, layout="A", out=None, box=None, x_affine=None, slab_holder=None, bias_tail=None):
     """`box` = (n_lim, c_lim, sn, st, sc, numel): write dW[n][t][c] at out[n*sn + t*st + c*sc] instead of one of
     the two standard layouts (the caller guarantees `out` has `numel` elements and is zero elsewhere).
     `x_affine` = (scale, shift, c_true), fp32 [Ip]: X is read as bf16(X * scale + shift) on real pixels (a
-    BatchNorm in front of the layer applied on load); only the streaming kernel (1x1 / few-tap problems) has it."""
+    BatchNorm in front of the layer applied on load); only the streaming kernel (1x1 / few-tap problems) has it.
+    `bias_tail` = (col, off), 1x1 problems with a custom box on the streaming kernel: column `col` >= c_lim of X is a
+    column of ones (`im2col_1ch(ones=True)`) and sum_m dY[m][n] -- the bias gradient -- is written at out[off + n]."""
     _chk_act(x, "x")
     _chk_act(dy, "dy")
     B = x.shape[0]
@@ -1606,10 +1610,10 @@ def conv_wgrad(x, dy, g: ConvGeom, layout="A", out=None, box=None, x_affine=None
         total = None
         for b0, b1 in ranges:
             if total is None:
-                total = conv_wgrad(x[b0:b1], dy[b0:b1], g, layout, out, box, x_affine, slab_holder)
+                total = conv_wgrad(x[b0:b1], dy[b0:b1], g, layout, out, box, x_affine, slab_holder, bias_tail)
             else:
                 total.add_(conv_wgrad(x[b0:b1], dy[b0:b1], g, layout, torch.empty_like(total) if box is None
-                                      else torch.zeros_like(total), box, x_affine, slab_holder))
+                                      else torch.zeros_like(total), box, x_affine, slab_holder, bias_tail))
         return total
     dev = x.device
     T = g.KH * g.KW
@@ -1653,7 +1657,10 @@ def conv_wgrad(x, dy, g: ConvGeom, layout="A", out=None, box=None, x_affine=None
     if out.numel() != numel:
         raise ValueError(f"conv_wgrad: out has {out.numel()} elements, expected {numel} for layout {layout}")
     _chk_f32(out, numel, "dW")
-    plans = _wgrad2_plans(g, B, Ip, Op, n_lim, c_lim) if WGRAD_IMPL == "wgrad2" else []
+    plans = _wgrad2_plans(g, B, Ip, Op, n_lim, c_lim) if (WGRAD_IMPL == "wgrad2" and bias_tail is None) else []
+    if bias_tail is not None and box is None:
+        raise ValueError("conv_wgrad: bias_tail needs a custom box")
+    bcol, boff = (-1, 0) if bias_tail is None else (int(bias_tail[0]), int(bias_tail[1]))
     xs = xh = None
     xct = Ip
     if x_affine is not None:
@@ -1698,7 +1705,7 @@ def conv_wgrad(x, dy, g: ConvGeom, layout="A", out=None, box=None, x_affine=None
                 torch.empty(ksplit * numel, dtype=torch.float32, device=dev)
         rc = _wgrad(dy.data_ptr(), x.data_ptr(), out.data_ptr(), _p(slab), numel, ksplit, B, g.OH, g.OW, Op, g.H,
                     g.W, Ip, g.KH, g.KW, g.sh, g.sw, g.dh, g.dw, g.pt, g.pl, n_lim, c_lim, sn, st, sc, xs, xh, xct,
-                    _stream())
+                    bcol, boff, _stream())
         if rc:
             raise ValueError(f"conv_wgrad rejected the problem (rc={rc}): {g}")
 
@@ -1738,7 +1745,7 @@ def conv_wgrad(x, dy, g: ConvGeom, layout="A", out=None, box=None, x_affine=None
             torch.empty(ksplit * numel, dtype=torch.float32, device=dev)
     rc = _wgrad(dy.data_ptr(), x.data_ptr(), out.data_ptr(), _p(slab), numel, ksplit, B, g.OH, g.OW, Op, g.H,
                 g.W, Ip, g.KH, g.KW, g.sh, g.sw, g.dh, g.dw, g.pt, g.pl, n_lim, c_lim, sn, st, sc, xs, xh, xct,
-                _stream())
+                bcol, boff, _stream())
     if rc:
         raise ValueError(f"conv_wgrad rejected the problem (rc={rc}): {g}")
     _done()

@@ -94,6 +94,35 @@ def test_conv_fprop_dgrad_wgrad(hip, case, B):
     close(dwB[..., :O], dw_ref.permute(3, 1, 2, 0), rtol=1e-2)
 
 
+@pytest.mark.parametrize("B", [3, 500])
+def test_wgrad_bias_tail_from_ones_column(hip, B):
+    """One-channel input conv: im2col_1ch(ones=True) puts 1.0 in the first padding tap, and the streaming weight
+    gradient routes that column of dW to out[off + n] -- the bias gradient sum_m dY[m][n] from the same launch.
+    The weight part must equal the plain call bit for bit; the bias part is compared with the fp32 column sum."""
+    g = G.conv2d_geom(28, 28, 1, 32, (5, 5), (2, 2), (1, 1), "same")
+    T, Tp = 25, 32
+    g1 = G.ConvGeom(g.OH, g.OW, T, g.OH, g.OW, g.O, 1, 1).check()
+    torch.manual_seed(21)
+    img = torch.zeros(B, 28, 28, 8)
+    img[..., 0] = torch.randn(B, 28, 28)
+    img = img.bfloat16().cuda().contiguous()
+    dy = torch.randn(B, g.OH, g.OW, 32).bfloat16().cuda().contiguous()
+    numel = g.O * T * 8
+    plain = torch.zeros(numel, device="cuda")
+    hip.conv_wgrad(hip.im2col_1ch(img, g), dy, g1, "A", out=plain, box=(g.O, T, T * 8, 0, 8, numel))
+    xc1 = hip.im2col_1ch(img, g, ones=True)
+    assert float(xc1[..., T].float().min()) == 1.0 and float(xc1[..., T + 1:].float().abs().max()) == 0.0
+    off = numel + 64                                    # an alignment gap between the two gradient slots
+    flat = torch.zeros(off + g.O, device="cuda")
+    hip.conv_wgrad(xc1, dy, g1, "A", out=flat, box=(g.O, T, T * 8, 0, 8, flat.numel()), bias_tail=(T, off))
+    assert torch.equal(flat[:numel], plain)
+    assert float(flat[numel:off].abs().max()) == 0.0
+    ref = dy.float().sum(dim=(0, 1, 2))
+    close(flat[off:].cpu(), ref.cpu(), rtol=1e-3, atol=1e-3 * float(ref.abs().max()) + 1e-3)
+    with pytest.raises(ValueError):
+        hip.conv_wgrad(xc1, dy, g1, "A", out=flat, box=(g.O, T, T * 8, 0, 8, flat.numel()), bias_tail=(T, flat.numel()))
+
+
 @pytest.mark.parametrize("impl", ["pconv", "igemm"])
 @pytest.mark.parametrize("prev", ["relu", "leaky", "linear", "tanh"])
 def test_dgrad_fused_act_grad_is_bit_identical_to_the_separate_pass(hip, impl, prev, monkeypatch):
