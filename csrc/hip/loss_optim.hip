@@ -265,7 +265,16 @@ __global__ __launch_bounds__(256) void head_finalize_kernel(const float* __restr
     double s = 0;
     if (k < K) {
         int b = lb;
-        for (; b + 56 < nblocks; b += 64) {      // eight independent loads per trip, summed in a fixed order
+        // sixteen, then eight independent loads per trip, summed in a fixed order (the walk is a latency chain: 512
+        // partial rows are 64 loads per thread)
+        for (; b + 120 < nblocks; b += 128) {
+            float v[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) v[u] = dw_part[(size_t)(b + 8 * u) * K + k];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) s += v[u];
+        }
+        for (; b + 56 < nblocks; b += 64) {
             float v[8];
 #pragma unroll
             for (int u = 0; u < 8; ++u) v[u] = dw_part[(size_t)(b + 8 * u) * K + k];
@@ -284,7 +293,13 @@ __global__ __launch_bounds__(256) void head_finalize_kernel(const float* __restr
     }
     if (blockIdx.x == 0) {
         float t = 0.f;
-        for (int i = threadIdx.x; i < M; i += 256) t += dlogit[i];
+        for (int i = threadIdx.x; i < M; i += 256 * 8) {       // eight loads in flight (a serial walk is 1 us per load)
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = i + 256 * u < M ? dlogit[i + 256 * u] : 0.f;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) t += v[u];
+        }
         t = wave_sum(t);
         if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = t;
         __syncthreads();
@@ -293,7 +308,13 @@ __global__ __launch_bounds__(256) void head_finalize_kernel(const float* __restr
     if (blockIdx.x == gridDim.x - 1 && loss_out) {     // mean loss (saves the separate mean_kernel launch)
         __shared__ double lsum[4];
         double t = 0;
-        for (int i = threadIdx.x; i < M; i += 256) t += rowloss[i];
+        for (int i = threadIdx.x; i < M; i += 256 * 8) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = i + 256 * u < M ? rowloss[i + 256 * u] : 0.f;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) t += v[u];
+        }
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) t += __shfl_xor(t, o, 64);
         if ((threadIdx.x & 63) == 0) lsum[threadIdx.x >> 6] = t;
