@@ -130,6 +130,33 @@ def test_fused_activation_backward_is_bit_exact(monkeypatch):
     assert torch.equal(a.D.P, b.D.P) and torch.equal(a.G.P, b.G.P)
 
 
+def test_first_layer_bias_gradient_from_the_weight_gradient_launch(monkeypatch):
+    """D's one-channel input conv takes its bias gradient out of the weight-gradient launch (ones column in the taps
+    tensor, network.ConvOp._bias_tail): same kernel gradient bits as the separate column reduction, bias gradient
+    equal to fp32 summation-order noise, nothing else in the flat gradient buffer touched."""
+    from distributeddeeplearning_amd.models import network
+    import distributeddeeplearning_amd.ops.hip as hip
+    torch.manual_seed(0)
+    x = torch.rand(96, 28, 28, 1).bfloat16().float()
+    dy = hip.pad_channels((torch.randn(96, 1).abs() / 64).bfloat16().float().cuda(), 8)
+    grads = []
+    for fused in (True, False):
+        monkeypatch.setattr(network, "BIAS_IN_WGRAD", fused)
+        g = Network(discriminator_spec(), "cuda", 1, "batch")
+        first = next(op for op in g.ops if isinstance(op, network.ConvOp))
+        assert (first._bias_tail(25) is not None) == fused
+        g.forward(g.prepare_input(x), training=True)
+        g.backward(dy, need_input_grad=True)
+        torch.cuda.synchronize()
+        grads.append((g.G.clone(), first.gkernel.clone(), first.gbias.clone()))
+    (Ga, ka, ba), (Gb, kb, bb) = grads
+    assert torch.equal(ka, kb)
+    assert float(bb.abs().max()) > 0
+    assert float((ba - bb).abs().max()) <= 1e-4 * float(bb.abs().max()) + 1e-6
+    same = Ga == Gb
+    assert int((~same).sum()) <= ba.numel()          # only the bias slot may differ (in its last bits)
+
+
 def test_generator_inference_forward_with_folded_batchnorm():
     """training=False: inference BN is folded into the producing conv's epilogue where the kernel allows
     (pconv AFFINE) -- same outputs as the CPU oracle with non-trivial moving statistics."""
