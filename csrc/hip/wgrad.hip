@@ -33,6 +33,10 @@ struct WgradArgs {
     // optional (1x1 problems): column `bias_col` of X (>= c_lim, a column of ones written by im2col_1ch) lands at
     // out[bias_off + n] -- the bias gradient sum_m dY[m][n] rides in the same MFMAs; -1 = off
     int bias_col; long bias_off;
+    // optional: row `bias_row` of the dY operand summed over all pixels (one more MFMA per sub-tile against a fragment
+    // of ones) lands at out[bias_off] -- the scalar bias gradient of a one-channel transposed conv, whose dY operand
+    // is the taps tensor of the image gradient (centre tap = the image gradient itself); -1 = off
+    int bias_row;
 };
 
 // floor(x / d) for 0 <= x < 2^31 with d's magic pair (host: magic_div)
@@ -81,6 +85,11 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a) {
     for (int i = 0; i < SN; ++i)
 #pragma unroll
         for (int j = 0; j < SC; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    f32x4 accb[SN];                                     // row sums of the dY operand (bias_row)
+#pragma unroll
+    for (int i = 0; i < SN; ++i) accb[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const bool rowsum = a.bias_row >= 0 && blockIdx.y == 0 && ct == 0;
+    const s16x8 ones8 = {0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80};
 
     // staging assignment: 16-B units (8 channels of one pixel)
     constexpr int UY = TN / 8, UX = TC / 8;              // units per pixel row
@@ -180,6 +189,12 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a) {
 #pragma unroll
             for (int j = 0; j < SC; ++j)
                 acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fy[i], fx[j], acc[i][j], 0, 0, 0);
+        if (rowsum) {
+#pragma unroll
+            for (int i = 0; i < SN; ++i)
+                accb[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fy[i], __builtin_bit_cast(bf16x8_t, ones8), accb[i],
+                                                                  0, 0, 0);
+        }
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
         __builtin_amdgcn_wave_barrier();
     };
@@ -216,6 +231,22 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a) {
         if (n < a.n_lim) {
             if (c < a.c_lim) out[n * a.sn + tap * a.st + c * a.sc] = s;
             else if (c == a.bias_col) out[a.bias_off + n] = s;
+        }
+    }
+    if (rowsum && a.bias_row >= n0 && a.bias_row < n0 + TN) {      // block-uniform
+        // every column of the ones product holds the row sum: take column 0 (li == 0) of each wave, fold the 4 waves
+        __syncthreads();
+        float* rb = (float*)smem;                                   // [4 waves][TN]
+        if (li == 0) {
+#pragma unroll
+            for (int i = 0; i < SN; ++i)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) rb[wave * TN + 16 * i + 4 * g + e] = accb[i][e];
+        }
+        __syncthreads();
+        if (tid == 0) {
+            const int r = a.bias_row - n0;
+            out[a.bias_off] = ((rb[r] + rb[TN + r]) + rb[2 * TN + r]) + rb[3 * TN + r];
         }
     }
 }
@@ -304,10 +335,12 @@ DDL_API int ddl_conv_wgrad(const void* dy, const void* x, float* out, float* sla
                            int OH, int OW, int Ny, int H, int W, int Cx, int KH, int KW, int sh, int sw, int dh,
                            int dw, int pt, int pl, int n_lim, int c_lim, long sn, long st, long sc,
                            const float* x_scale, const float* x_shift, int x_ctrue, int bias_col, long bias_off,
-                           hipStream_t s) {
+                           int bias_row, hipStream_t s) {
     if (Ny % 8 || Cx % 8 || ksplit < 1) return -1;
     if (bias_col >= 0 && (KH * KW != 1 || bias_col < c_lim || bias_col >= Cx || bias_off < 0 ||
                           bias_off + n_lim > numel || x_scale))
+        return -4;
+    if (bias_row >= 0 && (KH * KW != 1 || bias_col >= 0 || bias_row >= n_lim || bias_off < 0 || bias_off >= numel))
         return -4;
     if (x_scale && !x_shift) return -1;
     long M = (long)B * OH * OW;
@@ -317,6 +350,7 @@ DDL_API int ddl_conv_wgrad(const void* dy, const void* x, float* out, float* sla
     a.slab = ksplit == 1 ? out : slab;
     a.x_scale = x_scale; a.x_shift = x_shift; a.x_ctrue = x_ctrue;
     a.bias_col = bias_col >= 0 ? bias_col : -1; a.bias_off = bias_off;
+    a.bias_row = bias_row >= 0 ? bias_row : -1;
     a.B = B; a.OH = OH; a.OW = OW; a.Ny = Ny; a.H = H; a.W = W; a.Cx = Cx;
     a.KH = KH; a.KW = KW; a.sh = sh; a.sw = sw; a.dh = dh; a.dw = dw; a.pt = pt; a.pl = pl;
     a.n_lim = n_lim; a.c_lim = c_lim; a.sn = sn; a.st = st; a.sc = sc;

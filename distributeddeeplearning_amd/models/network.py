@@ -215,7 +215,7 @@ class ConvOp(Op):
         self._gbias_is_zero = False
         F.bias_grad(dy, out=self.gbias)
 
-    def _bias_tail(self, T):
+    def _bias_tail(self, T, nbias=None):
         """(offset, flat view over [kernel gradient | alignment gap | bias gradient]) when this layer's bias gradient
         is a plain column sum of dY and can be produced by the weight-gradient launch itself, else None."""
         bn = self.next_bn
@@ -227,9 +227,23 @@ class ConvOp(Op):
         if gk.untyped_storage().data_ptr() != gb.untyped_storage().data_ptr() or not gk.is_contiguous():
             return None
         off = gb.storage_offset() - gk.storage_offset()
-        if off < gk.numel() or off - gk.numel() > 4096 or (off + gb.numel()) % 4 or gb.numel() != self.g.O:
+        if off < gk.numel() or off - gk.numel() > 4096 or gb.numel() != (self.g.O if nbias is None else nbias):
             return None
-        return off, torch.as_strided(gk, (off + gb.numel(),), (1,))
+        # every parameter starts at a multiple of ALIGN elements: what follows the bias up to the next multiple of 4 is
+        # alignment padding of the flat buffer (it receives zeros; the wide slab reduce wants float4 columns)
+        total = _round_up(off + gb.numel(), 4)
+        if ALIGN % 4 or gk.storage_offset() + total > gk.untyped_storage().nbytes() // 4:
+            return None
+        return off, torch.as_strided(gk, (total,), (1,))
+
+    def _centre_tap(self):
+        """Index of the tap whose im2col column IS the image (stride 1, the tap that reads pixel (h, w) for output
+        (h, w)), or None: its pixel sum is the sum of the image."""
+        g = self.g
+        if g.sh != 1 or g.sw != 1 or g.OH != g.H or g.OW != g.W or g.pt % g.dh or g.pl % g.dw:
+            return None
+        kh, kw = g.pt // g.dh, g.pl // g.dw
+        return kh * g.KW + kw if (kh < g.KH and kw < g.KW) else None
 
     def _fwd_onech(self, x, training):
         g, g1, hip = self.g, self.g1, F.hip_backend()
@@ -309,8 +323,18 @@ class ConvOp(Op):
 
                 def wg():
                     d = dyc[0] if dyc[0] is not None else hip.im2col_1ch(dy, g)
-                    hip.conv_wgrad(x, d, g1, "A", out=self.gkernel, x_affine=xa)
-                    self._bias_grad(dy)
+                    # the scalar bias gradient sum(dY) = the pixel sum of d's centre tap: one more MFMA in this launch
+                    ctr = self._centre_tap()
+                    tail = self._bias_tail(1, nbias=1) if ctr is not None else None
+                    if tail is not None:
+                        off, flat = tail
+                        Ip = x.shape[-1]
+                        hip.conv_wgrad(x, d, g1, "A", out=flat, x_affine=xa, slab_holder=self._slabs,
+                                       box=(g1.O, Ip, Ip, Ip, 1, flat.numel()), bias_tail=("row", ctr, off))
+                        self._gbias_is_zero = False
+                    else:
+                        hip.conv_wgrad(x, d, g1, "A", out=self.gkernel, x_affine=xa)
+                        self._bias_grad(dy)
                 _BR.run(wg, dy)
         return dx
 

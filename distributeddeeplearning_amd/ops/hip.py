@@ -87,7 +87,7 @@ _pconv = _sig("ddl_pconv", ci, vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, c
 _pconv_lds = _sig("ddl_pconv_lds_bytes", ci, ci, ci, cl)
 _wgrad_ksplit = _sig("ddl_wgrad_ksplit", ci, ci, ci, ci, ci)
 _wgrad = _sig("ddl_conv_wgrad", ci, vp, vp, vp, vp, cl, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci,
-              ci, ci, ci, ci, cl, cl, cl, vp, vp, ci, ci, cl, vp)
+              ci, ci, ci, ci, cl, cl, cl, vp, vp, ci, ci, cl, ci, vp)
 _wgrad2 = _sig("ddl_conv_wgrad2", ci, vp, vp, vp, cl, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci,
                cl, cl, cl, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, vp)
 _wgrad2_frag_elems = _sig("ddl_wgrad2_frag_elems", cl, ci, ci, ci, ci, ci, ci, ci)
@@ -1598,7 +1598,10 @@ def conv_wgrad(x, dy, g: ConvGeom, layout="A", out=None, box=None, x_affine=None
     `x_affine` = (scale, shift, c_true), fp32 [Ip]: X is read as bf16(X * scale + shift) on real pixels (a
     BatchNorm in front of the layer applied on load); only the streaming kernel (1x1 / few-tap problems) has it.
     `bias_tail` = (col, off), 1x1 problems with a custom box on the streaming kernel: column `col` >= c_lim of X is a
-    column of ones (`im2col_1ch(ones=True)`) and sum_m dY[m][n] -- the bias gradient -- is written at out[off + n]."""
+    column of ones (`im2col_1ch(ones=True)`) and sum_m dY[m][n] -- the bias gradient -- is written at out[off + n].
+    `bias_tail` = ("row", row, off): sum_m dY[m][row] (one row of the dY operand summed over all pixels, from one more
+    MFMA against a fragment of ones) is written at out[off] -- the scalar bias gradient of a one-channel transposed
+    conv, whose dY operand is the taps tensor of the image gradient (row = the centre tap)."""
     _chk_act(x, "x")
     _chk_act(dy, "dy")
     B = x.shape[0]
@@ -1660,7 +1663,12 @@ def conv_wgrad(x, dy, g: ConvGeom, layout="A", out=None, box=None, x_affine=None
     plans = _wgrad2_plans(g, B, Ip, Op, n_lim, c_lim) if (WGRAD_IMPL == "wgrad2" and bias_tail is None) else []
     if bias_tail is not None and box is None:
         raise ValueError("conv_wgrad: bias_tail needs a custom box")
-    bcol, boff = (-1, 0) if bias_tail is None else (int(bias_tail[0]), int(bias_tail[1]))
+    bcol, boff, brow = -1, 0, -1
+    if bias_tail is not None:
+        if bias_tail[0] == "row":
+            brow, boff = int(bias_tail[1]), int(bias_tail[2])
+        else:
+            bcol, boff = int(bias_tail[0]), int(bias_tail[1])
     xs = xh = None
     xct = Ip
     if x_affine is not None:
@@ -1705,7 +1713,7 @@ def conv_wgrad(x, dy, g: ConvGeom, layout="A", out=None, box=None, x_affine=None
                 torch.empty(ksplit * numel, dtype=torch.float32, device=dev)
         rc = _wgrad(dy.data_ptr(), x.data_ptr(), out.data_ptr(), _p(slab), numel, ksplit, B, g.OH, g.OW, Op, g.H,
                     g.W, Ip, g.KH, g.KW, g.sh, g.sw, g.dh, g.dw, g.pt, g.pl, n_lim, c_lim, sn, st, sc, xs, xh, xct,
-                    bcol, boff, _stream())
+                    bcol, boff, brow, _stream())
         if rc:
             raise ValueError(f"conv_wgrad rejected the problem (rc={rc}): {g}")
 
@@ -1745,7 +1753,7 @@ def conv_wgrad(x, dy, g: ConvGeom, layout="A", out=None, box=None, x_affine=None
             torch.empty(ksplit * numel, dtype=torch.float32, device=dev)
     rc = _wgrad(dy.data_ptr(), x.data_ptr(), out.data_ptr(), _p(slab), numel, ksplit, B, g.OH, g.OW, Op, g.H,
                 g.W, Ip, g.KH, g.KW, g.sh, g.sw, g.dh, g.dw, g.pt, g.pl, n_lim, c_lim, sn, st, sc, xs, xh, xct,
-                bcol, boff, _stream())
+                bcol, boff, brow, _stream())
     if rc:
         raise ValueError(f"conv_wgrad rejected the problem (rc={rc}): {g}")
     _done()

@@ -123,6 +123,34 @@ def test_wgrad_bias_tail_from_ones_column(hip, B):
         hip.conv_wgrad(xc1, dy, g1, "A", out=flat, box=(g.O, T, T * 8, 0, 8, flat.numel()), bias_tail=(T, flat.numel()))
 
 
+@pytest.mark.parametrize("B", [3, 500])
+@pytest.mark.parametrize("affine", [False, True])
+def test_wgrad_bias_tail_from_a_row_sum_of_the_dy_operand(hip, B, affine):
+    """One-channel transposed conv: the weight gradient's dY operand is the taps tensor of the image gradient, and
+    its centre-tap row summed over all pixels (one more MFMA against a fragment of ones) is the scalar bias gradient,
+    written at out[off].  The weight part must equal the plain call bit for bit (also with the on-load affine)."""
+    g = G.conv2d_geom(28, 28, 1, 32, (5, 5), (1, 1), (1, 1), "same")
+    T, Tp, C = 25, 32, 32
+    g1 = G.ConvGeom(g.OH, g.OW, C, g.OH, g.OW, T, 1, 1).check()
+    torch.manual_seed(22)
+    img = torch.zeros(B, 28, 28, 8)
+    img[..., 0] = torch.randn(B, 28, 28)
+    img = img.bfloat16().cuda().contiguous()
+    x = torch.randn(B, 28, 28, C).bfloat16().cuda().contiguous()
+    xa = (torch.rand(C, device="cuda") + 0.5, torch.randn(C, device="cuda") * 0.1, C) if affine else None
+    d = hip.im2col_1ch(img, g)
+    plain = hip.conv_wgrad(x, d, g1, "A", x_affine=xa).reshape(-1)
+    numel = T * C
+    assert plain.numel() == numel
+    off = numel + 8
+    flat = torch.zeros(off + 4, device="cuda")
+    hip.conv_wgrad(x, d, g1, "A", out=flat, x_affine=xa, box=(T, C, C, C, 1, flat.numel()), bias_tail=("row", 12, off))
+    assert torch.equal(flat[:numel], plain)
+    assert float(flat[numel:off].abs().max()) == 0.0 and float(flat[off + 1:].abs().max()) == 0.0
+    ref = float(img[..., 0].float().sum())
+    assert abs(float(flat[off]) - ref) <= 1e-3 * float(img[..., 0].float().abs().sum()) / 30 + 1e-3
+
+
 @pytest.mark.parametrize("impl", ["pconv", "igemm"])
 @pytest.mark.parametrize("prev", ["relu", "leaky", "linear", "tanh"])
 def test_dgrad_fused_act_grad_is_bit_identical_to_the_separate_pass(hip, impl, prev, monkeypatch):

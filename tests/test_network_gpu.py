@@ -157,6 +157,32 @@ def test_first_layer_bias_gradient_from_the_weight_gradient_launch(monkeypatch):
     assert int((~same).sum()) <= ba.numel()          # only the bias slot may differ (in its last bits)
 
 
+def test_image_layer_bias_gradient_from_the_weight_gradient_launch(monkeypatch):
+    """G's one-channel transposed conv takes its scalar bias gradient out of the weight-gradient launch (row sum of
+    the taps tensor's centre tap): same kernel gradient bits, bias gradient equal to summation-order noise."""
+    from distributeddeeplearning_amd.models import network
+    import distributeddeeplearning_amd.ops.hip as hip
+    torch.manual_seed(0)
+    z = (torch.rand(64, 128) * 2 - 1).bfloat16().float()
+    dy = hip.pad_channels(torch.randn(64, 28, 28, 1).bfloat16().float().cuda(), 8)
+    grads = []
+    for fused in (True, False):
+        monkeypatch.setattr(network, "BIAS_IN_WGRAD", fused)
+        g = Network(generator_spec(), "cuda", 2, "batch")
+        last = [op for op in g.ops if isinstance(op, network.ConvOp)][-1]
+        assert last.onech == "out" and last._centre_tap() == 12
+        assert (last._bias_tail(1, nbias=1) is not None) == fused
+        g.forward(g.prepare_input(z), training=True)
+        g.backward(dy)
+        torch.cuda.synchronize()
+        grads.append((g.G.clone(), last.gkernel.clone(), last.gbias.clone()))
+    (Ga, ka, ba), (Gb, kb, bb) = grads
+    assert torch.equal(ka, kb)
+    assert float(bb.abs().max()) > 0
+    assert float((ba - bb).abs().max()) <= 1e-4 * float(bb.abs().max()) + 1e-4
+    assert int((Ga != Gb).sum()) <= 1                # only the bias slot may differ (in its last bits)
+
+
 def test_generator_inference_forward_with_folded_batchnorm():
     """training=False: inference BN is folded into the producing conv's epilogue where the kernel allows
     (pconv AFFINE) -- same outputs as the CPU oracle with non-trivial moving statistics."""
