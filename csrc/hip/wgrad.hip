@@ -35,7 +35,8 @@ struct WgradArgs {
     int bias_col; long bias_off;
     // optional: row `bias_row` of the dY operand summed over all pixels (one more MFMA per sub-tile against a fragment
     // of ones) lands at out[bias_off] -- the scalar bias gradient of a one-channel transposed conv, whose dY operand
-    // is the taps tensor of the image gradient (centre tap = the image gradient itself); -1 = off
+    // is the taps tensor of the image gradient (centre tap = the image gradient itself); -1 = off;
+    // -2 = every row n < n_lim, at out[bias_off + n] (the bias gradient of a Dense / 1x1 layer)
     int bias_row;
 };
 
@@ -88,7 +89,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a) {
     f32x4 accb[SN];                                     // row sums of the dY operand (bias_row)
 #pragma unroll
     for (int i = 0; i < SN; ++i) accb[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    const bool rowsum = a.bias_row >= 0 && blockIdx.y == 0 && ct == 0;
+    const bool rowsum = a.bias_row != -1 && blockIdx.y == 0 && ct == 0;
     const s16x8 ones8 = {0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80};
 
     // staging assignment: 16-B units (8 channels of one pixel)
@@ -233,7 +234,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a) {
             else if (c == a.bias_col) out[a.bias_off + n] = s;
         }
     }
-    if (rowsum && a.bias_row >= n0 && a.bias_row < n0 + TN) {      // block-uniform
+    if (rowsum && (a.bias_row == -2 || (a.bias_row >= n0 && a.bias_row < n0 + TN))) {      // block-uniform
         // every column of the ones product holds the row sum: take column 0 (li == 0) of each wave, fold the 4 waves
         __syncthreads();
         float* rb = (float*)smem;                                   // [4 waves][TN]
@@ -244,7 +245,10 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a) {
                 for (int e = 0; e < 4; ++e) rb[wave * TN + 16 * i + 4 * g + e] = accb[i][e];
         }
         __syncthreads();
-        if (tid == 0) {
+        if (a.bias_row == -2) {
+            if (tid < TN && n0 + tid < a.n_lim)
+                out[a.bias_off + n0 + tid] = ((rb[tid] + rb[TN + tid]) + rb[2 * TN + tid]) + rb[3 * TN + tid];
+        } else if (tid == 0) {
             const int r = a.bias_row - n0;
             out[a.bias_off] = ((rb[r] + rb[TN + r]) + rb[2 * TN + r]) + rb[3 * TN + r];
         }
@@ -342,6 +346,8 @@ DDL_API int ddl_conv_wgrad(const void* dy, const void* x, float* out, float* sla
         return -4;
     if (bias_row >= 0 && (KH * KW != 1 || bias_col >= 0 || bias_row >= n_lim || bias_off < 0 || bias_off >= numel))
         return -4;
+    if (bias_row < -1 && (bias_row != -2 || KH * KW != 1 || bias_col >= 0 || bias_off < 0 || bias_off + n_lim > numel))
+        return -4;
     if (x_scale && !x_shift) return -1;
     long M = (long)B * OH * OW;
     if (M >= (1L << 31) || M * Ny >= (1L << 31) || (long)B * H * W * Cx >= (1L << 31)) return -3;
@@ -350,7 +356,7 @@ DDL_API int ddl_conv_wgrad(const void* dy, const void* x, float* out, float* sla
     a.slab = ksplit == 1 ? out : slab;
     a.x_scale = x_scale; a.x_shift = x_shift; a.x_ctrue = x_ctrue;
     a.bias_col = bias_col >= 0 ? bias_col : -1; a.bias_off = bias_off;
-    a.bias_row = bias_row >= 0 ? bias_row : -1;
+    a.bias_row = bias_row;
     a.B = B; a.OH = OH; a.OW = OW; a.Ny = Ny; a.H = H; a.W = W; a.Cx = Cx;
     a.KH = KH; a.KW = KW; a.sh = sh; a.sw = sw; a.dh = dh; a.dw = dw; a.pt = pt; a.pl = pl;
     a.n_lim = n_lim; a.c_lim = c_lim; a.sn = sn; a.st = st; a.sc = sc;

@@ -392,8 +392,18 @@ class ConvOp(Op):
             dy4, x4 = dy.reshape(B, 1, 1, -1), x.reshape(B, 1, 1, -1)
             if need_dw:
                 def wg():
-                    F.conv_wgrad(x4, dy4, g, "A", out=self._w4(self.gkernel))
-                    self._bias_grad(dy)
+                    # the bias gradient (column sums of dY) as row sums of the weight gradient's dY operand: one more
+                    # MFMA per sub-tile against a fragment of ones, no reduction pass of its own
+                    tail = self._bias_tail(1) if (dy.is_cuda and self.kstruct is None) else None
+                    if tail is not None:
+                        off, flat = tail
+                        Ip = x4.shape[-1]
+                        F.hip_backend().conv_wgrad(x4, dy4, g, "A", out=flat, slab_holder=self._slabs,
+                                                   box=(g.O, Ip, Ip, Ip, 1, flat.numel()), bias_tail=("rows", off))
+                        self._gbias_is_zero = False
+                    else:
+                        F.conv_wgrad(x4, dy4, g, "A", out=self._w4(self.gkernel))
+                        self._bias_grad(dy)
                 _BR.run(wg, dy)
             if need_dx:
                 dx = F.conv_dgrad(dy4, self._w4(self.w_alt), g, mul=mul).reshape(x.shape)

@@ -1601,7 +1601,8 @@ def conv_wgrad(x, dy, g: ConvGeom, layout="A", out=None, box=None, x_affine=None
     column of ones (`im2col_1ch(ones=True)`) and sum_m dY[m][n] -- the bias gradient -- is written at out[off + n].
     `bias_tail` = ("row", row, off): sum_m dY[m][row] (one row of the dY operand summed over all pixels, from one more
     MFMA against a fragment of ones) is written at out[off] -- the scalar bias gradient of a one-channel transposed
-    conv, whose dY operand is the taps tensor of the image gradient (row = the centre tap)."""
+    conv, whose dY operand is the taps tensor of the image gradient (row = the centre tap).
+    `bias_tail` = ("rows", off): the same for every row n < n_lim, at out[off + n] (a Dense layer's bias gradient)."""
     _chk_act(x, "x")
     _chk_act(dy, "dy")
     B = x.shape[0]
@@ -1667,6 +1668,8 @@ def conv_wgrad(x, dy, g: ConvGeom, layout="A", out=None, box=None, x_affine=None
     if bias_tail is not None:
         if bias_tail[0] == "row":
             brow, boff = int(bias_tail[1]), int(bias_tail[2])
+        elif bias_tail[0] == "rows":           # every row: sum_m dY[m][n] at out[off + n]
+            brow, boff = -2, int(bias_tail[1])
         else:
             bcol, boff = int(bias_tail[0]), int(bias_tail[1])
     xs = xh = None

@@ -151,6 +151,32 @@ def test_wgrad_bias_tail_from_a_row_sum_of_the_dy_operand(hip, B, affine):
     assert abs(float(flat[off]) - ref) <= 1e-3 * float(img[..., 0].float().abs().sum()) / 30 + 1e-3
 
 
+@pytest.mark.parametrize("shape", [(1000, 128, 6272), (37, 200, 10), (512, 64, 72)])
+def test_wgrad_bias_tail_all_rows_dense(hip, shape):
+    """Dense layer: dW and the bias gradient (column sums of dY = row sums of the kernel's dY operand) from one
+    launch; the weight part must equal the plain call bit for bit, the tail the fp32 column sums."""
+    M, K, N = shape
+    g = G.ConvGeom(1, 1, K, 1, 1, N, 1, 1).check()
+    Kp, Np = hip.pad8(K), hip.pad8(N)
+    torch.manual_seed(23)
+    x = torch.zeros(M, 1, 1, Kp)
+    x[..., :K] = torch.randn(M, 1, 1, K)
+    dy = torch.zeros(M, 1, 1, Np)
+    dy[..., :N] = torch.randn(M, 1, 1, N)
+    x, dy = x.bfloat16().cuda().contiguous(), dy.bfloat16().cuda().contiguous()
+    plain = hip.conv_wgrad(x, dy, g, "A").reshape(-1)
+    numel = N * Kp
+    assert plain.numel() == numel
+    off = numel + 8
+    total = (off + N + 3) // 4 * 4
+    flat = torch.zeros(total, device="cuda")
+    hip.conv_wgrad(x, dy, g, "A", out=flat, box=(N, Kp, Kp, Kp, 1, total), bias_tail=("rows", off))
+    assert torch.equal(flat[:numel], plain)
+    assert float(flat[numel:off].abs().max()) == 0.0
+    ref = dy.float().sum(dim=(0, 1, 2))[:N]
+    close(flat[off:off + N].cpu(), ref.cpu(), rtol=1e-3, atol=1e-3 * float(ref.abs().max()) + 1e-3)
+
+
 @pytest.mark.parametrize("impl", ["pconv", "igemm"])
 @pytest.mark.parametrize("prev", ["relu", "leaky", "linear", "tanh"])
 def test_dgrad_fused_act_grad_is_bit_identical_to_the_separate_pass(hip, impl, prev, monkeypatch):
