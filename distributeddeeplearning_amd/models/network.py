@@ -394,7 +394,7 @@ class ConvOp(Op):
                 def wg():
                     # the bias gradient (column sums of dY) as row sums of the weight gradient's dY operand: one more
                     # MFMA per sub-tile against a fragment of ones, no reduction pass of its own
-                    tail = self._bias_tail(1) if (dy.is_cuda and self.kstruct is None) else None
+                    tail = self._bias_tail(1) if dy.is_cuda else None
                     if tail is not None:
                         off, flat = tail
                         Ip = x4.shape[-1]
