@@ -158,10 +158,10 @@ def main():
 
     for _ in range(a.warmup):
         runner.step()
-    sync()
     if on_gpu:          # the graphed runners persisted their tuned plans before capture; eager ones do it here
         from distributeddeeplearning_amd.ops import functional as F
         F.hip_backend().save_choice_cache()
+    sync()
     t0 = time.perf_counter()
     for _ in range(a.steps):
         runner.step()
