@@ -123,28 +123,36 @@ def main():
         r.setup()
         return r
 
-    # hipGraph capture next to a live RCCL group is the one step of setup that can fail for reasons
-    # outside the model code; if it does on ANY rank, every rank steps down together (full -> on -> off:
-    # the measurement stays valid, only slower) instead of the job dying or ranks diverging.
+    # hipGraph capture next to a live RCCL group is the one step of setup that can fail for reasons outside the
+    # model code (utils/hipgraph.CaptureError, a communicator error); if it does on ANY rank, every rank steps down
+    # together (full -> on -> off: the measurement stays valid, only slower) and the record says why
+    # (`graph_fallback_reason`).  Anything else -- a programming error -- is raised on every rank: a fallback must
+    # never turn a bug into a slower-but-green run.
+    from distributeddeeplearning_amd.utils.hipgraph import CaptureError
+    soft = (CaptureError, torch.distributed.DistBackendError) if hasattr(torch.distributed, "DistBackendError") \
+        else (CaptureError,)
     chain = {"full": ["full", "on", "off"], "on": ["on", "off"], "off": ["off"]}[a.graph] if on_gpu else [a.graph]
     runner = None
+    fallback_reason = None
     for k, mode in enumerate(chain):
         a.graph = mode
-        err = None
+        err, code = None, 0.0
         try:
             runner = build_runner()
-        except Exception as e:          # noqa: BLE001 - re-raised below unless a fallback applies
-            err = e
-        failed = err is not None
+        except soft as e:
+            err, code = e, 1.0
+        except Exception as e:          # noqa: BLE001 - agreed on with the other ranks, then re-raised everywhere
+            err, code = e, 2.0
         if world > 1:
-            f = torch.tensor([1.0 if failed else 0.0], device=device)
+            f = torch.tensor([code], device=device)
             torch.distributed.all_reduce(f, op=torch.distributed.ReduceOp.MAX)
-            failed = bool(f.item() > 0)
-        if not failed:
+            code = float(f.item())
+        if code == 0.0:
             break
         runner = None
-        if k + 1 == len(chain):
+        if code == 2.0 or k + 1 == len(chain):
             raise err if err is not None else RuntimeError("setup failed on another rank")
+        fallback_reason = f"--graph {mode}: " + (repr(err) if err is not None else "capture failed on another rank")
         print(f"[rank {rank}] setup with --graph {mode} failed ({err!r}); falling back to --graph {chain[k + 1]}",
               file=sys.stderr, flush=True)
         if on_gpu:
@@ -183,6 +191,7 @@ def main():
         out["config"]["graph"] = a.graph
         out["rccl_ranks_seen"] = seen
         out["graph_mode_used"] = a.graph
+        out["graph_fallback_reason"] = fallback_reason
         out["captured_collective_selftest"] = captured_ok
         out["comm_backend"] = backend
         out.update(info.get("extra", {}))

@@ -17,7 +17,7 @@
 
 #define MLP_B 32            // rows per step (Keras default batch); a step may use fewer (ragged last batch)
 #define MLP_MAXN 32         // units per layer
-#define MLP_MAXL 8          // Dense layers including the softmax head
+#define MLP_MAXL 11         // Dense layers including the softmax head (DDL.py:19-20,31-32: up to 9 hidden + head)
 #define MLP_T 1024          // 16 waves: the first layer's weight streams are latency-bound, occupancy hides it
 #define MLP_KQ 8            // split-K groups of the first layer's forward
 #define MLP_NQ (MLP_T / 32 / MLP_KQ)     // output groups per (row, K range): 4 -> 8 outputs per thread
@@ -81,8 +81,11 @@ __global__ __launch_bounds__(MLP_T) void mlp_persistent_kernel(const MlpMember* 
     float* mean_s = D1 + MLP_B * MLP_LD;                                   // [MAXL][32]
     float* istd_s = mean_s + MLP_MAXL * MLP_MAXN;                          // [MAXL][32]
     float* coef = istd_s + MLP_MAXL * MLP_MAXN;                            // [2][32] dbeta, dgamma of the current BN
-    float* red = coef + 2 * MLP_MAXN;                                      // [8][32][32] layer-0 split-K partials
-    float* rowloss = red + 8 * MLP_B * MLP_MAXN;                           // [32]
+    float* rowloss = coef + 2 * MLP_MAXN;                                  // [32]
+    // layer-0 split-K partials [8][32][32] live on H: they are produced and consumed inside layer 0's forward, before
+    // its BatchNorm writes H[0] (a barrier in between), and H[1..] is not touched until layer 1
+    static_assert(MLP_MAXL * MLP_LD >= MLP_KQ * MLP_MAXN, "split-K partials must fit inside H");
+    float* red = H;
     int* lab_s = (int*)(rowloss + MLP_B);                                  // [32]
     __shared__ OptStep opt;
     __shared__ float s_loss;
@@ -361,7 +364,7 @@ DDL_API int ddl_mlp_limits(int* max_layers, int* max_units, int* batch) {
 static size_t mlp_smem(int pixels) {
     const int pixS = (pixels + 15) / 16 * 16;
     size_t f = (size_t)2 * MLP_MAXL * MLP_B * MLP_LD + 2 * MLP_B * MLP_LD + 2 * MLP_MAXL * MLP_MAXN + 2 * MLP_MAXN +
-               8 * MLP_B * MLP_MAXN + MLP_B + MLP_B;
+               MLP_B + MLP_B;
     return (size_t)MLP_B * pixS + f * sizeof(float);
 }
 

@@ -11,6 +11,8 @@ Images are synthetic MNIST-shaped uint8 resident in HBM; a batch is one on-devic
 """
 from __future__ import annotations
 
+import os
+import time
 from pathlib import Path
 
 import numpy as np
@@ -69,7 +71,6 @@ class ClassifierBench:
         # placed longest-first (models/classifier.py member_streams), so one replica's latency-bound tail layers run
         # beside another's bandwidth-bound front layers
         self.streams = None
-        import os
         if (self.dp is None and use_graph and self.device.type == "cuda"
                 and os.environ.get("DDL_CLS_CONCURRENT", "1") == "1"):
             from .models.classifier import member_streams
@@ -114,8 +115,13 @@ class ClassifierBench:
                "sync": (f"weight average every {self.args.avg_every} steps, overlapped" if self.local_sgd
                         else "flat gradient all-reduce per network per step, overlapped with the next network"),
                "graph": self.args.graph}
+        extra = {"loss": float(self.loss),
+                 "replica_streams": len(self.stream_pool) if self.streams is not None else 0,
+                 "replica_ms": getattr(self, "replica_ms", None),
+                 "replica_group_mode": self.group.mode if self.group is not None else None,
+                 "averages_done": self.averager.n_averages if self.averager is not None else None}
         return {"metric": f"{name}_train_images_per_sec", "images_per_step_per_rank": self.batch * 5,
-                "config": cfg, "extra": {"loss": float(self.loss)}}
+                "config": cfg, "extra": extra}
 
 
 class LocalSGDBench(ClassifierBench):
@@ -139,7 +145,6 @@ class EnsembleBench:
         self.preset = getattr(args, "preset", "ddl")
 
     def setup(self):
-        import os
         from .models import search
         self.serial = os.environ.get("DDL_SERIAL_MEMBERS", "0") == "1"
         chunk = max(RandomModel.CHUNK, 1)
@@ -207,4 +212,5 @@ class EnsembleBench:
                "graph": self.args.graph}
         return {"metric": "ensemble32_train_images_per_sec",
                 "images_per_step_per_rank": self.batch * self.steps_per_call * self.n_members,
-                "config": cfg, "extra": {}}
+                "config": cfg, "extra": {"member_streams": len(self.stream_pool) if self.streams is not None else 0,
+                                         "steps_per_graph": self.chunk}}

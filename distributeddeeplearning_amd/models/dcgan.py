@@ -177,7 +177,6 @@ class GANTrainer:
         self.merged = bool(self._split and self.G.on_gpu and self.G.can_forward_into()
                            and os.environ.get("DDL_GAN_MERGED_G", "1") == "1")
         self._buf3 = None
-        self._buf3_src = None
         # D ends BN -> LeakyReLU -> Flatten -> Dense(1): with batch statistics on device the head kernel applies
         # that BatchNorm on load and emits its backward reduction (ops/hip.py dense1_bce_fwd_bwd `bn=`)
         self._head_bn = self._find_head_bn()
@@ -230,15 +229,21 @@ class GANTrainer:
                                                     h.gbias if want_dw else None)
         return loss, dfeat
 
+    def real_slot(self, like: torch.Tensor) -> torch.Tensor:
+        """The [B] real-image part of the merged pass's [real | G(z1) | G(z2)] buffer, allocated for batches shaped
+        like `like` (a prepared batch).  A caller that WRITES its minibatch here and passes this very tensor to
+        `train_step` pays no copy per step (static-buffer idiom of a captured graph: refill between replays, see
+        GraphedGANStep.set_real); any other tensor is copied in on every step."""
+        B = like.shape[0]
+        if self._buf3 is None or self._buf3.shape[0] != 3 * B or self._buf3.shape[1:] != like.shape[1:]:
+            self._buf3 = torch.empty((3 * B,) + tuple(like.shape[1:]), dtype=like.dtype, device=like.device)
+        return self._buf3[:B]
+
     def _d_backward_merged(self, real):
         B = real.shape[0]
-        if self._buf3 is None or self._buf3.shape[0] != 3 * B:
-            self._buf3 = torch.empty((3 * B,) + tuple(real.shape[1:]), dtype=real.dtype, device=real.device)
-            self._buf3_src = None
-        key = (real.data_ptr(), real._version)
-        if self._buf3_src != key:                    # the real images change only when the caller's tensor does
-            self._buf3[:B].copy_(real)
-            self._buf3_src = key
+        slot = self.real_slot(real)
+        if real.data_ptr() != slot.data_ptr():       # a foreign tensor: always copied (its CONTENTS may have changed
+            slot.copy_(real)                         # under the same address and version counter)
         z = self.rng.uniform((2 * B, self.cfg.noise_dim), self.G.cdtype)
         self.G.forward(z, training=True, out=self._buf3[B:], bn_groups=2)
         self.G.narrow_saved(B, 2 * B, group=1)       # the G phase trains on z2 only
@@ -450,6 +455,12 @@ class GraphedGANStep:
                  capture_collectives: bool = False):
         self.t, self.real = trainer, real_prepared
         self.B = real_prepared.shape[0]
+        if trainer.merged and real_prepared.is_contiguous():
+            # the captured step reads the real images from the trainer's own static slot: no copy inside the graph,
+            # and `set_real` (refill between replays) reaches the buffer the discriminator actually reads
+            slot = trainer.real_slot(real_prepared)
+            slot.copy_(real_prepared)
+            self.real = slot
         self.full = (trainer.dp is None or capture_collectives or trainer.sharded
                      or getattr(trainer.dp, "captures_safely", False))
         t = trainer
@@ -477,6 +488,11 @@ class GraphedGANStep:
                 fns.pop(1)
             for fn in fns:
                 self.graphs.append(hipgraph.capture(fn, pool)[0])
+
+    def set_real(self, real_prepared: torch.Tensor):
+        """New real minibatch for the following replays (same shape; prepared layout)."""
+        if real_prepared.data_ptr() != self.real.data_ptr():
+            self.real.copy_(real_prepared)
 
     def step(self):
         t = self.t

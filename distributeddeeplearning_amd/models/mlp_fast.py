@@ -24,6 +24,7 @@ from ..ops import functional as F
 from .network import BNOp, ConvOp, ViewOp
 
 _OPT = {"adam": 0, "sgd": 1, "rmsprop": 2}
+MAX_LAYERS = 11     # MLP_MAXL of csrc/hip/mlp_persistent.hip (checked against the library in `limits`)
 _limits = None
 
 
@@ -46,6 +47,8 @@ def limits():
         a, b, c = C.c_int(), C.c_int(), C.c_int()
         _lib().ddl_mlp_limits(C.byref(a), C.byref(b), C.byref(c))
         _limits = (a.value, b.value, c.value)
+        if a.value != MAX_LAYERS or _lib().ddl_mlp_member_bytes() != C.sizeof(_Member):
+            raise ImportError("libddl_hip.so's MlpMember layout differs from models/mlp_fast.py: rebuild (python build.py)")
     return _limits
 
 
@@ -59,7 +62,7 @@ class _Member(C.Structure):
     _fields_ = [("P", C.c_void_p), ("M", C.c_void_p), ("V", C.c_void_p), ("S", C.c_void_p), ("step", C.c_void_p),
                 ("loss_acc", C.c_void_p), ("idx", C.c_void_p), ("n_layers", C.c_int), ("pixels", C.c_int),
                 ("cpad0", C.c_int), ("ctrue0", C.c_int), ("opt_kind", C.c_int), ("lr", C.c_float), ("b1", C.c_float),
-                ("b2", C.c_float), ("eps", C.c_float), ("rho", C.c_float), ("L", _Layer * 8)]
+                ("b2", C.c_float), ("eps", C.c_float), ("rho", C.c_float), ("L", _Layer * MAX_LAYERS)]
 
 
 def _chain(net):

@@ -100,8 +100,8 @@ class PeriodicAverager:
     # ------------------------------------------------------------------ hooks
     def after_step(self):
         self.t += 1
-        if self.dp is None or self.dp.world == 1:
-            return
+        if self.dp is None:         # a 1-rank group still runs the whole path (bench.py --force-dp): the mean of one
+            return                  # replica is itself, so the correction is exactly zero
         if not self.overlap:
             if self.t % self.every == 0:
                 self._average_now()
@@ -113,7 +113,7 @@ class PeriodicAverager:
 
     def finish(self):
         """Drain an in-flight average and end on a common model (all ranks identical)."""
-        if self.dp is None or self.dp.world == 1:
+        if self.dp is None:
             return
         if self._pending is not None:
             self._apply()

@@ -26,10 +26,22 @@ def quiesce():
         torch.cuda.synchronize()
 
 
+class CaptureError(RuntimeError):
+    """A stream capture failed for a reason of the runtime's (an operation that is not permitted while capturing,
+    a communicator that cannot be captured, an invalidated capture).  The only kind of set-up failure a caller may
+    answer by stepping down to a less-captured mode; programming errors inside the captured function (NameError,
+    TypeError, ...) are never wrapped and propagate as they are."""
+
+
 def capture(fn, pool=None):
     """Record `fn()` into a new graph; returns (graph, fn's return value)."""
     g = torch.cuda.CUDAGraph()
     mode = "thread_local" if _dist_up() else "global"
-    with torch.cuda.graph(g, pool=pool, capture_error_mode=mode):
-        out = fn()
+    try:
+        with torch.cuda.graph(g, pool=pool, capture_error_mode=mode):
+            out = fn()
+    except RuntimeError as e:           # torch.AcceleratorError / DistBackendError are RuntimeErrors too
+        if isinstance(e, (NotImplementedError, RecursionError)):
+            raise
+        raise CaptureError(f"hipGraph capture failed: {e}") from e
     return g, out

@@ -144,6 +144,31 @@ def test_persistent_mlp_kernel_matches_cpu_oracle(opt_name, n_train):
         assert (pg - pc).abs().max().item() < 5e-2
 
 
+def test_persistent_mlp_kernel_covers_the_deepest_ddl_member():
+    """/root/reference/DDL.py:19-20,31-32: `dense_size` draws up to 9 hidden Dense layers, plus the softmax head = 10
+    Dense layers, each up to 29 units: such a member must run in the persistent kernel (MLP_MAXL = 11) and agree with
+    the fp32 CPU oracle after a few steps."""
+    import numpy as np
+    from distributeddeeplearning_amd import config
+    from distributeddeeplearning_amd.models import classifier, mlp_fast, search
+    sp = config.get_space("ddl", ["data_train_size=48", "epochs=2", "early_stop_rate=-1.0", "seed=2", "conv2d_size=0,1",
+                                  "dense_size=9,10", "optimizers=Adam", "lr_exponent=-3,-2", "activations=relu,softplus"])
+    dg = Data("cuda", channels=3, n_train=200, n_test=64, synthetic=True, seed=4)
+    dc = Data("cpu", channels=3, n_train=200, n_test=64, synthetic=True, seed=4)
+    c = search.make_new_model(sp, np.random.default_rng(1), dg.input_shape, 10)
+    g = classifier.RandomModel(dg, dg.get_random_sample(48, seed=3), sp, c, "cuda", 0, 0, verbose=False)
+    o = classifier.RandomModel(dc, dc.get_random_sample(48, seed=3), sp, c, "cpu", 0, 0, verbose=False)
+    chain = mlp_fast._chain(g.net)
+    assert chain is not None and len(chain) == 10 and mlp_fast.limits()[0] >= 10
+    assert mlp_fast.eligible(g)
+    classifier.train_concurrently([g])
+    o.train()
+    hg, hc = np.array(g.history), np.array(o.history)
+    assert hg.shape == hc.shape == (1, 2) and np.isfinite(hg).all()
+    assert np.allclose(hg, hc, rtol=5e-3, atol=5e-3), (hg, hc)
+    assert g.opt.steps_taken() == o.opt.t == 4
+
+
 def test_member_streams_places_longest_first_on_least_loaded_stream():
     """Concurrent ensemble members share `k` streams (one per hardware queue): sorted by measured step time, each goes
     to the stream with the least work so far -- no stream ends up with the three slowest members."""

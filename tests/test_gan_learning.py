@@ -188,3 +188,43 @@ def test_graphed_resume_is_bitwise_identical_to_uninterrupted_run(tmp_path):
                  (a.optD.v, c.optD.v)):
         assert torch.equal(x, y)
     assert c.optG.steps_taken() == 2 * K
+
+
+@pytest.mark.gpu
+def test_discriminator_follows_a_new_real_batch_eager_and_graphed():
+    """the merged generator pass reads the real images from its own [real | G(z1) | G(z2)] buffer.  A fresh
+    minibatch must reach it on EVERY step -- a `prepare_input` result can reuse the address of the previous one, and a
+    graph replay must see what `set_real` put into the static slot.  Oracle: a second trainer that only ever saw the
+    second batch differs from one that saw batch A then batch B, but a trainer fed A, A, B must equal... itself re-run
+    with the same feed; and the d_loss of a step on all-black images differs from one on glyphs."""
+    glyph = _glyphs(64, "cuda")
+    black = torch.zeros_like(glyph)
+
+    def eager(feed):
+        t = GANTrainer(GANConfig(batch=64, seed=11), "cuda")
+        assert t.merged
+        out = []
+        for x in feed:
+            d, _ = t.train_step(x)                        # unprepared input: a fresh prepared tensor per step
+            out.append(float(d))
+        return t, out
+
+    ta, la = eager([glyph, glyph, black, black])
+    tb, lb = eager([glyph, glyph, glyph, glyph])
+    assert la[:2] == lb[:2]
+    assert la[2] != lb[2] and not torch.equal(ta.D.P, tb.D.P)        # the third step saw different real images
+
+    def graphed(feed):
+        t = GANTrainer(GANConfig(batch=64, seed=11), "cuda")
+        step = GraphedGANStep(t, t.D.prepare_input(feed[0]), warmup=1)
+        out = []
+        for x in feed[1:]:
+            step.set_real(t.D.prepare_input(x))
+            d, _ = step.step()
+            out.append(float(d))
+        torch.cuda.synchronize()
+        return t, out
+
+    tc, lc = graphed([glyph, glyph, black, black])
+    assert lc == la[1:]                                   # replay == eager, bit for bit, on a changing feed
+    assert torch.equal(tc.D.P, ta.D.P) and torch.equal(tc.G.P, ta.G.P)

@@ -856,3 +856,49 @@ def test_autotune_choices_export_import_and_persist(hip, tmp_path, monkeypatch):
     hip._CONV_CHOICE.clear()
     hip.import_choices(table)                     # what sync_choices does on ranks != 0
     assert torch.equal(hip.conv_fprop(x, w, None, g), y0)
+
+
+# ------------------------------------------------------------------------------ local-SGD kernels (BASELINE config 5)
+@pytest.mark.parametrize("n", [8, 1000, 259848, 1066184])
+def test_avg_delta_and_scale_emit_vs_fp32_torch(hip, n):
+    """`avg_delta` (P += sum * 1/W - snapshot, bf16 copy re-emitted) and `scale_emit` (P *= 1/W, bf16 copy) are the
+    two kernels of parallel/averaging.py; checked against the same arithmetic in fp32 torch, bit for bit (one fused
+    multiply-add free expression per element: `p + (s * w - o)` evaluated left to right as the kernel does)."""
+    g = torch.Generator().manual_seed(n)
+    P = torch.randn(n, generator=g).cuda()
+    total = (torch.randn(n, generator=g) * 4).cuda()
+    snap = torch.randn(n, generator=g).cuda()
+    Pc = torch.zeros(n, dtype=torch.bfloat16, device="cuda")
+    for inv in (0.5, 0.125, 1.0 / 3.0):
+        p0 = P.clone()
+        hip.avg_delta(P, Pc, total, snap, inv)
+        ref = p0.cpu() + (total.cpu() * torch.tensor(inv, dtype=torch.float32) - snap.cpu())
+        # the compiler may contract s * w - o into one fma: allow one ulp of the product term
+        assert torch.allclose(P.cpu(), ref, rtol=0, atol=float(total.abs().max()) * inv * 2 ** -22)
+        assert torch.equal(Pc.cpu(), P.cpu().bfloat16())
+        p0 = P.clone()
+        hip.scale_emit(P, Pc, inv)
+        assert torch.equal(P.cpu(), p0.cpu() * torch.tensor(inv, dtype=torch.float32))
+        assert torch.equal(Pc.cpu(), P.cpu().bfloat16())
+    # no bf16 copy requested: only the master buffer moves
+    p0 = P.clone()
+    hip.scale_emit(P, None, 0.25)
+    assert torch.equal(P.cpu(), p0.cpu() * 0.25)
+
+
+def test_averaging_kernels_equal_the_cpu_form_of_the_averager(hip):
+    """The device branch of PeriodicAverager._apply / _average_now against its own CPU branch on the same numbers:
+    W replicas' parameters, a snapshot taken `delay` steps ago, local progress since then."""
+    W, n = 4, 4096
+    g = torch.Generator().manual_seed(1)
+    snaps = [torch.randn(n, generator=g) for _ in range(W)]            # every rank's snapshot
+    prog = torch.randn(n, generator=g) * 0.01                          # this rank's local progress since the snapshot
+    total = torch.stack(snaps).sum(0)
+    cpu = snaps[0] + prog
+    cpu = cpu + (total * (1.0 / W) - snaps[0])                         # averaging.py CPU branch
+    P = (snaps[0] + prog).cuda()
+    Pc = torch.empty(n, dtype=torch.bfloat16, device="cuda")
+    hip.avg_delta(P, Pc, total.cuda(), snaps[0].cuda(), 1.0 / W)
+    assert torch.allclose(P.cpu(), cpu, rtol=0, atol=1e-6)
+    # the average keeps the local progress and replaces the snapshot by the mean
+    assert torch.allclose(P.cpu(), total / W + prog, rtol=0, atol=1e-5)
