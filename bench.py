@@ -5,10 +5,16 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 One step = the reference iteration (/root/reference/GAN_distributed.py:133-135): a D update on
-[B real ; B generated] and a G update on B noise vectors, Adam(2e-4), per rank, with one flat
-RCCL all-reduce per network per step.  B = 1000 per GPU as in the reference (weak scaling: the
-global batch grows with N).  `value` = real images consumed per second by the whole job.
-Other BASELINE.json configs: --config dcgan64 | classifier | localsgd.
+[B real ; B generated] and a G update on B noise vectors, Adam(2e-4), per rank, gradients averaged over the ranks
+every step.  B = 1000 per GPU as in the reference (weak scaling: the global batch grows with N).
+`value` = real images consumed per second by the whole job.
+Other BASELINE.json configs: --config dcgan64 | classifier | localsgd | ensemble32.
+
+Under N > 1 the job chooses its data-parallel step by measurement before the timed region
+(distributeddeeplearning_amd/parallel/dp_tune.py): RCCL or the xGMI direct all-reduce kernel (probed in child
+processes first, validated against RCCL, health-checked after warm-up and after the timed loop), merged or split
+generator pass, bucketed or flat gradient all-reduce; the record says what was chosen and what it cost
+(`comm_chosen`, `dp_variant`, `allreduce_us_{D,G}`, `exposed_comm_us_per_step`).
 """
 import argparse
 import json
@@ -38,20 +44,27 @@ def main():
                          "collectives are captured too (one graph per step), auto = full if the start-up self-test "
                          "of a captured all-reduce passes on every rank (parallel/selfcheck.py), else on")
     ap.add_argument("--comm-dtype", default="fp32", choices=["fp32", "bf16"])
-    ap.add_argument("--comm", default="torch", choices=["torch", "rccl", "p2p"],
+    ap.add_argument("--comm", default="auto", choices=["auto", "torch", "rccl", "p2p"],
                     help="gradient all-reduce through torch.distributed (nccl == RCCL), the native C++ RCCL "
                          "communicator, or the xGMI direct all-reduce kernel with the optimizer fused into its "
-                         "epilogue (csrc/comm/p2p_allreduce.hip; validated against RCCL at start-up, RCCL if it fails)")
+                         "epilogue (csrc/comm/p2p_allreduce.hip).  auto (dcgan configs): both are built, the kernel is "
+                         "validated against RCCL, and the faster one on the real step is used")
+    ap.add_argument("--dp-variant", default="auto", choices=["auto", "default"],
+                    help="dcgan28 under data parallelism: auto = time {merged, split generator pass} x {bucketed, "
+                         "flat all-reduce} x communicators at start-up and keep the fastest; default = merged + "
+                         "bucketed on the communicator --comm names (RCCL for auto)")
+    ap.add_argument("--no-probe", action="store_true",
+                    help="skip the child-process probe of the xGMI kernel (N > 1 only; it costs a few seconds)")
     ap.add_argument("--avg-every", type=int, default=8, help="local-SGD averaging period (config localsgd)")
     ap.add_argument("--zero", action="store_true",
                     help="dcgan configs, N>1: reduce-scatter + sharded update + all-gather instead of all-reduce")
     ap.add_argument("--force-dp", action="store_true",
-                    help="diagnostics: run the data-parallel code path (segmented graphs + collectives) on a "
+                    help="diagnostics: run the data-parallel code path (collectives, start-up selection) on a "
                          "1-rank process group, to price its overhead without a second GPU")
     ap.add_argument("--device", default="cuda")
     a = ap.parse_args()
 
-    from distributeddeeplearning_amd.parallel import ddp
+    from distributeddeeplearning_amd.parallel import ddp, dp_tune
     on_gpu = a.device == "cuda"
     if on_gpu and not torch.cuda.is_available():
         print("bench.py needs a GPU (use --device cpu for a plumbing run)", file=sys.stderr)
@@ -69,56 +82,56 @@ def main():
     if world != a.gpus:
         if rank == 0:
             print(f"warning: --gpus {a.gpus} but WORLD_SIZE={world}; using {world}", file=sys.stderr)
-    dp = None
+
+    # ---- communicators ------------------------------------------------------------------------------------------
+    base, p2p, base_name = None, None, "none"
     if world > 1 or a.force_dp:
         cd = torch.bfloat16 if a.comm_dtype == "bf16" else None
         if a.comm == "rccl" and on_gpu:
             from distributeddeeplearning_amd.parallel.rccl import RcclCommunicator
-            dp = RcclCommunicator.from_env(device, comm_dtype=cd)
+            base, base_name = RcclCommunicator.from_env(device, comm_dtype=cd), "rccl-native"
         else:
-            dp = ddp.FlatDataParallel(comm_dtype=cd)
-        if a.comm == "p2p" and on_gpu:
-            from distributeddeeplearning_amd.parallel.p2p import P2PAllReduce
-            p2p, p2p_ok = None, False
-            try:
-                p2p = P2PAllReduce(dp, device, 1 << 22)          # 16 MB of fp32: the largest flat gradient is 4.3 MB
-            except Exception as e:      # noqa: BLE001 - fall back below, on every rank together
-                print(f"[rank {rank}] xGMI all-reduce unavailable: {e!r}", file=sys.stderr, flush=True)
-            f = torch.tensor([0.0 if p2p is not None else 1.0], device=device)
-            torch.distributed.all_reduce(f, op=torch.distributed.ReduceOp.MAX)
-            if float(f.item()) == 0.0:
-                p2p_ok = p2p.validate(1 << 20)
-            if p2p_ok:
-                dp = p2p
-            else:
-                a.comm = "torch"
-                if rank == 0:
-                    print("xGMI all-reduce failed its validation against RCCL: using RCCL", file=sys.stderr, flush=True)
+            base = ddp.FlatDataParallel(comm_dtype=cd)
+            base_name = "torch.distributed/" + torch.distributed.get_backend()
+        want_p2p = on_gpu and not a.zero and (a.comm == "p2p" or (a.comm == "auto" and a.config in ("dcgan28", "dcgan64")))
+        if want_p2p:        # 16 MB of fp32 staging: the largest flat gradient (64x64 generator) is 12.8 MB
+            p2p = dp_tune.build_p2p(base, device, 1 << 22, probe=not a.no_probe, verbose=True)
+            if p2p is None and rank == 0:
+                print("xGMI all-reduce not available / not validated: staying on RCCL", file=sys.stderr, flush=True)
+    p2p_name = "xgmi-p2p all-reduce + fused optimizer (bootstrap " + base_name + ")"
 
     from distributeddeeplearning_amd import benchmarks
     from distributeddeeplearning_amd.parallel import selfcheck
+    from distributeddeeplearning_amd.utils.hipgraph import CaptureError
 
     # N > 1: prove the communicator spans N ranks, then let the captured-collective self-test pick the graph mode
-    seen = selfcheck.ranks_seen(dp, device)
+    seen = selfcheck.ranks_seen(base, device)
     captured_ok = None
     if a.graph == "auto":
-        if dp is None or not on_gpu:
+        if base is None or not on_gpu:
             a.graph = "on" if on_gpu else "off"
-        elif getattr(dp, "captures_safely", False):
-            a.graph = "full"             # the xGMI kernel is an ordinary launch: nothing of RCCL inside the graph
         else:
-            captured_ok = selfcheck.captured_collective_ok(dp, device, verbose=True)
+            captured_ok = selfcheck.captured_collective_ok(base, device, verbose=True)
             a.graph = "full" if captured_ok else "on"
-    if dp is None:
-        backend = "none"
-    elif a.comm == "rccl" and on_gpu:
-        backend = "rccl-native"
-    elif a.comm == "p2p" and on_gpu:
-        backend = "xgmi-p2p all-reduce + fused optimizer (bootstrap torch.distributed/" + torch.distributed.get_backend() + ")"
-    else:
-        backend = "torch.distributed/" + torch.distributed.get_backend()
+    graph_wanted = a.graph
 
-    def build_runner():
+    def sync():
+        if world > 1:
+            torch.distributed.barrier()
+        if on_gpu:
+            torch.cuda.synchronize()
+
+    def build_runner(use_p2p: bool):
+        """dp / comms for this attempt; dcgan configs may tune between the candidates in `a.comms`."""
+        a.comms, a.full_ok = {}, {}
+        if base is not None:
+            if a.comm != "p2p" or p2p is None or not use_p2p:
+                a.comms[base_name], a.full_ok[base_name] = base, a.graph == "full"
+            if p2p is not None and use_p2p:
+                a.comms[p2p_name], a.full_ok[p2p_name] = p2p, True
+        dp = None
+        if base is not None:
+            dp = p2p if (a.comm == "p2p" and p2p is not None and use_p2p) else base
         r = benchmarks.make(a.config, device, dp, rank, a)
         r.setup()
         return r
@@ -128,57 +141,70 @@ def main():
     # together (full -> on -> off: the measurement stays valid, only slower) and the record says why
     # (`graph_fallback_reason`).  Anything else -- a programming error -- is raised on every rank: a fallback must
     # never turn a bug into a slower-but-green run.
-    from distributeddeeplearning_amd.utils.hipgraph import CaptureError
     soft = (CaptureError, torch.distributed.DistBackendError) if hasattr(torch.distributed, "DistBackendError") \
         else (CaptureError,)
-    chain = {"full": ["full", "on", "off"], "on": ["on", "off"], "off": ["off"]}[a.graph] if on_gpu else [a.graph]
-    runner = None
-    fallback_reason = None
-    for k, mode in enumerate(chain):
-        a.graph = mode
-        err, code = None, 0.0
-        try:
-            runner = build_runner()
-        except soft as e:
-            err, code = e, 1.0
-        except Exception as e:          # noqa: BLE001 - agreed on with the other ranks, then re-raised everywhere
-            err, code = e, 2.0
-        if world > 1:
-            f = torch.tensor([code], device=device)
-            torch.distributed.all_reduce(f, op=torch.distributed.ReduceOp.MAX)
-            code = float(f.item())
-        if code == 0.0:
-            break
-        runner = None
-        if code == 2.0 or k + 1 == len(chain):
-            raise err if err is not None else RuntimeError("setup failed on another rank")
-        fallback_reason = f"--graph {mode}: " + (repr(err) if err is not None else "capture failed on another rank")
-        print(f"[rank {rank}] setup with --graph {mode} failed ({err!r}); falling back to --graph {chain[k + 1]}",
-              file=sys.stderr, flush=True)
-        if on_gpu:
-            torch.cuda.synchronize()
 
-    def sync():
-        if world > 1:
-            torch.distributed.barrier()
-        if on_gpu:
-            torch.cuda.synchronize()
+    def setup_with_fallback(use_p2p: bool):
+        chain = {"full": ["full", "on", "off"], "on": ["on", "off"], "off": ["off"]}[a.graph] if on_gpu else [a.graph]
+        reason = None
+        for k, mode in enumerate(chain):
+            a.graph = mode
+            err, code, runner = None, 0.0, None
+            try:
+                runner = build_runner(use_p2p)
+            except soft as e:
+                err, code = e, 1.0
+            except Exception as e:          # noqa: BLE001 - agreed on with the other ranks, then re-raised everywhere
+                err, code = e, 2.0
+            code = dp_tune.agree_max(code, device)
+            if code == 0.0:
+                return runner, reason
+            if code == 2.0 or k + 1 == len(chain):
+                raise err if err is not None else RuntimeError("setup failed on another rank")
+            reason = f"--graph {mode}: " + (repr(err) if err is not None else "capture failed on another rank")
+            print(f"[rank {rank}] setup with --graph {mode} failed ({err!r}); falling back to --graph {chain[k + 1]}",
+                  file=sys.stderr, flush=True)
+            if on_gpu:
+                torch.cuda.synchronize()
 
-    for _ in range(a.warmup):
-        runner.step()
-    if on_gpu:          # the graphed runners persisted their tuned plans before capture; eager ones do it here
-        from distributeddeeplearning_amd.ops import functional as F
-        F.hip_backend().save_choice_cache()
-    sync()
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        runner.step()
-    sync()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=device)
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        dt = float(t.item())
+    def p2p_in_use(runner):
+        dp = getattr(getattr(runner, "t", None), "dp", None) or getattr(runner, "dp", None)
+        return dp if (dp is not None and hasattr(dp, "healthy_everywhere")) else None
+
+    # The xGMI kernel answers a time-out (a peer that never signals) with a sticky status word and from then on skips
+    # every reduction AND the fused update: a dead communicator runs FASTER than a healthy one.  So its health is
+    # read, and agreed across ranks, after the warm-up and after the timed loop; an unhealthy run is thrown away and
+    # repeated on RCCL.
+    p2p_healthy, p2p_dropped = None, None
+    for attempt, use_p2p in enumerate((True, False)):
+        a.graph = graph_wanted
+        runner, fallback_reason = setup_with_fallback(use_p2p and p2p is not None)
+        for _ in range(a.warmup):
+            runner.step()
+        if on_gpu:          # the graphed runners persisted their tuned plans before capture; eager ones do it here
+            from distributeddeeplearning_amd.ops import functional as F
+            F.hip_backend().save_choice_cache()
+        live = p2p_in_use(runner)
+        if live is not None and not live.healthy_everywhere():
+            p2p_healthy, p2p_dropped = False, "a wait inside the xGMI kernel timed out during warm-up"
+            continue
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(a.steps):
+            runner.step()
+        sync()
+        dt = time.perf_counter() - t0
+        if live is not None:
+            p2p_healthy = live.healthy_everywhere()
+            if not p2p_healthy:
+                p2p_dropped = "a wait inside the xGMI kernel timed out during the timed loop"
+                continue
+        break
+    else:
+        raise RuntimeError("the run did not complete on either communicator")
+    if p2p_dropped is not None and rank == 0:
+        print(f"xGMI all-reduce dropped ({p2p_dropped}); the record below was measured on RCCL", file=sys.stderr, flush=True)
+    dt = dp_tune.agree_max(dt, device)
     info = runner.describe()
     images = info["images_per_step_per_rank"] * world * a.steps
     if rank == 0:
@@ -193,7 +219,11 @@ def main():
         out["graph_mode_used"] = a.graph
         out["graph_fallback_reason"] = fallback_reason
         out["captured_collective_selftest"] = captured_ok
-        out["comm_backend"] = backend
+        live = p2p_in_use(runner)
+        out["comm_backend"] = "none" if base is None else (p2p_name if live is not None else base_name)
+        out["p2p_validated"] = None if base is None else (p2p is not None)
+        out["p2p_healthy"] = p2p_healthy
+        out["p2p_dropped"] = p2p_dropped
         out.update(info.get("extra", {}))
         print(json.dumps(out), flush=True)
     if torch.distributed.is_initialized():

@@ -16,9 +16,32 @@ class _DCGAN:
         gen = torch.Generator().manual_seed(1234 + self.rank)
         real = torch.rand(self.batch, self.size, self.size, 1, generator=gen)    # synthetic [0,1] images
         self.real = self.t.D.prepare_input(real)
-        self.graphed = None
+        self.graphed, self.dp_report = None, {}
+        comms = getattr(self.args, "comms", None) or {}
         if self.device.type == "cuda" and self.args.graph != "off":
-            self.graphed = GraphedGANStep(self.t, self.real, capture_collectives=self.args.graph == "full")
+            tune = (self.dp is not None and comms and not getattr(self.args, "zero", False)
+                    and getattr(self.args, "dp_variant", "default") == "auto" and self.size == 28)
+            if tune:        # communicator x generator pass x bucketing, timed on this machine (parallel/dp_tune.py)
+                from .parallel import dp_tune
+                self.graphed, self.dp_report = dp_tune.tune_gan_step(self.t, self.real, comms, self.args.full_ok,
+                                                                     verbose=self.rank == 0)
+            else:
+                from .parallel import dp_tune
+                if self.dp is not None and len(comms) > 1:
+                    # no step tuning (64x64: a step is ~170 ms, the collectives are noise): the communicator with
+                    # the lower latency on the two real gradient sizes
+                    lat = {n: sum(dp_tune.allreduce_latency_us(c, net.G.numel(), self.device) for net in (self.t.D, self.t.G))
+                           for n, c in comms.items()}
+                    name = min(lat, key=lat.get)
+                    self.t.set_comm(comms[name])
+                    self.dp_report = {"comm_chosen": name, "allreduce_us_D_plus_G": {k: round(v, 2) for k, v in lat.items()}}
+                full = self.args.graph == "full" or getattr(self.t.dp, "captures_safely", False)
+                self.graphed = GraphedGANStep(self.t, self.real, capture_collectives=full)
+                if self.dp is not None:
+                    self.dp_report.setdefault("comm_chosen", next((n for n, c in comms.items() if c is self.t.dp), None))
+                    self.dp_report["dp_variant"] = {"merged_generator_pass": self.t.merged,
+                                                    "bucketed_allreduce": bool(self.t.buckets and self.graphed.full),
+                                                    "fused_optimizer_in_allreduce": bool(self.t.fused)}
 
     def step(self):
         if self.graphed is not None:
@@ -35,7 +58,7 @@ class _DCGAN:
                            "graph": self.args.graph},
                 "extra": {"d_loss": float(self.t.d_loss), "g_loss": float(self.t.g_loss),
                           "hbm_high_water_gb": (round(torch.cuda.max_memory_allocated(self.device) / 2 ** 30, 2)
-                                                if self.device.type == "cuda" else None)}}
+                                                if self.device.type == "cuda" else None), **self.dp_report}}
 
 
 def make(name, device, dp, rank, args):

@@ -169,6 +169,17 @@ class GANTrainer:
         self.fused = bool(dp is not None and not self.sharded and self.G.on_gpu
                           and getattr(dp, "supports_fused_update", False))
         self._comm_stream = torch.cuda.Stream() if (dp is not None and self.G.on_gpu) else None
+        # Gradient buckets (Network.grad_buckets): the tail of each flat gradient buffer -- D: conv3 + BN + head, 0.8
+        # of its 1.04 MB; G: the transposed convolutions -- is all-reduced on the communication stream as soon as
+        # its last layer's backward has been issued, under the rest of the backward pass; only the bucket that
+        # finishes last (D: conv1 + conv2, 0.2 MB; G: the Dense layer) stays exposed.  One launch per bucket in a
+        # fixed order on every rank; sums are elementwise, so bucketed == unbucketed bit for bit for any
+        # communicator whose per-element summation order does not depend on the buffer length (the xGMI kernel: rank
+        # order; two ranks: commutative).  DDL_DP_BUCKETS=1 restores one collective per network.
+        nb = int(os.environ.get("DDL_DP_BUCKETS", "2"))
+        self.buckets = bool(dp is not None and not self.sharded and nb > 1)
+        self._bk = {id(n): n.grad_buckets(max(nb, 1)) for n in (self.D, self.G)}
+        self.comm_off = False           # measurement knob (parallel/dp_tune.py): same step, collectives skipped
         # "split" policy on device: the generator's weights are the same in the D phase and in the G phase of an
         # iteration (G is updated last), so both forwards run as ONE pass over [z1 ; z2] with per-half batch
         # statistics: half the generator launches, each on twice the rows (these kernels do not fill 256 CUs at
@@ -249,7 +260,7 @@ class GANTrainer:
         self.G.narrow_saved(B, 2 * B, group=1)       # the G phase trains on z2 only
         self._fake = self._buf3[2 * B:]
         loss, resume = self._d_forward_head(self._buf3[:2 * B], 2, B, 1.0, 0.0, True)
-        resume(need_input_grad=False)
+        resume(need_input_grad=False, after_op=self._bucket_hook(self.D, self.optD))
         self.d_loss = loss
         return loss
 
@@ -272,7 +283,7 @@ class GANTrainer:
         if g_train:
             self.G.release()
         loss, resume = self._d_forward_head(xs, 2 if self._split else 1, B, 1.0, 0.0, True)
-        resume(need_input_grad=False)
+        resume(need_input_grad=False, after_op=self._bucket_hook(self.D, self.optD))
         self.d_loss = loss
         return loss
 
@@ -292,7 +303,8 @@ class GANTrainer:
         from .network import FUSE_ACT_BWD
         mul = Network.act_owner(self.G.ops[-1]) if (FUSE_ACT_BWD and isinstance(self.D.ops[0], ConvOp)) else None
         dfake = resume(need_input_grad=True, need_dw=False, input_mul=mul)
-        self.G.backward(dfake, need_input_grad=False, dy_premultiplied=mul is not None)
+        self.G.backward(dfake, need_input_grad=False, dy_premultiplied=mul is not None,
+                        after_op=self._bucket_hook(self.G, self.optG))
         self.g_loss = loss
         self._fake = None
         return loss
@@ -304,7 +316,7 @@ class GANTrainer:
 
     def phase_b(self, B):
         """D update, then G forward / D dgrad / G backward (local gradients in G.G)."""
-        if not self.fused:
+        if not self.fused or self.comm_off:
             self.optD.step(self._gscale)
         return self.g_backward(B)
 
@@ -313,58 +325,99 @@ class GANTrainer:
         return self.g_forward(B)
 
     def phase_b2(self, B):
-        if not self.fused:
+        if not self.fused or self.comm_off:
             self.optD.step(self._gscale)
         return self.g_backward(B, self._fake)
 
     def phase_c(self):
-        if not self.fused:
+        if not self.fused or self.comm_off:
             self.optG.step(self._gscale)
         self.D.release()
         self.G.release()
 
-    def reduce_D(self):
-        """Average D's gradients over the ranks (and, fused, update D): one collective / one kernel."""
-        if self.dp is None or self.sharded:
-            return
+    # ---- gradient exchange ------------------------------------------------------------------
+    def set_comm(self, dp):
+        """Swap the communicator (start-up selection between RCCL and the xGMI kernel, parallel/dp_tune.py)."""
+        self.dp = dp
+        self.fused = bool(dp is not None and not self.sharded and self.G.on_gpu
+                          and getattr(dp, "supports_fused_update", False))
+
+    def _on_comm(self, fn):
+        cs = self._comm_stream if not self.sharded else None
+        if cs is None:
+            return fn()
+        cs.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(cs):
+            return fn()
+
+    def _join_comm(self):
+        if self._comm_stream is not None and not self.sharded:
+            torch.cuda.current_stream().wait_stream(self._comm_stream)
+
+    def _bucketed(self, net) -> bool:
+        return bool(self.buckets and self.dp is not None and not self.sharded and not self.comm_off
+                    and len(self._bk[id(net)]) > 1)
+
+    def _reduce_range(self, net, opt, lo, hi, first, last):
         if self.fused:
-            self.optD.step_allreduce_fused(self.dp)
+            opt.step_allreduce_fused(self.dp, lo, hi, first, last)
         else:
-            self.dp.all_reduce_sum_(self.D.G)
+            self.dp.all_reduce_sum_(net.G if (lo == 0 and hi == net.G.numel()) else net.G[lo:hi])
+
+    def _bucket_hook(self, net, opt):
+        """`after_op` callback of `Network.backward`: launches every bucket but the last-finishing one on the
+        communication stream the moment its gradients are complete."""
+        if not self._bucketed(net):
+            return None
+        bk = self._bk[id(net)]
+        ready = {b[2]: k for k, b in enumerate(bk[:-1])}
+
+        def hook(i):
+            k = ready.get(i)
+            if k is not None:
+                lo, hi, _ = bk[k]
+                self._on_comm(lambda: self._reduce_range(net, opt, lo, hi, k == 0, False))
+        return hook
+
+    def _reduce_rest(self, net, opt):
+        """What the hooks have not sent yet: the last bucket, or the whole buffer (one collective / one kernel)."""
+        if self.dp is None or self.sharded or self.comm_off:
+            return
+        if self._bucketed(net):
+            lo, hi, _ = self._bk[id(net)][-1]
+            self._reduce_range(net, opt, lo, hi, False, True)
+        else:
+            self._reduce_range(net, opt, 0, net.G.numel(), True, True)
+
+    def reduce_D(self):
+        """Average D's gradients over the ranks (and, fused, update D)."""
+        self._reduce_rest(self.D, self.optD)
 
     def reduce_G(self):
-        if self.dp is None or self.sharded:
-            return
-        if self.fused:
-            self.optG.step_allreduce_fused(self.dp)
-        else:
-            self.dp.all_reduce_sum_(self.G.G)
+        self._reduce_rest(self.G, self.optG)
 
     @property
     def _gscale(self):
         return 1.0 if self.dp is None else self.dp.grad_scale
 
     def train_step(self, real, prepared: bool = False):
-        """One iteration.  Data parallel on device: D's gradient exchange runs on a communication stream while
-        the generator's forward of the G phase (which does not depend on D) runs on the main one -- captured
-        into a hipGraph the fork / join become two branches."""
+        """One iteration.  Data parallel on device: gradient buckets are reduced on a communication stream under
+        the rest of the backward pass that produces them; D's last bucket additionally hides behind the
+        generator's forward of the G phase when that is a pass of its own (`merged` off) -- captured into a
+        hipGraph the forks / joins become graph branches."""
         if not prepared:
             real = self.D.prepare_input(real)
         B = real.shape[0]
         self.phase_a(real)
-        cs = self._comm_stream if not self.sharded else None
-        if cs is not None:
-            main = torch.cuda.current_stream()
-            cs.wait_stream(main)
-            with torch.cuda.stream(cs):
-                self.reduce_D()
-            self.phase_b1(B)
-            main.wait_stream(cs)
-            self.phase_b2(B)
+        self._on_comm(self.reduce_D)
+        self.phase_b1(B)                # a no-op after the merged generator pass
+        self._join_comm()
+        self.phase_b2(B)
+        if self._bucketed(self.G):      # G's first bucket is already on the communication stream: stay in order
+            self._on_comm(self.reduce_G)
+            self._join_comm()
         else:
-            self.reduce_D()
-            self.phase_b(B)
-        self.reduce_G()
+            self.reduce_G()
         self.phase_c()
         return self.d_loss, self.g_loss
 
@@ -482,6 +535,8 @@ class GraphedGANStep:
             self.graphs = [g]
         else:
             # A | all-reduce(D grads) on the comm stream || B1 (G forward) | B2 | all-reduce(G grads) | C
+            # (segments cannot contain an eager collective, so the bucket hooks are off in this mode)
+            t.buckets = False
             self.comm_stream = torch.cuda.Stream()
             fns = [lambda: t.phase_a(self.real), lambda: t.phase_b1(self.B), lambda: t.phase_b2(self.B), t.phase_c]
             if t.merged:            # the G-phase forward is part of phase A's merged generator pass

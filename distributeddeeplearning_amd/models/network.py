@@ -952,14 +952,17 @@ class Network:
         return None
 
     def backward(self, dy, need_input_grad: bool = False, need_dw: bool = True,
-                 start: Optional[int] = None, input_mul=None, dy_premultiplied: bool = False):
+                 start: Optional[int] = None, input_mul=None, dy_premultiplied: bool = False, after_op=None):
         """Back-propagate from op index `start` (exclusive upper bound, default: all ops).
 
         Activation backward fusion: when the op below a conv/dense layer (through reshapes) carries an
         unfused activation, its act'(y) is applied in the epilogue of this layer's input-gradient kernel
         instead of a separate elementwise pass.  `input_mul` does the same for the network INPUT gradient
         (y of the producer network's last layer: G -> D chains), `dy_premultiplied` tells this network that
-        its incoming dY already carries the last layer's act'(y)."""
+        its incoming dY already carries the last layer's act'(y).
+
+        `after_op(i)` is called once op i's backward kernels have been issued (weight-gradient branch joined): every
+        gradient of ops i.. is then complete in stream order -- the hook of bucketed gradient all-reduces."""
         start = len(self.ops) if start is None else (start if start >= 0 else len(self.ops) + start)
         if need_input_grad and getattr(self, "no_input_grad", False):
             raise ValueError("this network was declared input-gradient-free (set_no_input_grad)")
@@ -992,8 +995,47 @@ class Network:
                 dy = op.bwd(dy, need_dx=need_dx, need_dw=need_dw)
             if self.emulate_bf16 and not self.on_gpu and dy is not None and not isinstance(op, ViewOp):
                 dy = dy.bfloat16().float()
+            if after_op is not None and op.has_params:
+                _BR.join()
+                after_op(i)
         _BR.join()
         return dy
+
+    def grad_buckets(self, max_buckets: int = 2, min_tail_frac: float = 0.5):
+        """Split of the flat gradient buffer for all-reduces that overlap the backward pass: [(lo, hi, ready_op)] in
+        the order the buckets complete during `backward` -- bucket k may be reduced as soon as `after_op(ready_op)`
+        fires.  The flat buffer is laid out in forward order and the backward pass walks it from the end, so a bucket
+        is a contiguous TAIL [offset(op s), previous boundary): everything from conv-like op s upwards, BatchNorm
+        parameters behind it included.  With two buckets the boundary is the latest layer (earliest ready) whose tail
+        holds at least `min_tail_frac` of the parameters; if no layer above the first one does, the boundary sits
+        right above the first parameter layer (everything but the last-finished gradient overlaps)."""
+        pops = [i for i, op in enumerate(self.ops) if isinstance(op, ConvOp)]
+        n = self.n_train
+        if max_buckets < 2 or len(pops) < 2:
+            return [(0, n, pops[0] if pops else 0)]
+        offs = {}
+        for i in pops:
+            op = self.ops[i]
+            kname = "depthwise_kernel" if op.kind == "depthwise_conv2d" else "kernel"
+            offs[i] = self._pmap[(op.name, kname)].offset
+        cuts = []
+        hi = n
+        cand = pops[1:]
+        while len(cuts) < max_buckets - 1 and cand:
+            want = min_tail_frac * hi
+            good = [i for i in cand if hi - offs[i] >= want]
+            s_ = max(good) if good else min(cand)
+            if hi - offs[s_] <= 0:
+                break
+            cuts.append(s_)
+            hi = offs[s_]
+            cand = [i for i in cand if i < s_]
+        out, hi = [], n
+        for s_ in cuts:
+            out.append((offs[s_], hi, s_))
+            hi = offs[s_]
+        out.append((0, hi, pops[0]))
+        return out
 
     def release(self):
         for op in self.ops:

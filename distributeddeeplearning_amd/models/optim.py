@@ -74,15 +74,18 @@ class FlatOptimizer:
         else:
             raise ValueError(c.kind)
 
-    def step_allreduce_fused(self, dp):
+    def step_allreduce_fused(self, dp, lo: int = 0, hi: Optional[int] = None, first: bool = True, last: bool = True):
         """Data-parallel step with the gradient all-reduce, the 1/world factor and this update in ONE kernel
         (parallel/p2p.py: xGMI direct all-reduce with the optimizer in its epilogue).  Replaces
         `dp.all_reduce_sum_(net.G); opt.step(dp.grad_scale)` and produces the same bits as that pair when the
-        communicator sums in rank order."""
-        self.t += 1
-        F.hip_backend().step_inc(self.step_dev)
-        dp.all_reduce_update_(self)
-        self.net.refresh_working_copies(cast=False)
+        communicator sums in rank order.  With gradient buckets the call is made once per range [lo, hi): the
+        `first` one advances the step counter, the `last` one redoes the weight relayouts."""
+        if first:
+            self.t += 1
+            F.hip_backend().step_inc(self.step_dev)
+        dp.all_reduce_update_(self, lo, hi)
+        if last:
+            self.net.refresh_working_copies(cast=False)
 
     def steps_taken(self) -> int:
         """Optimizer steps actually executed.  On device the truth is the device-side counter: hipGraph

@@ -76,13 +76,25 @@ class P2PAllReduce:
         hb = lib.ddl_p2p_handle_bytes()
         mine = C.create_string_buffer(hb)
         self._h = lib.ddl_p2p_create(self.world, self.rank, idx, self.capacity, mine)
-        if not self._h:
-            raise P2PError(_err())
+        # Every rank takes part in every collective of this constructor whatever happened locally, and the ranks
+        # agree on each stage's outcome before the next one: a rank that cannot allocate or map raises TOGETHER with
+        # its peers instead of leaving them inside all_gather_object / barrier (mismatched collectives hang).
+        err = None if self._h else _err()
         handles = [None] * self.world
-        dist.all_gather_object(handles, (self.rank, mine.raw), group=base.group)
-        blob = b"".join(h for _, h in sorted(handles))
-        if lib.ddl_p2p_connect(self._h, C.create_string_buffer(blob, len(blob))) != 0:
-            raise P2PError(_err())
+        dist.all_gather_object(handles, (self.rank, err, mine.raw if self._h else b""), group=base.group)
+        bad = [(r, e) for r, e, _ in handles if e is not None]
+        if bad:
+            self.close()
+            raise P2PError(f"xGMI buffer allocation failed on rank(s) {[r for r, _ in bad]}: {bad[0][1]}")
+        blob = b"".join(h for _, _, h in sorted(handles))
+        rc = lib.ddl_p2p_connect(self._h, C.create_string_buffer(blob, len(blob)))
+        err = None if rc == 0 else _err()
+        verdicts = [None] * self.world
+        dist.all_gather_object(verdicts, (self.rank, err), group=base.group)
+        bad = [(r, e) for r, e in verdicts if e is not None]
+        if bad:
+            self.close()
+            raise P2PError(f"mapping the peers' buffers failed on rank(s) {[r for r, _ in bad]}: {bad[0][1]}")
         mb = int(os.environ.get("DDL_P2P_BLOCKS", "0")) if max_blocks is None else max_blocks
         lib.ddl_p2p_configure(self._h, mb or 0, -1 if oneshot_bytes is None else oneshot_bytes, timeout_s or 0.0)
         base.barrier()              # every peer has mapped every buffer before the first kernel touches one
@@ -114,15 +126,18 @@ class P2PAllReduce:
             return self.all_reduce_sum_(t, scale=1.0 / self.world)
         return self.base.all_reduce_mean_(t)
 
-    def all_reduce_update_(self, opt):
-        """scale * sum(G) -> fused optimizer update of opt.net's flat buffers (P, m, v, bf16 copy) in one kernel.
-        The caller has already advanced the device step counter (FlatOptimizer.step_allreduce_fused)."""
+    def all_reduce_update_(self, opt, lo: int = 0, hi: Optional[int] = None):
+        """scale * sum(G[lo:hi]) -> fused optimizer update of that range of opt.net's flat buffers (P, m, v, bf16
+        copy) in one kernel.  The caller has already advanced the device step counter
+        (FlatOptimizer.step_allreduce_fused); `lo` / `hi` are multiples of 4 elements (gradient buckets)."""
         net, c = opt.net, opt.cfg
-        if not self._eligible(net.G):
-            raise P2PError("gradient buffer is not eligible for the fused xGMI all-reduce (size / alignment)")
-        p = lambda t: None if t is None else t.data_ptr()
-        rc = _load().ddl_p2p_all_reduce_update(self._h, net.G.data_ptr(), net.G.numel(), self.grad_scale,
-                                               net.P.data_ptr(), p(opt.m), p(opt.v), net.Pc.data_ptr(),
+        hi = net.G.numel() if hi is None else hi
+        g = net.G[lo:hi]
+        if lo % 4 or not self._eligible(g):
+            raise P2PError("gradient range is not eligible for the fused xGMI all-reduce (size / alignment)")
+        p = lambda t, b: None if t is None else t.data_ptr() + lo * b     # noqa: E731
+        rc = _load().ddl_p2p_all_reduce_update(self._h, g.data_ptr(), g.numel(), self.grad_scale,
+                                               p(net.P, 4), p(opt.m, 4), p(opt.v, 4), p(net.Pc, 2),
                                                opt.step_dev.data_ptr(), _OPT_KIND[c.kind], c.lr, c.beta1, c.beta2,
                                                c.eps, c.rho, torch.cuda.current_stream().cuda_stream)
         if rc != 0:
@@ -154,6 +169,15 @@ class P2PAllReduce:
     def healthy(self) -> bool:
         """False once any wait inside the kernel timed out (synchronises the device)."""
         return _load().ddl_p2p_status(self._h) == 0
+
+    def healthy_everywhere(self) -> bool:
+        """`healthy()` agreed across ranks (a collective): after a time-out the kernel skips every reduction and
+        update on the rank that saw it, so one unhealthy rank invalidates the whole job's results."""
+        ok = self.healthy()
+        on_dev = dist.get_backend(self.group) == "nccl"
+        f = torch.tensor([0.0 if ok else 1.0], device=self.device if on_dev else "cpu")
+        dist.all_reduce(f, op=dist.ReduceOp.MAX, group=self.group)
+        return float(f.item()) == 0.0
 
     def validate(self, numel: Optional[int] = None) -> bool:
         """Kernel vs base communicator on rank-dependent data, both size classes; verdict agreed across ranks."""

@@ -141,6 +141,46 @@ def gan_dp(rank, world, port, out, sharded=False):
     dist.destroy_process_group()
 
 
+def gan_dp_buckets(rank, world, port, out, rank_order):
+    """Bucketed gradient all-reduce (tail bucket sent from inside the backward pass) vs one collective per network:
+    same parameters; every collective the bucketed trainer issued is recorded to prove the hook really fired.
+    `rank_order`: sum by all-gather + addition in rank order (what the xGMI kernel does) instead of gloo's ring."""
+    dp = _init(rank, world, port)
+    from distributeddeeplearning_amd.models.dcgan import GANConfig, GANTrainer
+    if rank_order:
+        def ordered(t, *a, **k):
+            parts = [torch.empty_like(t) for _ in range(world)]
+            dist.all_gather(parts, t.contiguous())
+            acc = parts[0].clone()
+            for p in parts[1:]:
+                acc += p
+            t.copy_(acc)
+        dp.all_reduce_sum_ = ordered
+    calls = []
+    orig = dp.all_reduce_sum_
+
+    def spy(t, *a, **k):
+        calls.append(int(t.numel()))
+        return orig(t, *a, **k)
+    real = torch.rand(4, 28, 28, 1, generator=torch.Generator().manual_seed(rank))
+    a = GANTrainer(GANConfig(batch=4, seed=3), "cpu", dp, rank)
+    assert a.buckets and len(a._bk[id(a.D)]) == 2 and len(a._bk[id(a.G)]) == 2
+    b = GANTrainer(GANConfig(batch=4, seed=3), "cpu", dp, rank)
+    b.buckets = False
+    for _ in range(3):
+        dp.all_reduce_sum_ = spy
+        a.train_step(real)
+        dp.all_reduce_sum_ = orig
+        b.train_step(real)
+    nD, nG = a.D.G.numel(), a.G.G.numel()
+    sizes = [hi - lo for lo, hi, _ in a._bk[id(a.D)]] + [hi - lo for lo, hi, _ in a._bk[id(a.G)]]
+    ok_calls = calls == sizes * 3 and sum(sizes[:2]) == nD and sum(sizes[2:]) == nG
+    d = max(float((a.G.P - b.G.P).abs().max()), float((a.D.P - b.D.P).abs().max()))
+    exact = torch.equal(a.G.P, b.G.P) and torch.equal(a.D.P, b.D.P)
+    np.save(f"{out}/bk{rank}.npy", np.concatenate([[float(ok_calls), d, float(exact)], a.G.P.numpy(), a.D.P.numpy()]))
+    dist.destroy_process_group()
+
+
 def sharded_adam(rank, world, port, out):
     """ZeRO-1 Adam == replicated Adam on all-reduced gradients, step for step."""
     dp = _init(rank, world, port)

@@ -135,9 +135,19 @@ def gan(rank, world, port, out):
     base = HostBroadcast()
     dp = P2PAllReduce(base, dev, 1 << 21, max_blocks=8, timeout_s=30.0)
     real = torch.rand(64, 28, 28, 1, generator=torch.Generator().manual_seed(rank))
+    # Kernel plans first: every rank tunes on its own clock and may pick different (equally correct) plans, and
+    # GraphedGANStep makes all ranks adopt rank 0's table between its warm-up steps and the capture -- a bit-for-bit
+    # comparison of two trainers is only meaningful once the plans can no longer change under them.
+    from distributeddeeplearning_amd.ops import functional as F
+    w = GANTrainer(GANConfig(batch=64, seed=5), dev, dp, rank)
+    rp = w.D.prepare_input(real)
+    w.train_step(rp, prepared=True)
+    torch.cuda.synchronize()
+    F.hip_backend().sync_choices(base)
+    del w
+
     a = GANTrainer(GANConfig(batch=64, seed=5), dev, dp, rank)
-    assert a.fused
-    rp = a.D.prepare_input(real)
+    assert a.fused and a._bucketed(a.D) and a._bucketed(a.G)     # fused update per gradient bucket, under the backward
     step = GraphedGANStep(a, rp, warmup=2)
     assert step.full
     for _ in range(4):
@@ -146,11 +156,17 @@ def gan(rank, world, port, out):
 
     dp.supports_fused_update = False                 # same communicator, all-reduce then the optimizer kernel
     b = GANTrainer(GANConfig(batch=64, seed=5), dev, dp, rank)
-    assert not b.fused
+    assert not b.fused and b._bucketed(b.D)
+    c = GANTrainer(GANConfig(batch=64, seed=5), dev, dp, rank)
+    c.buckets = False                                # ... and one collective per network, after the whole backward
     for _ in range(6):
         b.train_step(rp, prepared=True)
+        c.train_step(rp, prepared=True)
     torch.cuda.synchronize()
-    same = torch.equal(a.G.P, b.G.P) and torch.equal(a.D.P, b.D.P) and torch.equal(a.optG.m, b.optG.m)
+    same = True
+    for o in (b, c):
+        same = same and torch.equal(a.G.P, o.G.P) and torch.equal(a.D.P, o.D.P) and torch.equal(a.optG.m, o.optG.m) \
+            and torch.equal(a.optD.v, o.optD.v) and torch.equal(a.G.S, o.G.S)
     parts = [torch.empty_like(a.G.P.cpu()) for _ in range(world)]
     dist.all_gather(parts, a.G.P.cpu())
     replicas = all(torch.equal(parts[0], p) for p in parts)

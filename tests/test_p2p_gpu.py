@@ -31,7 +31,11 @@ def test_p2p_allreduce_processes_sharing_one_gpu(tmp_path, world):
         assert got.tolist() == [1] * len(got), open(tmp_path / f"p2p{r}.txt").read()
 
 
-def test_p2p_fused_graphed_gan_step_equals_unfused_eager(tmp_path):
-    mp.spawn(W.gan, args=(2, _port(), str(tmp_path)), nprocs=2, join=True)
-    for r in range(2):
+@pytest.mark.parametrize("world", [2, 4])
+def test_p2p_fused_bucketed_graphed_gan_step_equals_unfused_flat_eager(tmp_path, world):
+    """Whole-step hipGraph with the fused all-reduce + update launched per gradient BUCKET from inside the backward
+    pass == bucketed all-reduce + optimizer kernel, eager == one collective per network after the backward, eager:
+    bit for bit (the kernel sums in rank order whatever the message length), replicas identical on every rank."""
+    mp.spawn(W.gan, args=(world, _port(), str(tmp_path)), nprocs=world, join=True)
+    for r in range(world):
         assert np.load(tmp_path / f"gan{r}.npy").tolist() == [1, 1, 1]
