@@ -134,7 +134,15 @@ def main(argv=None):
                 say("model accuracy : ", acc, flush=True)                   # DDL.py:171-172
             vote = float(ens.get_accuracy())
         say("ensemble accuracy : ", vote, flush=True)                       # DDL.py:174
-        log.log(event="result", member_test_accuracy=accs, ensemble_accuracy=vote, seconds=time.time() - t0)
+        # ranking order (descending validation accuracy on each member's own hold-out, DDL.py:144-147)
+        if hasattr(ens, "accuracy_with_models"):
+            val = [float(e[0]) for e in ens.accuracy_with_models]
+            numbers = [getattr(getattr(e[1], "_a", None), "model", None) and e[1]._a.model.number
+                       for e in ens.accuracy_with_models]
+        else:
+            val, numbers = [float(m["acc"]) for m in ens.members], [m["number"] for m in ens.members]
+        log.log(event="result", member_val_accuracy=val, member_numbers=numbers, member_test_accuracy=accs,
+                top_k=space.predict_model_size, ensemble_accuracy=vote, seconds=time.time() - t0)
         if a.save:
             ens.save_models()
         if not a.no_plot and hasattr(ens, "plot_models"):

@@ -17,9 +17,10 @@ Three execution back-ends share that logic:
                     accuracies (DDL_Ray.py:144-149);
   * mode="async"    fire-and-forget train + queued accuracy futures, resolved only when ranking or
                     voting needs them (DDL_Ray2.py:151-158, DDL_Ray3.py:185-237);
-plus `SpmdEnsemble` for `torchrun`: every rank owns the members `i % world == rank`, and the
-driver-side gathers become RCCL collectives -- all_gather of accuracies (M3/M5), all_reduce(sum)
-of the vote matrix (M4), broadcast of a parent's flat weights (M6).  Images never travel: each
+plus `SpmdEnsemble` for `torchrun`: the members of a generation are placed on the ranks longest-first by
+estimated cost (every rank computes the same assignment, `SpmdEnsemble._place`), and the driver-side
+gathers become RCCL collectives -- all_reduce of the accuracy slots (M3/M5; each slot written by its
+owner), all_reduce(sum) of the vote matrix (M4), broadcast of a parent's flat weights (M6).  Images never travel: each
 process keeps the dataset resident and receives split seeds.
 """
 from __future__ import annotations
@@ -62,6 +63,7 @@ class MemberActor:
         self.data = shared_data(device, space.channels, data_kw)
         sample = self.data.get_random_sample(space.data_train_size, seed=sample_seed)
         parent_state, inherited = parent if parent is not None else (None, None)
+        parent_state = _resolve(parent_state)       # local mode hands over an already-resolved future
         self.model = RandomModel(self.data, sample, space, compiled, device, number, seed,
                                  parent_state, inherited, verbose=verbose)
 
@@ -80,6 +82,10 @@ class MemberActor:
     def get_model(self):
         compiled, state = self.model.get_model()
         return compiled, state
+
+    def get_state(self):
+        """Weights only (the driver already holds the member's spec): what a transfer child inherits (M6)."""
+        return self.model.get_model()[1]
 
     def save(self, directory: Optional[str] = None) -> str:
         return str(self.model.save(directory))
@@ -196,9 +202,12 @@ class EnsembleModel:
         self.sort_models()
         members = []
         for acc, h, c in self.accuracy_with_models[:n]:
-            parent_compiled, parent_state = _resolve(h.call("get_model"))      # M6
-            child, inherited = search.make_transfer_model(self.space, self.rng, parent_compiled.spec, 10)
-            members.append((self._spawn(child, parent=(parent_state, inherited)), child))
+            # M6: the parent's weights travel worker -> driver -> child's worker as a FUTURE: the runtime parks the
+            # child's creation until they exist (parallel/runtime.py outbox), the driver goes on building the
+            # generation from the spec it already holds (DDL_Ray3.py:198 blocks in ray.get here)
+            state = h.call("get_state")
+            child, inherited = search.make_transfer_model(self.space, self.rng, c.spec, 10)
+            members.append((self._spawn(child, parent=(state, inherited)), child))
         self._train_and_score(members)
 
     # ---- ranking / voting

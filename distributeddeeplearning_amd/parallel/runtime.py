@@ -10,7 +10,8 @@
 Semantics kept from the reference's use of Ray: an actor lives in one worker process and executes
 its calls strictly in submission order (the reference relies on `train.remote()` finishing before
 the queued `get_accuracy.remote()`, DDL_Ray2.py:151-154); calls on different workers run
-concurrently; `get` blocks; futures passed as arguments are resolved first.  What is different:
+concurrently; `get` blocks; futures passed as arguments are resolved by the runtime, not by the caller (the
+submitting thread never waits: the call is parked in its worker's outbox until its inputs exist).  What is different:
 workers are pinned one-per-GPU, big tensors never travel (each worker keeps the dataset resident
 and receives seeds/indices), transport is a native framed-socket endpoint
 (csrc/host/actor_transport.cpp), and a dying worker fails its futures with `WorkerDiedError`
@@ -51,13 +52,14 @@ class GetTimeoutError(TimeoutError):
 
 
 class ObjectRef:
-    __slots__ = ("id", "_rt", "_ev", "_ok", "_val", "worker")
+    __slots__ = ("id", "_rt", "_ev", "_ok", "_val", "worker", "_waiters")
 
     def __init__(self, rt, rid, worker):
         self.id, self._rt, self.worker = rid, rt, worker
         self._ev = threading.Event()
         self._ok = None
         self._val = None
+        self._waiters = set()       # workers whose outbox head is parked on this result
 
     def done(self) -> bool:
         return self._ev.is_set()
@@ -65,6 +67,8 @@ class ObjectRef:
     def _set(self, ok, val):
         self._ok, self._val = ok, val
         self._ev.set()
+        if self._waiters:           # calls parked on this result can go now (dispatcher thread, never this one)
+            self._rt._kick(self._waiters)
 
     def get(self, timeout: Optional[float] = None):
         if not self._ev.wait(timeout):
@@ -144,6 +148,13 @@ class Runtime:
         self._procs: List[subprocess.Popen] = []
         self._hello = threading.Condition()
         self._closing = False
+        # per-worker outbox: calls are SENT in submission order (an actor's mailbox is FIFO, DDL_Ray2.py:151-154), and
+        # a call whose arguments contain unresolved futures parks at the head of its worker's outbox -- without
+        # blocking the submitting thread (Ray resolves such arguments in its scheduler, not in the driver)
+        self._outbox: Dict[int, List[Tuple[ObjectRef, int, Any]]] = {i: [] for i in range(len(devices))}
+        self._out_mu = [threading.Lock() for _ in devices]
+        self._kicks: List[int] = []
+        self._kick_cv = threading.Condition()
         root = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
         for i, dev in enumerate(self.devices):
             e = dict(os.environ)
@@ -159,6 +170,8 @@ class Runtime:
                 env=e))              # workers share the driver's cwd: relative artifact paths agree
         self._thread = threading.Thread(target=self._pump, name="ddl-runtime-events", daemon=True)
         self._thread.start()
+        self._disp = threading.Thread(target=self._dispatch, name="ddl-runtime-dispatch", daemon=True)
+        self._disp.start()
         deadline = time.time() + connect_timeout
         with self._hello:
             while len(self._conn_of) < len(self.devices):
@@ -199,6 +212,7 @@ class Runtime:
                         self._refs.pop(r.id, None)
                 for r in lost:
                     r._set(False, WorkerDiedError(f"worker {idx} ({self.devices[idx]}) died"))
+                self._kick([idx])           # parked calls of the dead worker fail too
 
     # ------------------------------------------------------------------ submission
     def _pick_worker(self, num_gpus=0) -> int:
@@ -229,6 +243,7 @@ class Runtime:
         return {k: tuple(v) for k, v in out.items()}
 
     def _resolve(self, obj):
+        """Replace every (finished) future in `obj` by its value; raises the dependency's error if it failed."""
         if isinstance(obj, ObjectRef):
             return obj.get()
         if isinstance(obj, (list, tuple)):
@@ -236,6 +251,68 @@ class Runtime:
         if isinstance(obj, dict):
             return {k: self._resolve(v) for k, v in obj.items()}
         return obj
+
+    def _pending_deps(self, obj, out):
+        if isinstance(obj, ObjectRef):
+            if not obj.done():
+                out.append(obj)
+        elif isinstance(obj, (list, tuple)):
+            for o in obj:
+                self._pending_deps(o, out)
+        elif isinstance(obj, dict):
+            for o in obj.values():
+                self._pending_deps(o, out)
+        return out
+
+    def _kick(self, workers):
+        with self._kick_cv:
+            self._kicks.extend(workers)
+            self._kick_cv.notify()
+
+    def _dispatch(self):
+        """Re-drains outboxes whose parked head call became sendable (woken by ObjectRef._set)."""
+        while not self._closing:
+            with self._kick_cv:
+                while not self._kicks and not self._closing:
+                    self._kick_cv.wait(0.25)
+                todo, self._kicks = set(self._kicks), []
+            for w in todo:
+                self._drain(w)
+
+    def _drain(self, worker: int):
+        """Send this worker's queued calls, in order, up to the first one that still waits for an argument."""
+        with self._out_mu[worker]:
+            box = self._outbox[worker]
+            while box:
+                ref, tag, body = box[0]
+                deps = self._pending_deps(body, [])
+                if deps:
+                    for d in deps:
+                        d._waiters.add(worker)
+                    if all(d.done() for d in deps):     # finished between the scan and the registration
+                        continue
+                    return
+                box.pop(0)
+                if ref.done():              # already failed (its worker died while it was parked)
+                    continue
+                if worker in self._dead:
+                    with self._lock:
+                        self._refs.pop(ref.id, None)
+                    ref._set(False, WorkerDiedError(f"worker {worker} is dead"))
+                    continue
+                try:
+                    payload = _cp.dumps((ref.id, self._resolve(body)))
+                except Exception as e:      # noqa: BLE001 - a failed dependency fails the call that needed it
+                    with self._lock:
+                        self._refs.pop(ref.id, None)
+                    ref._set(False, e)
+                    continue
+                try:
+                    self._ep.send(self._conn_of[worker], tag, payload)
+                except T.TransportError as e:
+                    with self._lock:
+                        self._refs.pop(ref.id, None)
+                    ref._set(False, WorkerDiedError(f"worker {worker}: {e}"))
 
     def _submit(self, worker: int, tag: int, body) -> ObjectRef:
         rid = next(self._ids)
@@ -245,12 +322,9 @@ class Runtime:
             return ref
         with self._lock:
             self._refs[rid] = ref
-        try:
-            self._ep.send(self._conn_of[worker], tag, _cp.dumps((rid, self._resolve(body))))
-        except T.TransportError as e:
-            with self._lock:
-                self._refs.pop(rid, None)
-            ref._set(False, WorkerDiedError(f"worker {worker}: {e}"))
+        with self._out_mu[worker]:
+            self._outbox[worker].append((ref, tag, body))
+        self._drain(worker)
         return ref
 
     def _create_actor(self, cls, args, kwargs, num_gpus) -> ActorHandle:
@@ -310,7 +384,10 @@ class Runtime:
             except subprocess.TimeoutExpired:
                 p.kill()          # exact child PID, never a pattern
         self._closing = True
+        with self._kick_cv:
+            self._kick_cv.notify_all()
         self._thread.join(timeout=2)
+        self._disp.join(timeout=2)
         self._ep.close()
         try:
             os.rmdir(self._dir)

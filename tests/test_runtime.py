@@ -81,6 +81,31 @@ def test_actor_calls_keep_submission_order_and_state(rt):
     assert pending and not ready
 
 
+def test_future_arguments_do_not_block_the_submitting_thread(rt):
+    """A future passed as an argument is resolved by the runtime (Ray does it in its scheduler): the driver keeps
+    submitting while the producer still runs -- async mode builds transfer children from parents that are still
+    training (/root/reference/DDL_Ray3.py:195-205).  The consumer's mailbox stays FIFO behind the parked call, and a
+    failed producer fails exactly the calls that needed it."""
+    C = rt.remote(Counter, num_gpus=1)
+    a, b = C.remote(0), C.remote(1000)
+    rt.get([a.state.remote(), b.state.remote()])
+    t0 = time.time()
+    slow = a.add.remote(5, 0.6)                       # producer: 0.6 s on a's worker
+    parked = b.add.remote(slow)                       # needs the producer's result
+    behind = b.add.remote(1)                          # queued behind the parked call in b's mailbox
+    other = a.add.remote(1)                           # a's own mailbox is not held up by b's parked call
+    assert time.time() - t0 < 0.3                     # nothing above waited for the producer
+    assert not parked.done() and not behind.done()
+    assert rt.get(parked) == 1005 and rt.get(behind) == 1006 and rt.get(other) == 6
+    assert rt.get(b.state.remote())[1] == [5, 1]      # order kept: the parked call ran first
+    bad = a.boom.remote()
+    needs_bad = b.add.remote(bad)
+    after = b.add.remote(2)
+    with pytest.raises(runtime.RemoteError):
+        rt.get(needs_bad)
+    assert rt.get(after) == 1008                      # the mailbox moved on
+
+
 def test_remote_exception_and_timeout(rt):
     a = rt.remote(Counter).remote(0)
     with pytest.raises(runtime.RemoteError, match="ValueError: nope"):
