@@ -812,6 +812,7 @@ DDL_API void ddl_bn_bwd(const void* dy, const void* x, const void* y, void* dx, 
                                                                       dbeta, c1, c2, mean, invstd, gamma, nullptr,
                                                                       0, groups);
     }
+    if (!dx) return;            // finalize only: the caller applies the coefficients itself (ddl_dw_dgrad_bn)
     long n8 = rows * (C / 8);
     if (cs_ok(C / 8)) {
         int gx = cs_grid(rows * groups, C / 8) / groups;

@@ -16,9 +16,11 @@
 // Tiling (wave64, 256 threads = 4 waves): block tile BM pixels x BN channels, K step 64.
 // MFMA operands are swapped -- weights are the A operand (rows = channel n), pixels the B operand
 // (cols) -- so a lane's 4 accumulator registers are 4 consecutive channels of one pixel and the
-// epilogue stores 8-byte bf16x4 vectors.  LDS rows are 128 B of data on a 160 B pitch: with that
-// pitch the four 16-lane groups of a ds_read_b128 fragment read hit 16 distinct 16-B slots
-// (conflict-free).  Global->LDS staging goes through a ring of three register stages: the gathers
+// epilogue stores 8-byte bf16x4 vectors.  LDS rows are 128 B of data, unpadded, with the 16-byte slot XOR-ed by the
+// row's low three bits (slot' = chunk ^ (row & 7)): the four 16-lane groups of a ds_read_b128 fragment read hit 16
+// distinct 16-B slots of the 256-B bank row and a ds_write_b128 group of 8 lanes writes one whole row
+// (conflict-free both ways).  The earlier 160-B padded pitch was conflict-free too but made a 128 x 128 tile 80 KB of
+// LDS -- ONE block per CU, four waves, every latency exposed; at 64 KB two blocks co-reside.  Global->LDS staging goes through a ring of three register stages: the gathers
 // of K-step s+3 are issued before the MFMAs of step s, so three steps of loads are in flight per
 // wave (the gather latency, not the math, bounds these small-N problems); one barrier per step.
 #include "common.h"
@@ -42,7 +44,7 @@ struct ConvArgs {
 };
 
 #define BK 64                 // K elements per LDS stage
-#define PITCH 160             // bytes per LDS row (128 B of bf16 K-data + 32 B pad; 160/16 = 10 == 2 mod 4)
+#define PITCH 128             // bytes per LDS row (64 bf16 K-elements, XOR-swizzled 16-B slots)
 #define DEPTH 3               // global loads are issued DEPTH K-steps ahead of their use
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
@@ -73,6 +75,7 @@ __global__ __launch_bounds__(256) void igemm_conv_kernel(const ConvArgs a) {
 
     // ---- per-thread staging assignment: kgroup q (8 k-elements of the 64-wide stage), rows r0 + 32*r
     const int q = tid & 7, r0 = tid >> 3;
+    const int qsw = (q ^ (r0 & 7)) * 16;      // swizzled store slot (rows r0 + 32 r share r0's low bits)
     const int HW = cd.Hc * cd.Wc;
     const int Cs = a.Cs;
     int abase[RA], aih[RA], aiw[RA];          // element offsets fit 31 bits (checked on the host)
@@ -135,10 +138,10 @@ __global__ __launch_bounds__(256) void igemm_conv_kernel(const ConvArgs a) {
     auto lstore = [&](int buf, const u32x4 (&rA)[RA], const u32x4 (&rW)[RW]) {
 #pragma unroll
         for (int r = 0; r < RA; ++r)
-            *(u32x4*)(sA + (buf * BM + r0 + 32 * r) * PITCH + q * 16) = rA[r];
+            *(u32x4*)(sA + (buf * BM + r0 + 32 * r) * PITCH + qsw) = rA[r];
 #pragma unroll
         for (int r = 0; r < RW; ++r)
-            if (BN % 32 == 0 || r0 + 32 * r < BN) *(u32x4*)(sW + (buf * BN + r0 + 32 * r) * PITCH + q * 16) = rW[r];
+            if (BN % 32 == 0 || r0 + 32 * r < BN) *(u32x4*)(sW + (buf * BN + r0 + 32 * r) * PITCH + qsw) = rW[r];
     };
 
     f32x4 acc[NT][4];
@@ -160,10 +163,10 @@ __global__ __launch_bounds__(256) void igemm_conv_kernel(const ConvArgs a) {
             bf16x8_t wf[NT], xf[4];
 #pragma unroll
             for (int i = 0; i < NT; ++i)
-                wf[i] = *(const bf16x8_t*)(sW + (cur * BN + wn * WN + 16 * i + fr) * PITCH + h * 64 + fq * 16);
+                wf[i] = *(const bf16x8_t*)(sW + (cur * BN + wn * WN + 16 * i + fr) * PITCH + (((h * 4 + fq) ^ (fr & 7)) * 16));
 #pragma unroll
             for (int j = 0; j < 4; ++j)
-                xf[j] = *(const bf16x8_t*)(sA + (cur * BM + wm * 64 + 16 * j + fr) * PITCH + h * 64 + fq * 16);
+                xf[j] = *(const bf16x8_t*)(sA + (cur * BM + wm * 64 + 16 * j + fr) * PITCH + (((h * 4 + fq) ^ (fr & 7)) * 16));
 #pragma unroll
             for (int i = 0; i < NT; ++i)
 #pragma unroll

@@ -10,9 +10,12 @@
 // logits: [B][Cs] bf16 (Cs = padded stride), N true classes (N <= 64).  One row per lane.
 // mode 0: probabilities only; mode 1: categorical cross-entropy; mode 2: mean squared error.
 // Row losses go to rowloss[B]; dlogits (bf16, [B][Cs], pad = 0) already carry the 1/B mean factor.
+// `index` (optional): row r's target is target[index[r]] -- the label gather of a minibatch drawn by index from the
+// HBM-resident dataset happens here, not in a gather pass of its own.
 __global__ void softmax_loss_kernel(const bf16_t* __restrict__ logits, const float* __restrict__ target,
-                                    float* __restrict__ probs, bf16_t* __restrict__ dlogits,
-                                    float* __restrict__ rowloss, int B, int Cs, int N, int mode, int want_grad) {
+                                    const long* __restrict__ index, float* __restrict__ probs,
+                                    bf16_t* __restrict__ dlogits, float* __restrict__ rowloss, int B, int Cs, int N,
+                                    int mode, int want_grad) {
     int r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= B) return;
     const bf16_t* l = logits + (size_t)r * Cs;
@@ -25,7 +28,7 @@ __global__ void softmax_loss_kernel(const bf16_t* __restrict__ logits, const flo
     for (int j = 0; j < N; ++j) v[j] *= inv;
     if (probs) for (int j = 0; j < N; ++j) probs[(size_t)r * N + j] = v[j];
     if (mode == 0) return;
-    const float* t = target + (size_t)r * N;
+    const float* t = target + (size_t)(index ? index[r] : r) * N;
     float loss = 0.f;
     if (mode == 1) {
         float tsum = 0.f;
@@ -72,11 +75,11 @@ __global__ void mean_kernel(const float* __restrict__ v, long n, float scale, fl
     if (threadIdx.x == 0) out[0] = (float)(red[0] * scale);
 }
 
-DDL_API void ddl_softmax_loss(const void* logits, const float* target, float* probs, void* dlogits,
-                              float* rowloss, float* loss_out, int B, int Cs, int N, int mode, int want_grad,
-                              hipStream_t s) {
-    softmax_loss_kernel<<<(B + 127) / 128, 128, 0, s>>>((const bf16_t*)logits, target, probs, (bf16_t*)dlogits,
-                                                        rowloss, B, Cs, N, mode, want_grad);
+DDL_API void ddl_softmax_loss(const void* logits, const float* target, const long* index, float* probs,
+                              void* dlogits, float* rowloss, float* loss_out, int B, int Cs, int N, int mode,
+                              int want_grad, hipStream_t s) {
+    softmax_loss_kernel<<<(B + 127) / 128, 128, 0, s>>>((const bf16_t*)logits, target, index, probs,
+                                                        (bf16_t*)dlogits, rowloss, B, Cs, N, mode, want_grad);
     if (mode != 0) mean_kernel<<<1, LB, 0, s>>>(rowloss, B, 1.0 / (double)B, loss_out);
 }
 
@@ -365,7 +368,7 @@ DDL_API int ddl_dense1_bce(const void* x, const void* w, const float* bias, floa
                                                 fb > 1 ? loss_out : nullptr);
         if (fb > 1) return 0;
     }
-    mean_kernel<<<1, LB, 0, s>>>(rowloss, M, 1.0 / (double)M, loss_out);
+    if (loss_out) mean_kernel<<<1, LB, 0, s>>>(rowloss, M, 1.0 / (double)M, loss_out);   // null: the caller defers it
     return 0;
 }
 

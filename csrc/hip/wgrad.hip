@@ -710,6 +710,275 @@ __global__ __launch_bounds__(256) void dw_dgrad_fast_kernel(const bf16_t* __rest
     }
 }
 
+// ---- depthwise input gradient fused with the backward of the BatchNorm IN FRONT of the layer -----------------
+// The classifier replicas (DDL_Normal4.random_layer) follow every conv-like layer by a BatchNorm, and a BatchNorm in
+// front of a depthwise layer is applied on load, so in the backward pass the depthwise input gradient g is exactly
+// that BatchNorm's dY.  Unfused that is three passes over the LARGE tensor (57 x 57 x 128 x batch in model0): write g,
+// read (g, x) for the column sums, read (g, x) again and write dx.  g is cheap to recompute from the small dY
+// (2.25 live taps per pixel for a 3x3 stride-2 layer), so it is never stored:
+//   REDUCE pass: g from dY on the fly, x loaded -> the BatchNorm's column sums (colreduce MODE 1 / MODE 3 semantics,
+//                partials part[NS][C][blocks], finalized by the ordinary bn_bwd finalize kernel);
+//   APPLY  pass: g recomputed, dx = prev_act'(x) * (k0 * g + k1 * x + k2)  (bn_bwd_apply_cs semantics) stored.
+// g is rounded to bf16 before use, as the materialised tensor was.  Traffic: 2 reads of x + 1 write of dx instead of
+// 1 write of g + 2 reads of g + 2 reads of x + 1 write of dx.
+struct DwBnArgs {
+    const bf16_t* x;               // the BatchNorm's input (same shape as dx)
+    const float *mean, *invstd, *gamma, *c1, *c2;
+    float* part;                   // [NS][C][gridDim.x * gridDim.y]
+    int prev_act; float prev_alpha;
+};
+
+template <int K, int NS, int P>
+__global__ __launch_bounds__(256) void dw_dgrad_bn_reduce_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ w,
+                                                                 const DwArgs a, const DwBnArgs n) {
+    __shared__ float red[4 * 64 * NS * 8];
+    const int cg = a.C / 8;                    // a power of two <= 64 (host-checked): a thread's channel group is fixed
+    const int ph = blockIdx.y / a.sw, pw = blockIdx.y - ph * a.sw;
+    const int Hc = (a.H - ph + a.sh - 1) / a.sh, Wc = (a.W - pw + a.sw - 1) / a.sw;
+    float s[NS][8];
+#pragma unroll
+    for (int k = 0; k < NS; ++k)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) s[k][j] = 0.f;
+    const int gch = threadIdx.x & (cg - 1);
+    if (Hc > 0 && Wc > 0) {
+        int oh0[K], ow0[K];
+        bool lh[K], lw[K];
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const int th0 = ph + a.pt - k * a.dh, tw0 = pw + a.pl - k * a.dw;
+            const int qh = th0 >= 0 ? th0 / a.sh : -((-th0 + a.sh - 1) / a.sh);
+            const int qw = tw0 >= 0 ? tw0 / a.sw : -((-tw0 + a.sw - 1) / a.sw);
+            lh[k] = qh * a.sh == th0;
+            lw[k] = qw * a.sw == tw0;
+            oh0[k] = qh;
+            ow0[k] = qw;
+        }
+        float mu[8], is[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { mu[j] = n.mean[gch * 8 + j]; is[j] = n.invstd[gch * 8 + j]; }
+        const FastDiv dWc = a.dsw_wc[pw], dHc = a.dsh_hc[ph];
+        const unsigned total = (unsigned)a.B * Hc * Wc * cg;
+        // x is the HBM stream of this pass (dY is small and cache-resident): the load of the NEXT pixel's x is issued
+        // before this pixel's taps are gathered, unconditionally (clamped index), so the compiler can count it
+        auto x_at = [&](unsigned i) {
+            const unsigned p = fdivu(i, a.dcg);
+            const unsigned q = fdivu(p, dWc);
+            const int jc = (int)(p - q * Wc);
+            const unsigned b = fdivu(q, dHc);
+            const int ic = (int)(q - b * Hc);
+            return *(const uint4*)(n.x + ((size_t)(b * a.H + ph + a.sh * ic) * a.W + pw + a.sw * jc) * a.C + gch * 8);
+        };
+        const unsigned stride = gridDim.x * 256u;
+        unsigned i = blockIdx.x * 256u + threadIdx.x;
+        uint4 xn = x_at(i < total ? i : total - 1);
+        for (; i < total; i += stride) {
+            const uint4 x4 = xn;
+            xn = x_at(i + stride < total ? i + stride : total - 1);
+            const unsigned p = fdivu(i, a.dcg);
+            const unsigned q = fdivu(p, dWc);
+            const int jc = (int)(p - q * Wc);
+            const unsigned b = fdivu(q, dHc);
+            const int ic = (int)(q - b * Hc);
+            const bf16_t* gb = dy + (size_t)b * a.OH * a.OW * a.C + gch * 8;
+            float acc[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+#pragma unroll
+            for (int kh = 0; kh < K; ++kh) {
+                if (!lh[kh]) continue;
+                const int oh = oh0[kh] + ic;
+#pragma unroll
+                for (int kw = 0; kw < K; ++kw) {
+                    if (!lw[kw]) continue;
+                    const int ow = ow0[kw] + jc;
+                    const bool v = ((unsigned)oh < (unsigned)a.OH) & ((unsigned)ow < (unsigned)a.OW);
+                    const uint4 ld = *(const uint4*)(gb + (v ? (oh * a.OW + ow) * a.C : 0));
+                    const uint4 g4 = v ? ld : make_uint4(0, 0, 0, 0);
+                    float gf[8], wf[8];
+                    unpack8(g4, gf);
+                    unpack8(*(const uint4*)(w + (kh * K + kw) * a.C + gch * 8), wf);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) acc[j] = fmaf(gf[j], wf[j], acc[j]);
+                }
+            }
+            float gv[8], xv[8];
+            unpack8(pack8(acc), gv);                    // the bf16 rounding of the materialised g
+            unpack8(x4, xv);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { s[0][j] += gv[j]; s[1][j] += gv[j] * (xv[j] - mu[j]) * is[j]; }
+            if (NS == 5) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float ad = act_grad_y_k<P>(xv[j], n.prev_act, n.prev_alpha);
+                    s[2][j] += ad * gv[j];
+                    s[3][j] += ad * xv[j];
+                    s[4][j] += ad;
+                }
+            }
+        }
+    }
+    // lanes l, l + cg, ... of a wave hold different pixels of one channel group: shuffle fold, four waves through LDS
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int off = cg; off < 64; off <<= 1) {
+#pragma unroll
+        for (int k = 0; k < NS; ++k)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) s[k][j] += __shfl_xor(s[k][j], off, 64);
+    }
+    if (lane < cg) {
+#pragma unroll
+        for (int k = 0; k < NS; ++k)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) red[(wave * cg + lane) * (NS * 8) + k * 8 + j] = s[k][j];
+    }
+    __syncthreads();
+    const size_t nb = (size_t)gridDim.x * gridDim.y;
+    const size_t bi = (size_t)blockIdx.y * gridDim.x + blockIdx.x;
+    for (int t = threadIdx.x; t < cg * NS * 8; t += 256) {
+        const int gl = t / (NS * 8), e = t - gl * (NS * 8);
+        float v = red[t];
+#pragma unroll
+        for (int wv = 1; wv < 4; ++wv) v += red[wv * cg * (NS * 8) + t];
+        const int k = e >> 3, j = e & 7;
+        n.part[((size_t)k * a.C + gl * 8 + j) * nb + bi] = v;
+    }
+}
+
+template <int K, int P>
+__global__ __launch_bounds__(256) void dw_dgrad_bn_apply_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ w,
+                                                                bf16_t* __restrict__ dx, const DwArgs a,
+                                                                const DwBnArgs n) {
+    const int cg = a.C / 8;
+    const int ph = blockIdx.y / a.sw, pw = blockIdx.y - ph * a.sw;
+    const int Hc = (a.H - ph + a.sh - 1) / a.sh, Wc = (a.W - pw + a.sw - 1) / a.sw;
+    if (Hc <= 0 || Wc <= 0) return;
+    int oh0[K], ow0[K];
+    bool lh[K], lw[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        const int th0 = ph + a.pt - k * a.dh, tw0 = pw + a.pl - k * a.dw;
+        const int qh = th0 >= 0 ? th0 / a.sh : -((-th0 + a.sh - 1) / a.sh);
+        const int qw = tw0 >= 0 ? tw0 / a.sw : -((-tw0 + a.sw - 1) / a.sw);
+        lh[k] = qh * a.sh == th0;
+        lw[k] = qw * a.sw == tw0;
+        oh0[k] = qh;
+        ow0[k] = qw;
+    }
+    const int gch = threadIdx.x & (cg - 1);
+    // dx = prev_act'(x) * (k0*g + k1*x + k2),  k0 = gamma*is, k1 = -gamma*is*is*c2, k2 = -gamma*is*(c1 - mean*is*c2)
+    float k0[8], k1[8], k2[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int c = gch * 8 + j;
+        const float is = n.invstd[c], gi = n.gamma[c] * is;
+        k0[j] = gi;
+        k1[j] = -gi * is * n.c2[c];
+        k2[j] = -gi * (n.c1[c] - n.mean[c] * is * n.c2[c]);
+    }
+    const FastDiv dWc = a.dsw_wc[pw], dHc = a.dsh_hc[ph];
+    const unsigned total = (unsigned)a.B * Hc * Wc * cg;
+    for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < total; i += gridDim.x * 256u) {
+        const unsigned p = fdivu(i, a.dcg);
+        const unsigned q = fdivu(p, dWc);
+        const int jc = (int)(p - q * Wc);
+        const unsigned b = fdivu(q, dHc);
+        const int ic = (int)(q - b * Hc);
+        const bf16_t* gb = dy + (size_t)b * a.OH * a.OW * a.C + gch * 8;
+        const int ih = ph + a.sh * ic, iw = pw + a.sw * jc;
+        const size_t xo = ((size_t)(b * a.H + ih) * a.W + iw) * a.C + gch * 8;
+        const uint4 x4 = *(const uint4*)(n.x + xo);
+        float acc[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+#pragma unroll
+        for (int kh = 0; kh < K; ++kh) {
+            if (!lh[kh]) continue;
+            const int oh = oh0[kh] + ic;
+#pragma unroll
+            for (int kw = 0; kw < K; ++kw) {
+                if (!lw[kw]) continue;
+                const int ow = ow0[kw] + jc;
+                const bool v = ((unsigned)oh < (unsigned)a.OH) & ((unsigned)ow < (unsigned)a.OW);
+                const uint4 ld = *(const uint4*)(gb + (v ? (oh * a.OW + ow) * a.C : 0));
+                const uint4 g4 = v ? ld : make_uint4(0, 0, 0, 0);
+                float gf[8], wf[8];
+                unpack8(g4, gf);
+                unpack8(*(const uint4*)(w + (kh * K + kw) * a.C + gch * 8), wf);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc[j] = fmaf(gf[j], wf[j], acc[j]);
+            }
+        }
+        float gv[8], xv[8];
+        unpack8(pack8(acc), gv);
+        unpack8(x4, xv);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float d = fmaf(k0[j], gv[j], fmaf(k1[j], xv[j], k2[j]));
+            if (P != ACT_LINEAR) d *= act_grad_y_k<P>(xv[j], n.prev_act, n.prev_alpha);
+            gv[j] = d;
+        }
+        *(uint4*)(dx + xo) = pack8(gv);
+    }
+}
+
+// phase 0: REDUCE (writes n.part, returns the number of partial blocks per channel), phase 1: APPLY (writes dx).
+// `ns`: 2 (dgamma / dbeta sums) or 5 (plus the bias gradient of the conv in front of the BatchNorm).
+// Returns < 0 when the shape is outside the fused kernels' range (the caller runs the three-pass form).
+DDL_API int ddl_dw_dgrad_bn(int phase, const void* dy, const void* w, const void* x, void* dx, float* part, int B,
+                            int H, int W, int C, int OH, int OW, int K, int sh, int sw, int dh, int dw, int pt, int pl,
+                            const float* mean, const float* invstd, const float* gamma, const float* c1,
+                            const float* c2, int prev_act, float prev_alpha, int ns, hipStream_t s) {
+    const int cg = C / 8;
+    if (C % 8 || cg > 64 || (cg & (cg - 1)) || K < 1 || K > 3 || sh > 3 || sw > 3 || (ns != 2 && ns != 5)) return -1;
+    const long in_elems = (long)B * H * W * C, out_elems = (long)B * OH * OW * C;
+    if (in_elems >= (1L << 31) || out_elems >= (1L << 31)) return -1;
+    DwArgs d;
+    d.B = B; d.H = H; d.W = W; d.C = C; d.OH = OH; d.OW = OW; d.sh = sh; d.sw = sw; d.dh = dh; d.dw = dw;
+    d.pt = pt; d.pl = pl; d.c_true = C; d.act = 0; d.alpha = 0.f;
+    d.in_scale = nullptr; d.in_shift = nullptr; d.in_ctrue = 0; d.all_valid = 0;
+    d.total = (unsigned)((long)B * H * W * cg);
+    d.dcg = make_fastdiv(cg); d.dOW = make_fastdiv(OW); d.dOH = make_fastdiv(OH);
+    d.dW_ = make_fastdiv(W); d.dH_ = make_fastdiv(H); d.dsh = make_fastdiv(sh); d.dsw = make_fastdiv(sw);
+    for (int p_ = 0; p_ < 3; ++p_) {
+        const int hc = p_ < sh ? (H - p_ + sh - 1) / sh : 1, wc = p_ < sw ? (W - p_ + sw - 1) / sw : 1;
+        d.dsh_hc[p_] = make_fastdiv(hc > 0 ? hc : 1);
+        d.dsw_wc[p_] = make_fastdiv(wc > 0 ? wc : 1);
+    }
+    DwBnArgs n;
+    n.x = (const bf16_t*)x; n.mean = mean; n.invstd = invstd; n.gamma = gamma; n.c1 = c1; n.c2 = c2; n.part = part;
+    n.prev_act = prev_act; n.prev_alpha = prev_alpha;
+    const int classes = sh * sw;
+    unsigned g = (d.total + 255u) / 256u;
+    // REDUCE: few, long blocks (every block leaves NS * C partials); APPLY: the plain dgrad's grid
+    unsigned gx = phase == 0 ? (2048u + classes - 1) / classes : ((g > 8192u ? 8192u : g) + classes - 1) / classes;
+    if (phase == 0 && gx * 256u * classes > d.total) gx = (d.total / (256u * classes)) ? d.total / (256u * classes) : 1u;
+    if (gx < 1) gx = 1;
+    const dim3 grid(gx, classes);
+#define DWBN_K(KK)                                                                                                    \
+    do {                                                                                                              \
+        if (phase == 0) {                                                                                             \
+            if (ns == 5) {                                                                                            \
+                ACT1_DISPATCH(prev_act, DWBN_R5_##KK);                                                                \
+            } else                                                                                                    \
+                dw_dgrad_bn_reduce_kernel<KK, 2, 0><<<grid, 256, 0, s>>>((const bf16_t*)dy, (const bf16_t*)w, d, n);  \
+        } else {                                                                                                      \
+            ACT1_DISPATCH(prev_act, DWBN_A_##KK);                                                                     \
+        }                                                                                                             \
+    } while (0)
+#define DWBN_R5_1(A) dw_dgrad_bn_reduce_kernel<1, 5, A><<<grid, 256, 0, s>>>((const bf16_t*)dy, (const bf16_t*)w, d, n)
+#define DWBN_R5_2(A) dw_dgrad_bn_reduce_kernel<2, 5, A><<<grid, 256, 0, s>>>((const bf16_t*)dy, (const bf16_t*)w, d, n)
+#define DWBN_R5_3(A) dw_dgrad_bn_reduce_kernel<3, 5, A><<<grid, 256, 0, s>>>((const bf16_t*)dy, (const bf16_t*)w, d, n)
+#define DWBN_A_1(A) dw_dgrad_bn_apply_kernel<1, A><<<grid, 256, 0, s>>>((const bf16_t*)dy, (const bf16_t*)w, (bf16_t*)dx, d, n)
+#define DWBN_A_2(A) dw_dgrad_bn_apply_kernel<2, A><<<grid, 256, 0, s>>>((const bf16_t*)dy, (const bf16_t*)w, (bf16_t*)dx, d, n)
+#define DWBN_A_3(A) dw_dgrad_bn_apply_kernel<3, A><<<grid, 256, 0, s>>>((const bf16_t*)dy, (const bf16_t*)w, (bf16_t*)dx, d, n)
+    if (K == 1) DWBN_K(1);
+    else if (K == 2) DWBN_K(2);
+    else DWBN_K(3);
+#undef DWBN_K
+    return phase == 0 ? (int)(gx * classes) : 0;
+}
+
 // dW[t][c] partials: block = (pixel chunk, kernel ROW): the K taps of one kernel row share the dY load and
 // their X pixels are neighbours.  One block per tap (nine dY reads) and one block for all nine taps (one
 // dY read, 72 accumulators: 771 vs 544 us per classifier step) were both measured slower: K x the

@@ -65,17 +65,17 @@ class RandomModel:
             averager.attach(self.net)
 
     # ------------------------------------------------------------------ one optimisation step
-    def _loss(self, logits, y, want_grad=True):
+    def _loss(self, logits, y, want_grad=True, index=None):
         if self.loss_name == "mean_squared_error":
-            return F.softmax_mse(logits, y, want_grad)
-        return F.softmax_ce(logits, y, want_grad)
+            return F.softmax_mse(logits, y, want_grad, index=index)
+        return F.softmax_ce(logits, y, want_grad, index=index)
 
     def _fwd_bwd(self, idx):
         net = self.net
         x = net.prepare_input(self.data.train_x, index=idx)
-        y = self.data.train_y.index_select(0, idx)
         logits = net.forward(x, training=True)
-        loss, dlogits, _ = self._loss(logits, y)
+        # the minibatch's labels are read through the same index vector inside the loss kernel (no gather pass)
+        loss, dlogits, _ = self._loss(logits, self.data.train_y, index=idx)
         net.backward(dlogits)
         return loss
 

@@ -35,6 +35,7 @@ BN_BWD_FUSE = os.environ.get("DDL_BN_BWD_FUSE", "1") == "1"       # BN backward 
 BIAS_IN_WGRAD = os.environ.get("DDL_BIAS_IN_WGRAD", "1") == "1"   # one-channel input conv: bias gradient out of the weight-gradient launch
 BN_ON_LOAD = os.environ.get("DDL_BN_ON_LOAD", "1") == "1"         # BN in front of a 1-channel ConvT applied on load
 FUSE_ACT_BWD = os.environ.get("DDL_FUSE_ACT_BWD", "1") == "1"   # act'(y) of the layer below in the dgrad epilogue
+DW_BN_FUSE = os.environ.get("DDL_DW_BN_FUSE", "1") == "1"     # depthwise dgrad + backward of the BatchNorm in front of it
 BRANCH = os.environ.get("DDL_BRANCH", "1") == "1"    # weight-gradient branch on a side stream (captured steps)
 ALIGN = 8      # every tensor starts at a multiple of 8 elements (16 B in bf16, 32 B in fp32)
 
@@ -434,7 +435,33 @@ class ConvOp(Op):
                     self._bias_grad(dy)
                 _BR.run(wg, dy)
             if need_dx:
-                dx = F.conv_dgrad(dy, self.w_main if g.depthwise else self.w_alt, g, mul=mul)
+                dx = self._dw_bn_bwd(dy, need_dw) if (g.depthwise and mul is None) else None
+                if dx is None:
+                    dx = F.conv_dgrad(dy, self.w_main if g.depthwise else self.w_alt, g, mul=mul)
+        return dx
+
+    def _dw_bn_bwd(self, dy, need_dw):
+        """Depthwise layer behind a batch-statistics BatchNorm (every `random_layer` of DDL_Normal4.py:52 is followed
+        by one): the input gradient IS that BatchNorm's dY, so both backward steps run as two fused passes that
+        recompute it from the small dY instead of writing and re-reading it (ops/hip.py dw_dgrad_bn_bwd).  Returns the
+        gradient at the BatchNorm's input and marks the BatchNorm's backward as done, or None (unfused path)."""
+        bn = self.in_bn
+        if not (DW_BN_FUSE and dy.is_cuda and need_dw and bn is not None and bn.defer_to is self
+                and bn.used_batch_stats and bn.groups_used == 1 and bn.x is not None and bn.rank4
+                and bn.post_act in (None, "linear") and bn.pre_bwd is None):
+            return None
+        # the fused passes compute the stencil twice: worth it while a pixel has few live taps (stride 2: 2.25 of a
+        # 3x3), not for a stride-1 3x3 (nine taps, two loads each: 236 us fused vs 140 us in three passes, measured on
+        # model0's 28 x 28 x 128 layer at batch 512)
+        g = self.g
+        if g.KH * g.KW > 2.5 * g.sh * g.sw:
+            return None
+        conv = bn.bias_grad_for
+        dx = F.hip_backend().dw_dgrad_bn_bwd(dy, self.w_main, self.g, bn.x, bn.mean.reshape(-1), bn.invstd.reshape(-1),
+                                             bn.gamma, bn.prev_act, bn.prev_alpha, bn.ggamma, bn.gbeta,
+                                             conv.gbias if conv is not None else None)
+        if dx is not None:
+            bn.bwd_done = True
         return dx
 
     def release(self):
@@ -463,6 +490,7 @@ class BNOp(Op):
         self.defer_to = None           # ConvOp that applies this BN's affine on load (no output tensor of our own)
         self.fp32_handoff = False      # ... and does so in fp32 (depthwise tap sums): no bf16 rounding of our output
         self.pre_bwd = None            # (partials, blocks, sums) of our backward reduction, left by the kernel that made dy
+        self.bwd_done = False          # the layer above already ran our backward (ConvOp._dw_bn_bwd): dy IS our dx
 
     def fwd(self, x, training):
         use_batch = training and self.mode == "batch"
@@ -526,6 +554,9 @@ class BNOp(Op):
         return dx
 
     def bwd(self, dy, need_dx=True, need_dw=True):
+        if self.bwd_done:
+            self.bwd_done = False
+            return dy
         conv = self.bias_grad_for
         pre, self.pre_bwd = self.pre_bwd, None
         if pre is not None and pre[2] == (5 if (need_dw and conv is not None) else 2):

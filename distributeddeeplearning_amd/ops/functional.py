@@ -208,12 +208,17 @@ def softmax(logits, n_true=None):
     return cpu_ref.softmax(logits)
 
 
-def softmax_ce(logits, onehot, want_grad=True):
-    return _b(logits).softmax_ce(logits, onehot, want_grad)
+def softmax_ce(logits, onehot, want_grad=True, index=None):
+    """`index`: row r's target is onehot[index[r]] -- on device the gather happens inside the loss kernel."""
+    if index is not None and not logits.is_cuda:
+        onehot, index = onehot.index_select(0, index), None
+    return _b(logits).softmax_ce(logits, onehot, want_grad, **({"index": index} if index is not None else {}))
 
 
-def softmax_mse(logits, target, want_grad=True):
-    return _b(logits).softmax_mse(logits, target, want_grad)
+def softmax_mse(logits, target, want_grad=True, index=None):
+    if index is not None and not logits.is_cuda:
+        target, index = target.index_select(0, index), None
+    return _b(logits).softmax_mse(logits, target, want_grad, **({"index": index} if index is not None else {}))
 
 
 def sigmoid_bce(logits, labels, want_grad=True):

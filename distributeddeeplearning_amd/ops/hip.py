@@ -59,7 +59,7 @@ _pad_channels = _sig("ddl_pad_channels", None, vp, ci, vp, vp, cl, ci, ci, ci, c
 _strip_channels = _sig("ddl_strip_channels", None, vp, vp, cl, ci, ci, vp)
 _spatial_pad = _sig("ddl_spatial_pad", None, vp, vp, ci, ci, ci, ci, ci, ci, ci, ci, vp)
 _affine = _sig("ddl_affine", None, vp, vp, cl, ci, ci, cf, cf, vp)
-_softmax_loss = _sig("ddl_softmax_loss", None, vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, vp)
+_softmax_loss = _sig("ddl_softmax_loss", None, vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, vp)
 _sigmoid_bce = _sig("ddl_sigmoid_bce", None, vp, vp, vp, vp, vp, ci, vp)
 _dense1_blocks = _sig("ddl_dense1_bce_blocks", ci, ci)
 _dense1_bce = _sig("ddl_dense1_bce", ci, vp, vp, vp, cf, cf, ci, ci, ci, vp, vp, vp, vp, vp, vp, vp, vp, ci, ci,
@@ -95,6 +95,8 @@ _slab_reduce_frag = _sig("ddl_slab_reduce_frag", ci, vp, vp, ci, ci, ci, ci, ci,
 _wgrad2_lds = _sig("ddl_wgrad2_lds", ci, ci, ci, ci, ci, ci, ci, ci, ci, ci)
 _slab_reduce = _sig("ddl_slab_reduce", None, vp, vp, cl, cl, ci, vp)
 _dw_blocks = _sig("ddl_dw_wgrad_blocks", ci, cl, ci)
+_dw_dgrad_bn = _sig("ddl_dw_dgrad_bn", ci, ci, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci,
+                    vp, vp, vp, vp, vp, ci, cf, ci, vp)
 _depthwise = _sig("ddl_depthwise", ci, ci, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci,
                   ci, ci, ci, ci, cf, vp, vp, ci, vp)
 
@@ -321,6 +323,48 @@ def bn_bwd(dy, x, y, mean, invstd, gamma, act, alpha, train_stats, prev_act=None
             _stream())
     _done()
     return dx, out_dgamma, out_dbeta
+
+
+def dw_dgrad_bn_bwd(dy, w, g: "ConvGeom", x, mean, invstd, gamma, prev_act, prev_alpha, out_dgamma, out_dbeta,
+                    out_dbias=None):
+    """Depthwise input gradient fused with the backward of the batch-statistics BatchNorm in front of the layer
+    (csrc/hip/wgrad.hip `dw_dgrad_bn_*`): dy [B][OH][OW][Cp] -> dx [B][H][W][Cp], the gradient at the BatchNorm's INPUT
+    `x` (times prev_act'(x) of the conv in front of it), plus dgamma / dbeta (/ that conv's bias gradient).  The
+    BatchNorm's dY -- the depthwise input gradient proper -- is recomputed in both passes and never stored.
+    Returns None when the shape is outside the fused kernels' range."""
+    _chk_act(dy, "dy")
+    _chk_act(x, "x")
+    B, Cp = x.shape[0], x.shape[-1]
+    if tuple(x.shape[1:3]) != (g.H, g.W) or tuple(dy.shape) != (B, g.OH, g.OW, Cp) or g.KH != g.KW:
+        return None
+    cgn = Cp // 8
+    if cgn > 64 or cgn & (cgn - 1) or g.KH > 3 or g.sh > 3 or g.sw > 3:
+        return None
+    _chk_w(w, (g.KH, g.KW, Cp), "depthwise kernel")
+    for t, nme in ((mean, "mean"), (invstd, "invstd"), (gamma, "gamma"), (out_dgamma, "dgamma"), (out_dbeta, "dbeta")):
+        _chk_f32(t, Cp, nme)
+    ns = 5 if out_dbias is not None else 2
+    dev = x.device
+    classes = g.sh * g.sw
+    nb_max = (-(-2048 // classes)) * classes
+    part = torch.empty(ns * Cp * nb_max, dtype=torch.float32, device=dev)
+    coef = torch.empty(2, Cp, dtype=torch.float32, device=dev)
+    args = (B, g.H, g.W, Cp, g.OH, g.OW, g.KH, g.sh, g.sw, g.dh, g.dw, g.pt, g.pl, mean.data_ptr(), invstd.data_ptr(),
+            gamma.data_ptr(), coef[0].data_ptr(), coef[1].data_ptr(), ACT_CODE[prev_act], prev_alpha, ns, _stream())
+    nb = _dw_dgrad_bn(0, dy.data_ptr(), w.data_ptr(), x.data_ptr(), None, part.data_ptr(), *args)
+    if nb <= 0:
+        return None
+    # the ordinary finalize (fp64, fixed order): c1, c2, dgamma, dbeta, dbias from part[ns][Cp][nb]
+    _bn_bwd(None, None, None, None, B * g.H * g.W, Cp, mean.data_ptr(), invstd.data_ptr(), gamma.data_ptr(), 0, 0.3, 1,
+            ACT_CODE[prev_act], prev_alpha, part.data_ptr(), out_dgamma.data_ptr(), out_dbeta.data_ptr(),
+            coef[0].data_ptr(), coef[1].data_ptr(), _p(out_dbias), 0 if out_dbias is None else out_dbias.numel(), 1,
+            nb, _stream())
+    dx = torch.empty_like(x)
+    rc = _dw_dgrad_bn(1, dy.data_ptr(), w.data_ptr(), x.data_ptr(), dx.data_ptr(), part.data_ptr(), *args)
+    if rc < 0:
+        raise ValueError("dw_dgrad_bn apply pass rejected a shape its reduce pass accepted")
+    _done()
+    return dx
 
 
 def bias_grad(dy, out):
@@ -639,7 +683,7 @@ def strip_channels(x, c_true):
 
 
 # ------------------------------------------------------------------------------ losses
-def _softmax_common(logits, target, mode, want_grad, want_probs=True, n_true=None):
+def _softmax_common(logits, target, mode, want_grad, want_probs=True, n_true=None, index=None):
     _chk_act(logits, "logits")
     B, Cs = logits.shape
     N = n_true if target is None else target.shape[1]
@@ -648,16 +692,20 @@ def _softmax_common(logits, target, mode, want_grad, want_probs=True, n_true=Non
     dev = logits.device
     probs = torch.empty(B, N, dtype=torch.float32, device=dev) if want_probs else None
     if mode == 0:
-        _softmax_loss(logits.data_ptr(), None, probs.data_ptr(), None, None, None, B, Cs, N, 0, 0, _stream())
+        _softmax_loss(logits.data_ptr(), None, None, probs.data_ptr(), None, None, None, B, Cs, N, 0, 0, _stream())
         _done()
         return None, None, probs
-    if not (target.is_cuda and target.dtype == torch.float32 and target.is_contiguous() and target.shape[0] == B):
-        raise ValueError("target must be contiguous fp32 cuda [B,N]")
+    if not (target.is_cuda and target.dtype == torch.float32 and target.is_contiguous()
+            and target.shape[0] == (B if index is None else target.shape[0]) and target.shape[1] == N):
+        raise ValueError("target must be contiguous fp32 cuda [B,N] ([rows,N] with `index`)")
+    if index is not None and not (index.is_cuda and index.dtype == torch.int64 and index.is_contiguous()
+                                  and index.numel() == B):
+        raise ValueError("index must be a contiguous cuda int64 vector of B row numbers")
     dl = torch.empty_like(logits) if want_grad else None
     rowloss = torch.empty(B, dtype=torch.float32, device=dev)
     loss = torch.empty((), dtype=torch.float32, device=dev)
-    _softmax_loss(logits.data_ptr(), target.data_ptr(), _p(probs), _p(dl), rowloss.data_ptr(), loss.data_ptr(),
-                  B, Cs, N, mode, int(want_grad), _stream())
+    _softmax_loss(logits.data_ptr(), target.data_ptr(), _p(index), _p(probs), _p(dl), rowloss.data_ptr(),
+                  loss.data_ptr(), B, Cs, N, mode, int(want_grad), _stream())
     _done()
     return loss, dl, probs
 
@@ -666,12 +714,13 @@ def softmax(logits, n_true=None):
     return _softmax_common(logits, None, 0, False, True, n_true or logits.shape[1])[2]
 
 
-def softmax_ce(logits, onehot, want_grad=True):
-    return _softmax_common(logits, onehot, 1, want_grad)
+def softmax_ce(logits, onehot, want_grad=True, index=None):
+    """`index`: row r's target is onehot[index[r]] (label gather fused into the loss kernel)."""
+    return _softmax_common(logits, onehot, 1, want_grad, index=index)
 
 
-def softmax_mse(logits, target, want_grad=True):
-    return _softmax_common(logits, target, 2, want_grad)
+def softmax_mse(logits, target, want_grad=True, index=None):
+    return _softmax_common(logits, target, 2, want_grad, index=index)
 
 
 def sigmoid_bce(logits, labels, want_grad=True):
@@ -714,7 +763,10 @@ def dense1_bce_fwd_bwd(x, w, b, label_first, label_second, n_first, want_dx=True
     nb = _dense1_blocks(M // groups)
     dw_part = torch.empty(nb * groups * K, dtype=torch.float32, device=dev) if want_dw else None
     aux = torch.empty(3, M, dtype=torch.float32, device=dev)       # logits, rowloss, dlogit
-    loss = torch.empty((), dtype=torch.float32, device=dev)
+    # With a weight gradient the mean loss rides in head_finalize; without one (the generator phase) it would be a
+    # single-block launch of its own on every step, for a number that is only read when somebody logs it: the row
+    # losses stay on the device and the mean is taken when asked for (DeferredMean; a replayed graph rewrites `aux`)
+    loss = torch.empty((), dtype=torch.float32, device=dev) if (want_dw or not DEFER_MEAN) else None
     if bn is not None:
         part = torch.empty(2 * bC * groups * nb, dtype=torch.float32, device=dev)
         bn["part"], bn["nb"] = part, nb
@@ -728,12 +780,35 @@ def dense1_bce_fwd_bwd(x, w, b, label_first, label_second, n_first, want_dx=True
         _chk_f32(out_db, 1, "db")
     rc = _dense1_bce(x.data_ptr(), w.data_ptr(), b.data_ptr(), label_first, label_second, n_first, M, K,
                      _p(dx), _p(dw_part), aux[0].data_ptr(), aux[1].data_ptr(), aux[2].data_ptr(),
-                     loss.data_ptr(), _p(out_dw) if want_dw else None, _p(out_db) if want_dw else None,
+                     _p(loss), _p(out_dw) if want_dw else None, _p(out_db) if want_dw else None,
                      int(want_dx), int(want_dw), bsc, bsh, bmu, bis, bpart, bC, groups, bact, balpha, _stream())
     if rc != 0:
         raise ValueError(f"dense1_bce: unsupported K={K} (rc={rc})")
     _done()
-    return loss, dx, out_dw, out_db, aux[0]
+    return (loss if loss is not None else DeferredMean(aux[1])), dx, out_dw, out_db, aux[0]
+
+
+DEFER_MEAN = os.environ.get("DDL_DEFER_MEAN", "1") == "1"
+
+
+class DeferredMean:
+    """Mean of a device vector, computed when read (`float(x)` / `x.item()`): in fp64 over the row order, as the
+    single-block mean kernel does.  Holds the (static, under graph replay) buffer, not a value."""
+    __slots__ = ("rows",)
+
+    def __init__(self, rows: torch.Tensor):
+        self.rows = rows
+
+    def item(self) -> float:
+        return float(self.rows.double().sum().item() / self.rows.numel())
+
+    __float__ = item
+
+    def detach(self):
+        return self
+
+    def __repr__(self):
+        return f"DeferredMean({self.item():.6g})"
 
 
 def argmax_match_count(pred, onehot):

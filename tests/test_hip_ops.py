@@ -902,3 +902,75 @@ def test_averaging_kernels_equal_the_cpu_form_of_the_averager(hip):
     assert torch.allclose(P.cpu(), cpu, rtol=0, atol=1e-6)
     # the average keeps the local progress and replaces the snapshot by the mean
     assert torch.allclose(P.cpu(), total / W + prog, rtol=0, atol=1e-5)
+
+
+def test_softmax_loss_label_gather_by_index_equals_gathered_targets(hip):
+    """`softmax_ce(..., index=)` / `softmax_mse(..., index=)`: the minibatch's label rows are read through the index
+    vector inside the loss kernel -- bit-identical to gathering them first."""
+    g = torch.Generator().manual_seed(3)
+    logits = hip.pad_channels(torch.randn(96, 10, generator=g).cuda(), 16)
+    pool = torch.nn.functional.one_hot(torch.randint(0, 10, (500,), generator=g), 10).float().cuda()
+    idx = torch.randint(0, 500, (96,), generator=g).cuda()
+    for fn in (hip.softmax_ce, hip.softmax_mse):
+        l0, d0, p0 = fn(logits, pool.index_select(0, idx).contiguous())
+        l1, d1, p1 = fn(logits, pool, index=idx)
+        assert torch.equal(l0, l1) and torch.equal(d0, d1) and torch.equal(p0, p1)
+
+
+@pytest.mark.parametrize("case", [(57, 57, 128, 3, 2, 2, "softplus"), (28, 28, 128, 3, 1, 2, "relu"),
+                                  (18, 18, 16, 3, 1, 3, "linear"), (10, 10, 64, 2, 3, 2, "sigmoid"),
+                                  (13, 12, 32, 1, 2, 1, "tanh")])
+def test_depthwise_dgrad_fused_with_batchnorm_backward(hip, case):
+    """`dw_dgrad_bn_bwd`: depthwise input gradient + backward of the BatchNorm in front of the layer as two passes that
+    recompute the BatchNorm's dY instead of storing it.  Against the three-pass form on the same operands (dw dgrad ->
+    bn_bwd with the bias-gradient sums): dx agrees to bf16 rounding (the column sums are taken in another order), and
+    dgamma / dbeta / dbias to fp32 summation; and against the fp32 oracle."""
+    H, W, Cc, k, s, d, prev_act = case
+    g = G.depthwise_geom(H, W, Cc, (k, k), (s, s), (d, d), "valid", keras224_compat=True)
+    B = 4 if H > 30 else 19
+    torch.manual_seed(5)
+    x = r16(torch.randn(B, H, W, Cc) * 1.5 + 0.3)            # the BatchNorm's input (the conv output, post-activation)
+    if prev_act in ("relu", "softplus", "sigmoid"):
+        x = r16(x.abs() * (0.5 if prev_act == "sigmoid" else 1.0)).clamp(max=0.99 if prev_act == "sigmoid" else 1e9)
+    w = r16(torch.randn(k, k, Cc))
+    dy = r16(torch.randn(B, g.OH, g.OW, Cc))
+    gamma = torch.rand(Cc) + 0.5
+    xf = x.reshape(-1, Cc)
+    mean, var = xf.mean(0), xf.var(0, unbiased=False)
+    invstd = 1.0 / torch.sqrt(var + 1e-3)
+    xd, wd, dyd = dev(hip, x), padw(hip, w), dev(hip, dy)
+    md, isd, gd = mean.cuda(), invstd.cuda(), gamma.cuda()
+    outs = {}
+    for fused in (True, False):
+        dgam, dbet, dbias = (torch.zeros(Cc, device="cuda") for _ in range(3))
+        if fused:
+            dx = hip.dw_dgrad_bn_bwd(dyd, wd, g, xd, md, isd, gd, prev_act, 0.3, dgam, dbet, dbias)
+            assert dx is not None
+        else:
+            gfull = hip.conv_dgrad(dyd, wd, g)
+            dx, _, _ = hip.bn_bwd(gfull, xd, None, md, isd, gd, None, 0.3, True, prev_act, 0.3, dgam, dbet, dbias)
+        torch.cuda.synchronize()
+        outs[fused] = (host(hip, dx, Cc), dgam.cpu(), dbet.cpu(), dbias.cpu())
+    a, b = outs[True], outs[False]
+    close(a[0], b[0], rtol=1e-2)
+    # sums of many signed terms (the bias gradient of a conv in front of a BatchNorm cancels to ~0 where act' == 1):
+    # tolerances are set by the magnitude of the terms, not of the result
+    mag_g = float(cpu_ref.conv_dgrad(dy, w, g).abs().reshape(-1, Cc).sum(0).max())
+    mag_dx = float(b[0].abs().reshape(-1, Cc).sum(0).max())
+    close(a[1], b[1], rtol=1e-3, atol=1e-4 * mag_g * 3)
+    close(a[2], b[2], rtol=1e-3, atol=1e-4 * mag_g)
+    close(a[3], b[3], rtol=1e-3, atol=1e-3 * mag_dx)
+    # fp32 oracle of the same chain on the bf16-rounded g
+    gref = r16(cpu_ref.conv_dgrad(dy, w, g))
+    xhat = (x - mean) * invstd
+    rows = B * H * W
+    c1 = gref.reshape(-1, Cc).sum(0) / rows
+    c2 = (gref * xhat).reshape(-1, Cc).sum(0) / rows
+    dxr = gamma * invstd * (gref - c1 - xhat * c2)
+    ad = {"linear": torch.ones_like(x), "relu": (x > 0).float(), "sigmoid": x * (1 - x), "tanh": 1 - x * x,
+          "softplus": 1 - torch.exp(-x)}[prev_act]
+    dxr = dxr * ad
+    close(a[0], dxr, rtol=3e-2)
+    close(a[1], (gref * xhat).reshape(-1, Cc).sum(0), rtol=1e-2)
+    close(a[2], gref.reshape(-1, Cc).sum(0), rtol=1e-2, atol=1e-2 * float(gref.reshape(-1, Cc).sum(0).abs().max()) + 1e-3)
+    close(a[3], dxr.reshape(-1, Cc).sum(0), rtol=2e-2, atol=2e-3 * float(dxr.abs().reshape(-1, Cc).sum(0).max()))

@@ -292,3 +292,44 @@ def test_bn_on_load_matches_materialised_depthwise(i):
     errs = [float((a.float() - b.float()).norm() / (b.float().norm() + 1e-6)) for a, b in zip(res[True], res[False])]
     print("ONLOAD_ERRS", i, errs)
     assert all(e < tol for e, tol in zip(errs, (3e-2, 6e-2, 1e-2))), errs
+
+
+@pytest.mark.parametrize("i", [0, 2])          # the replicas with a stride-2 depthwise layer (few live taps per pixel)
+def test_depthwise_bn_backward_fusion_matches_three_pass_form(i):
+    """models/network.py `_dw_bn_bwd`: whole-network gradients of the reference replicas with a BatchNorm -> depthwise
+    pair, fused (depthwise dgrad + BatchNorm backward in two recomputing passes) vs unfused (dgrad, column sums, apply).
+    Same arithmetic per element; only the order of the column sums differs."""
+    import os
+    from distributeddeeplearning_amd.models import network as N
+    from distributeddeeplearning_amd.utils import ckpt
+    ref = os.path.join(os.path.dirname(os.path.abspath(__file__)), "fixtures", "reference_models", f"model{i}")
+    if not os.path.isdir(ref):
+        pytest.skip("reference checkpoints not present on this box")
+    net = ckpt.load_model(ref, "cuda")
+    torch.manual_seed(40 + i)
+    x = net.prepare_input(torch.randint(0, 256, (24, 28, 28, 1), dtype=torch.uint8).cuda())
+    s0 = net.S.clone()
+    res, used = {}, {}
+    real = N.ConvOp._dw_bn_bwd
+    for fused in (True, False):
+        N.DW_BN_FUSE = fused
+        hits = []
+
+        def spy(self, dy, need_dw, _real=real, _hits=hits):
+            out = _real(self, dy, need_dw)
+            _hits.append(out is not None)
+            return out
+        N.ConvOp._dw_bn_bwd = spy
+        try:
+            net.S.copy_(s0)
+            y = net.forward(x, training=True)
+            net.G.zero_()
+            net.backward(torch.full_like(y, 0.01), need_input_grad=False)
+            torch.cuda.synchronize()
+            res[fused], used[fused] = net.G.clone(), list(hits)
+        finally:
+            N.DW_BN_FUSE = True
+            N.ConvOp._dw_bn_bwd = real
+    assert any(used[True]) and not any(used[False])
+    err = float((res[True] - res[False]).norm() / (res[False].norm() + 1e-12))
+    assert err < 2e-2, err
