@@ -21,11 +21,25 @@ class _DCGAN:
         if self.device.type == "cuda" and self.args.graph != "off":
             tune = (self.dp is not None and comms and not getattr(self.args, "zero", False)
                     and getattr(self.args, "dp_variant", "default") == "auto" and self.size == 28)
+            tuned, can_merge = False, self.t.merged
             if tune:        # communicator x generator pass x bucketing, timed on this machine (parallel/dp_tune.py)
                 from .parallel import dp_tune
-                self.graphed, self.dp_report = dp_tune.tune_gan_step(self.t, self.real, comms, self.args.full_ok,
-                                                                     verbose=self.rank == 0)
-            else:
+                err = None
+                try:
+                    self.graphed, self.dp_report = dp_tune.tune_gan_step(self.t, self.real, comms, self.args.full_ok,
+                                                                         verbose=self.rank == 0)
+                except Exception as e:      # noqa: BLE001 - every rank falls back together, the record says why
+                    err = e
+                if dp_tune.agree_max(0.0 if err is None else 1.0, self.device) > 0.0:
+                    self.graphed = None
+                    self.dp_report = {"dp_tune_failed": repr(err) if err is not None else "failed on another rank"}
+                    self.t.set_comm(self.dp)
+                    self.t.merged, self.t.buckets, self.t.comm_off, self.t._fake = can_merge, False, False, None
+                    comms = {n: c for n, c in comms.items() if c is self.dp}       # the plain, unbucketed RCCL step
+                    torch.cuda.synchronize()
+                else:
+                    tuned = True
+            if not tuned:
                 from .parallel import dp_tune
                 if self.dp is not None and len(comms) > 1:
                     # no step tuning (64x64: a step is ~170 ms, the collectives are noise): the communicator with
@@ -34,7 +48,8 @@ class _DCGAN:
                            for n, c in comms.items()}
                     name = min(lat, key=lat.get)
                     self.t.set_comm(comms[name])
-                    self.dp_report = {"comm_chosen": name, "allreduce_us_D_plus_G": {k: round(v, 2) for k, v in lat.items()}}
+                    self.dp_report.update(comm_chosen=name,
+                                          allreduce_us_D_plus_G={k: round(v, 2) for k, v in lat.items()})
                 full = self.args.graph == "full" or getattr(self.t.dp, "captures_safely", False)
                 self.graphed = GraphedGANStep(self.t, self.real, capture_collectives=full)
                 if self.dp is not None:

@@ -189,7 +189,6 @@ def tune_gan_step(trainer, real_prepared, comms: Dict[str, object], full_ok: Dic
     trainer is configured with the winner, its training state is what it was on entry, and the returned step object
     is captured and warm."""
     from ..models.dcgan import GraphedGANStep
-    from ..utils.hipgraph import CaptureError
     device = trainer.device
     can_merge = trainer.merged
     if can_merge:                       # plans of both generator-pass shapes, tuned without communication
@@ -211,21 +210,24 @@ def tune_gan_step(trainer, real_prepared, comms: Dict[str, object], full_ok: Dic
         trainer._fake = None
         return GraphedGANStep(trainer, real_prepared, warmup=warmup, capture_collectives=full_ok.get(c["comm"], False))
 
+    dropped = []
+
     def attempt(c, comm_off=False):
-        step, err, code = None, None, 0.0
+        """Build + time one candidate.  A candidate that cannot be built on ANY rank is dropped on all of them, whatever
+        the reason (the eight-GPU machine is where this code meets real links for the first time: the job must end on
+        the candidates that work, and the record says which did not and why)."""
+        step, err = None, None
         try:
             step = build(c, comm_off)
-        except CaptureError as e:
-            err, code = e, 1.0
-        except Exception as e:      # noqa: BLE001 - agreed on below, then raised on every rank
-            err, code = e, 2.0
-        code = agree_max(code, device)
-        if code >= 2.0:
-            raise err if err is not None else RuntimeError("a data-parallel step candidate failed on another rank")
-        if code >= 1.0:
+        except Exception as e:      # noqa: BLE001 - recorded in `dp_candidates_dropped`, agreed on below
+            err = e
+        failed = agree_max(0.0 if err is None else 1.0, device) > 0.0
+        if failed:
+            dropped.append(dict(c, comm_off=comm_off, error=repr(err) if err is not None else "failed on another rank"))
             if verbose:
                 print(f"[dp_tune] candidate {c} dropped: {err!r}", file=sys.stderr, flush=True)
-            torch.cuda.synchronize()
+            if trainer.G.on_gpu:
+                torch.cuda.synchronize()
             return None, None
         for _ in range(3):
             step.step()
@@ -266,6 +268,6 @@ def tune_gan_step(trainer, real_prepared, comms: Dict[str, object], full_ok: Dic
                              "fused_optimizer_in_allreduce": bool(trainer.fused),
                              "buckets_D": [hi - lo for lo, hi, _ in trainer._bk[id(trainer.D)]] if best["buckets"] else None,
                              "buckets_G": [hi - lo for lo, hi, _ in trainer._bk[id(trainer.G)]] if best["buckets"] else None},
-              "dp_candidates_us": timings, "exposed_comm_us_per_step": exposed,
+              "dp_candidates_us": timings, "dp_candidates_dropped": dropped, "exposed_comm_us_per_step": exposed,
               "step_us_without_collectives": None if exposed is None else round(dt0 * 1e6, 2), **lat}
     return final, report

@@ -56,3 +56,5 @@ def test_bench_force_dp_reports_comm_fields():
     assert d["graph_fallback_reason"] is None and d["rccl_ranks_seen"] == [0]
     for k in ("comm_chosen", "allreduce_us_D", "allreduce_us_G", "exposed_comm_us_per_step", "dp_variant"):
         assert k in d, k
+    assert d["dp_candidates_dropped"] == [] and "dp_tune_failed" not in d      # every candidate built: no hidden bug
+    assert len(d["dp_candidates_us"]) == 8 and d["p2p_validated"] is True

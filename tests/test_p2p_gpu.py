@@ -71,3 +71,8 @@ def test_spmd_ensemble_device_two_processes_with_transfer_broadcast(tmp_path):
     assert set(owners.tolist()) == {0.0, 1.0}      # the generation really was spread over both ranks
     assert a[-1] == 1.0                            # kernel healthy
     assert vote >= max(test_accs[:3]) - 0.1        # top-3 vote is no worse than its best member (small test set)
+
+
+def test_dp_step_tuner_two_processes_agree_and_restore_state(tmp_path):
+    mp.spawn(W.tune_gan, args=(2, _port(), str(tmp_path)), nprocs=2, join=True)
+    _flags(tmp_path, "tn", 2)
