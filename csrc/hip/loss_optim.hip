@@ -462,6 +462,36 @@ DDL_API void ddl_scale_emit(float* P, void* Pc, long n, float scale, hipStream_t
     scale_emit_kernel<<<grid, 256, 0, s>>>((float4*)P, (uint2*)Pc, n4, scale);
 }
 
+// ------------------------------------------------------------------------------ flat fp32 helpers
+// dst += src (sum of per-slice weight gradients when a batch is split into several launches) and dst = 0: the
+// framework's own launches, so no torch elementwise / fill kernel sits on the device path.
+__global__ void add_f32_kernel(float4* __restrict__ dst, const float4* __restrict__ src, long n4) {
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+        float4 a = dst[i];
+        const float4 b = src[i];
+        a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+        dst[i] = a;
+    }
+}
+__global__ void add_f32_tail_kernel(float* __restrict__ dst, const float* __restrict__ src, long lo, long n) {
+    const long i = lo + blockIdx.x * (long)blockDim.x + threadIdx.x;
+    if (i < n) dst[i] += src[i];
+}
+
+DDL_API void ddl_add_f32(float* dst, const float* src, long n, hipStream_t s) {
+    const long n4 = (((uintptr_t)dst | (uintptr_t)src) & 15) ? 0 : n / 4;
+    if (n4 > 0) {
+        long g = (n4 + 255) / 256;
+        add_f32_kernel<<<(int)(g > 2048 ? 2048 : g), 256, 0, s>>>((float4*)dst, (const float4*)src, n4);
+    }
+    const long rest = n - n4 * 4;
+    if (rest > 0) add_f32_tail_kernel<<<(int)((rest + 255) / 256), 256, 0, s>>>(dst, src, n4 * 4, n);
+}
+
+DDL_API int ddl_zero_bytes(void* dst, long bytes, hipStream_t s) {
+    return hipMemsetAsync(dst, 0, (size_t)bytes, s) == hipSuccess ? 0 : -1;
+}
+
 // ------------------------------------------------------------------------------ Philox noise
 // Philox4x32-10, counter = (element group index, stream offset), key = seed.  The 64-bit offset
 // lives in device memory (state[1]) and is advanced by a 1-thread kernel after each draw, so a

@@ -116,35 +116,53 @@ def main(argv=None):
             reference_exact=cfg.reference_exact, size=cfg.size, data=data.source, device=str(dev))
     step = None
     i = start
-    if dev.type == "cuda" and a.graph == "on":
-        # the graph's warm-up launches are real training steps: they count as iterations
-        warm = min(3, max(cfg.iterations - start, 0))
-        step = GraphedGANStep(trainer, real_p, warmup=warm)
+    remaining = max(cfg.iterations - start, 0)
+    full = False
+    if dp is not None and dev.type == "cuda" and remaining > 0:
+        # kernel plans tuned without collectives and shared by all ranks, then: may the collectives be captured into
+        # the step graph (gradient buckets under the backward pass need that)?  Agreed across ranks.
+        from ..parallel import dp_tune, selfcheck
+        dp_tune.pretune_gan(trainer, real_p)
+        full = selfcheck.captured_collective_ok(dp, dev)
+    first = None                    # losses of the first executed iteration, logged as the reference does at i == 0
+    if dev.type == "cuda" and a.graph == "on" and remaining > 0:
+        # the graph's warm-up launches are real training steps: they count as iterations (nothing is captured when no
+        # iteration remains: a capture without warm-up would record autotuning launches)
+        warm = min(3, remaining)
+        step = GraphedGANStep(trainer, real_p, warmup=warm, capture_collectives=full)
+        first = (trainer.d_loss, trainer.g_loss, i + warm - 1)
         i += warm
     meter = trace.StepMeter(images_per_step=cfg.train_images * world)
+
+    def report(it, d_loss, g_loss):
+        """GAN_distributed.py:137-142: losses, iteration, sample JPEGs (+ diagnostics the reference lacks)."""
+        with trace.range("gan_log"):
+            trainer.sync_bn_stats()
+            n_s = max(cfg.sample_images, 32)
+            imgs = trainer.generate(n_s)
+            if rank == 0:
+                print("generator loss : ", float(g_loss))              # GAN_distributed.py:138-140
+                print("discriminator loss : ", float(d_loss))
+                print(it, f"({meter.images_per_sec():.0f} images/s)", flush=True)
+                if log.enabled:
+                    diag = trainer.diagnose(real_p)
+                    log.log(event="eval", iteration=it, d_loss=float(d_loss), g_loss=float(g_loss),
+                            nn_distance=nn_distance(imgs, real), images_per_sec=meter.images_per_sec(), **diag)
+                out = imgs.cpu().numpy() * 255.0
+                for k in range(cfg.sample_images):
+                    image.save_img(os.path.join(cfg.image_directory, f"{k}.jpg"), out[k])
+                if a.sample_grid:
+                    save_grid(a.sample_grid, imgs[:32])
+
+    if first is not None and start == 0:        # the reference prints and samples at iteration 0
+        report(first[2], first[0], first[1])
     while i < cfg.iterations:
         with meter, trace.range("gan_step"):
             d_loss, g_loss = step.step() if step is not None else trainer.train_step(real_p, prepared=True)
-        if a.log_every and i % a.log_every == 0:
+        if log.enabled and a.log_every and i % a.log_every == 0:    # float() is a host sync: only when somebody reads it
             log.log(event="loss", iteration=i, d_loss=float(d_loss), g_loss=float(g_loss))
         if i % cfg.log_period == 0 or i == cfg.iterations - 1:
-            with trace.range("gan_log"):
-                trainer.sync_bn_stats()
-                n_s = max(cfg.sample_images, 32)
-                imgs = trainer.generate(n_s)
-                if rank == 0:
-                    print("generator loss : ", float(g_loss))              # GAN_distributed.py:138-140
-                    print("discriminator loss : ", float(d_loss))
-                    print(i, f"({meter.images_per_sec():.0f} images/s)", flush=True)
-                    diag = trainer.diagnose(real_p)
-                    score = nn_distance(imgs, real)
-                    log.log(event="eval", iteration=i, d_loss=float(d_loss), g_loss=float(g_loss), nn_distance=score,
-                            images_per_sec=meter.images_per_sec(), **diag)
-                    out = imgs.cpu().numpy() * 255.0
-                    for k in range(cfg.sample_images):
-                        image.save_img(os.path.join(cfg.image_directory, f"{k}.jpg"), out[k])
-                    if a.sample_grid:
-                        save_grid(a.sample_grid, imgs[:32])
+            report(i, d_loss, g_loss)
         i += 1
         if a.checkpoint and a.checkpoint_every and i % a.checkpoint_every == 0:
             trainer.save_checkpoint(a.checkpoint, i, write=rank == 0)

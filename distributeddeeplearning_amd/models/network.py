@@ -228,12 +228,16 @@ class ConvOp(Op):
         if gk.untyped_storage().data_ptr() != gb.untyped_storage().data_ptr() or not gk.is_contiguous():
             return None
         off = gb.storage_offset() - gk.storage_offset()
-        if off < gk.numel() or off - gk.numel() > 4096 or gb.numel() != (self.g.O if nbias is None else nbias):
+        # the launch zero-fills whatever lies between the kernel and the bias gradient: that may only ever be the flat
+        # buffer's alignment padding (< ALIGN elements), never another parameter's gradient
+        if gk.dtype != torch.float32 or gb.dtype != torch.float32:
+            return None
+        if off < gk.numel() or off - gk.numel() >= ALIGN or gb.numel() != (self.g.O if nbias is None else nbias):
             return None
         # every parameter starts at a multiple of ALIGN elements: what follows the bias up to the next multiple of 4 is
         # alignment padding of the flat buffer (it receives zeros; the wide slab reduce wants float4 columns)
         total = _round_up(off + gb.numel(), 4)
-        if ALIGN % 4 or gk.storage_offset() + total > gk.untyped_storage().nbytes() // 4:
+        if ALIGN % 4 or gk.storage_offset() + total > gk.untyped_storage().nbytes() // gk.element_size():
             return None
         return off, torch.as_strided(gk, (total,), (1,))
 

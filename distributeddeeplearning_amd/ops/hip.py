@@ -68,6 +68,8 @@ _argmax_match = _sig("ddl_argmax_match", None, vp, vp, ci, ci, vp, vp)
 _optim_step = _sig("ddl_optim_step", None, vp, vp, vp, vp, vp, vp, cl, ci, cf, cf, cf, cf, cf, cf, vp, cf, vp)
 _step_inc = _sig("ddl_step_inc", None, vp, vp)
 _scale_emit = _sig("ddl_scale_emit", None, vp, vp, cl, cf, vp)
+_add_f32 = _sig("ddl_add_f32", None, vp, vp, cl, vp)
+_zero_bytes = _sig("ddl_zero_bytes", ci, vp, cl, vp)
 _avg_delta = _sig("ddl_avg_delta", None, vp, vp, vp, vp, cl, cf, vp)
 _im2col = _sig("ddl_im2col_1ch", ci, vp, vp, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, vp)
 _col2im = _sig("ddl_col2im_1ch", ci, vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, cf, vp, ci,
@@ -851,6 +853,25 @@ def optimizer_step_flat(P, G, m, v, Pc, step_dev, c, grad_scale=1.0):
     _optim_step(P.data_ptr(), G.data_ptr(), _p(m), _p(v), _p(Pc), step_dev.data_ptr(), n, _OPT_KIND[c.kind],
                 c.lr, c.beta1, c.beta2, c.eps, c.rho, grad_scale, None, 0.0, _stream())
     _done()
+
+
+def add_f32_(dst, src):
+    """dst += src (flat fp32, same size)."""
+    n = dst.numel()
+    _chk_f32(dst, n, "dst")
+    _chk_f32(src, n, "src")
+    _add_f32(dst.data_ptr(), src.data_ptr(), n, _stream())
+    _done()
+    return dst
+
+
+def zero_(t):
+    """t = 0 for a contiguous device tensor (hipMemsetAsync on the current stream; capturable)."""
+    if not (t.is_cuda and t.is_contiguous()):
+        return t.zero_()
+    if _zero_bytes(t.data_ptr(), t.numel() * t.element_size(), _stream()) != 0:
+        raise RuntimeError("hipMemsetAsync failed")
+    return t
 
 
 def scale_emit(P, Pc, scale):
@@ -1691,8 +1712,11 @@ def conv_wgrad(x, dy, g: ConvGeom, layout="A", out=None, box=None, x_affine=None
             if total is None:
                 total = conv_wgrad(x[b0:b1], dy[b0:b1], g, layout, out, box, x_affine, slab_holder, bias_tail)
             else:
-                total.add_(conv_wgrad(x[b0:b1], dy[b0:b1], g, layout, torch.empty_like(total) if box is None
-                                      else torch.zeros_like(total), box, x_affine, slab_holder, bias_tail))
+                part = torch.empty_like(total)
+                if box is not None:
+                    zero_(part)
+                add_f32_(total.reshape(-1), conv_wgrad(x[b0:b1], dy[b0:b1], g, layout, part, box, x_affine,
+                                                       slab_holder, bias_tail).reshape(-1))
         return total
     dev = x.device
     T = g.KH * g.KW
@@ -1764,7 +1788,7 @@ def conv_wgrad(x, dy, g: ConvGeom, layout="A", out=None, box=None, x_affine=None
             per = _wgrad2_frag_elems(pl["TN"], pl["TC"], pl["TPW"], pl["NW"], pl["ngroups"], n_lim, c_lim)
             slab = torch.empty(ns * per, dtype=torch.float32, device=dev)
             if box is not None:
-                out.zero_()
+                zero_(out)
         else:
             slab = (torch.zeros if box is not None else torch.empty)(ns * numel, dtype=torch.float32, device=dev)
         rc = _wgrad2(dy.data_ptr(), x.data_ptr(), slab.data_ptr(), numel, ns, B, g.OH, g.OW, Op, g.H, g.W, Ip,

@@ -88,6 +88,10 @@ class JsonlLogger:
     def __init__(self, path: Optional[str]):
         self.f = open(path, "a") if path else None
 
+    @property
+    def enabled(self) -> bool:
+        return self.f is not None
+
     def log(self, **kv):
         if self.f:
             kv.setdefault("ts", time.time())
