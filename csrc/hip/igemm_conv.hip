@@ -355,8 +355,52 @@ __global__ __launch_bounds__(256) void igemm_conv_kernel_k32(const ConvArgs a) {
         wbase[r] = (nl < BN && n < a.Nw) ? n * a.Ttot * Cs : -1;
     }
 
+    // ---- uniform-tap gather (UT).  When a K stage never straddles two taps (Cs % 32 == 0) the tap of a stage is the
+    // same for every thread of the block: its table entry, the tap's byte offset and the position along the channel
+    // axis are SCALAR values (SALU, s_load), and what is left per gathered row is one add and a validity bit out of a
+    // per-row mask built once (bit = position of the tap's (offh, offw) inside the class's offset box, host-packed
+    // into ClassDesc::pad and the tap's fourth word).  The generic gather below spends ~12 vector instructions per
+    // row and stage -- two of them 64-bit multiply-adds -- against 8-16 MFMAs per wave: these kernels were bound by
+    // address arithmetic, not by the matrix pipe or by memory.
+    const bool ut = cd.pad != 0 && (Cs & 31) == 0;
+    unsigned vmask[RA], rowoff[RA], wrow[RW];
+    int ut_tap = 0, ut_c = 0;
+    if (ut) {
+        const int minh = ((cd.pad >> 1) & 127) - 64, minw = ((cd.pad >> 8) & 127) - 64;
+        const int rw = (cd.pad >> 15) & 63, rh = (cd.pad >> 21) & 63;
+#pragma unroll
+        for (int r = 0; r < RA; ++r) {
+            unsigned wm = 0, m2 = 0;
+            for (int wb = 0; wb < rw; ++wb) wm |= ((unsigned)(aiw[r] + minw + wb) < (unsigned)a.Ws ? 1u : 0u) << wb;
+            for (int hb = 0; hb < rh; ++hb)
+                m2 |= ((unsigned)(aih[r] + minh + hb) < (unsigned)a.Hs ? wm : 0u) << (hb * rw);
+            vmask[r] = m2;                        // rows beyond M have aih = -2^24: no bit set
+            rowoff[r] = (unsigned)(abase[r] + (aih[r] * a.Ws + aiw[r]) * Cs + q * 8) * 2u;
+        }
+#pragma unroll
+        for (int r = 0; r < RW; ++r) wrow[r] = wbase[r] >= 0 ? (unsigned)(wbase[r] + q * 8) * 2u : 0xF0000000u;
+        ut_tap = (s_begin * 32) / Cs;
+        ut_c = s_begin * 32 - ut_tap * Cs;
+    }
+    const int4* __restrict__ gtaps = a.taps + cd.tap_off;
+
     u32x4 regA[RA], regW[RW];
     auto gload = [&]() {
+        if (ut) {
+            const bool tv = ut_tap < cd.ntaps;
+            const int4 te = gtaps[min(ut_tap, last_tap)];                 // uniform address: a scalar load
+            const unsigned soffA = (unsigned)(((te.x * a.Ws + te.y) * Cs + ut_c) * 2);
+            const unsigned soffW = (unsigned)((te.z * Cs + ut_c) * 2);
+#pragma unroll
+            for (int r = 0; r < RA; ++r) {
+                const bool ok = tv & (((vmask[r] >> te.w) & 1u) != 0u);
+                regA[r] = __builtin_amdgcn_raw_buffer_load_b128(rsA, ok ? rowoff[r] + soffA : 0xFFFFFFF0u, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < RW; ++r)
+                regW[r] = __builtin_amdgcn_raw_buffer_load_b128(rsW, tv ? wrow[r] + soffW : 0xFFFFFFF0u, 0, 0);
+            return;
+        }
         const bool tv = tap < cd.ntaps;
         const int4 te = sT[min(tap, last_tap)];
 #pragma unroll
@@ -382,6 +426,11 @@ __global__ __launch_bounds__(256) void igemm_conv_kernel_k32(const ConvArgs a) {
             if (r0 + 64 * r < BN) *(u32x4*)(sW + (buf * BN + r0 + 64 * r) * PITCH1 + qsw) = regW[r];
     };
     auto advance = [&]() {
+        if (ut) {
+            ut_c += 32;
+            if (ut_c >= Cs) { ut_c = 0; ++ut_tap; }
+            return;
+        }
         c += 32;
         while (c >= Cs) { c -= Cs; ++tap; }
     };

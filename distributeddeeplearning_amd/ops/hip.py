@@ -933,6 +933,9 @@ def _class_taps(g: ConvGeom, mode: str):
     return classes, taps
 
 
+IGEMM_UT = os.environ.get("DDL_IGEMM_UT", "1") == "1"      # uniform-tap gather in the implicit-GEMM kernels
+
+
 def _tables(g: ConvGeom, mode: str, B: int, device):
     """Class descriptors + tap tables for the implicit-GEMM kernel (see igemm_conv.hip)."""
     key = (g, mode, B, str(device))
@@ -940,8 +943,21 @@ def _tables(g: ConvGeom, mode: str, B: int, device):
     if hit is not None:
         return hit
     cl_, tp_ = _class_taps(g, mode)
-    classes = [(c[0], c[1], c[2], c[3], c[4], c[5], B * c[2] * c[3], 0) for c in cl_]
-    taps = [(t[0], t[1], t[2], 0) for t in tp_] or [(0, 0, 0, 0)]
+    # uniform-tap gather (igemm_conv.hip): per class the box of its taps' (offh, offw); when the box has at most 32
+    # cells every gathered row keeps one validity bit per cell, and a tap's fourth word is its cell
+    classes, taps = [], [(t[0], t[1], t[2], 0) for t in tp_] or [(0, 0, 0, 0)]
+    for c in cl_:
+        pad = 0
+        tl = tp_[c[5]:c[5] + c[4]]
+        if tl and IGEMM_UT:
+            minh, minw = min(t[0] for t in tl), min(t[1] for t in tl)
+            rh, rw = max(t[0] for t in tl) - minh + 1, max(t[1] for t in tl) - minw + 1
+            if rh * rw <= 32 and -64 <= minh < 64 and -64 <= minw < 64:
+                pad = 1 | (minh + 64) << 1 | (minw + 64) << 8 | rw << 15 | rh << 21
+                for k in range(c[5], c[5] + c[4]):
+                    t = tp_[k]
+                    taps[k] = (t[0], t[1], t[2], (t[0] - minh) * rw + (t[1] - minw))
+        classes.append((c[0], c[1], c[2], c[3], c[4], c[5], B * c[2] * c[3], pad))
     ct = torch.tensor(classes, dtype=torch.int32).to(device)
     tt = torch.tensor(taps, dtype=torch.int32).to(device)
     res = (ct, tt, len(classes), max(c[6] for c in classes), max(max(c[4] for c in classes), 1))
