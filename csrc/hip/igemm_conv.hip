@@ -551,6 +551,240 @@ __global__ __launch_bounds__(256) void igemm_conv_kernel_k32(const ConvArgs a) {
     }
 }
 
+// ---- the LDS-DMA variant, for problems large enough to be bound by the staging path rather than by latency.
+// The register-staged kernels above push every operand byte through VGPRs and a ds_write_b128, and the wide LDS
+// store is the slowest LDS instruction there is (13 cycles per wave-instruction, ~79 B/clk per CU against 256 B/clk
+// for ds_read_b128): for a 128 x 128 x 32 stage that is 16 stores = 208 LDS cycles beside 128 cycles of fragment
+// reads and 256 MFMA cycles per SIMD -- the stores, not the matrix pipe, bounded the big layers at ~650 TFLOP/s.
+// Here each wave fills its share of the stage with `buffer_load_dwordx4 ... lds`: the loaded bytes go straight into
+// LDS (wave-uniform base + 16 B x lane), no VGPR and no LDS store instruction.  Consequences for the layout:
+//   * one wave-instruction writes 1 KiB = 16 rows x 64 B linearly, so the XOR swizzle of the 16-byte slots is applied
+//     on the SOURCE side: the lane that lands in (row, slot) fetches k-group  slot ^ ((-(row >> 2)) & 3)  of that row
+//     (the same involution the fragment reads apply);
+//   * padding pixels, rows beyond M and channels beyond Nw fetch an out-of-range buffer offset, which writes zeros;
+//   * the tap of a K stage must be uniform over the block (uniform-tap tables, Cs % 32 == 0): the per-stage vector
+//     work is one mask test, one select and one add per 16-row piece.
+// A ring of STAGES LDS buffers keeps STAGES - 1 stages of DMA in flight across ONE raw s_barrier per K step, retired
+// by a counted s_waitcnt vmcnt (a __syncthreads() would drain the whole queue at every step).
+// Blocks are numbered so that the channel tiles of one pixel tile run back to back on the same XCD (its L2 then
+// serves the second gather of the same pixels): id = blockIdx.x, xcd = id % 8, k = id / 8,
+// (n tile, m tile) = (k % n_ntiles, (k / n_ntiles) * 8 + xcd).
+template <int NT, int MT>
+__device__ __forceinline__ void igemm_epilogue(const ConvArgs& a, const ClassDesc& cd, f32x4 (&acc)[NT][MT],
+                                               int mb, int nb0, int lane) {
+    const int fr = lane & 15, fq = lane >> 4;
+    const int HW = cd.Hc * cd.Wc;
+    const bool vec_ok = (a.Nd & 3) == 0;
+    const bool mul = a.mul_y && vec_ok;
+    constexpr int JG = NT >= 8 ? 2 : 4;         // pixel tiles per group
+    // ONE activation dispatch around the whole epilogue (a run-time switch per element is a chain of scalar branches
+    // per element, common.h); inside it a few pixel tiles at a time, so that a 128-accumulator wave tile never holds
+    // a second copy of itself: the y loads of the group first (one round trip), then activation, multiply, store
+    act_switch(a.act, [&](auto KA) {
+        float bias_[NT][4];
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int n = nb0 + 16 * t + 4 * fq + e;
+                bias_[t][e] = (n < a.Nw && a.bias) ? a.bias[n] : 0.f;
+            }
+#pragma unroll
+        for (int j0 = 0; j0 < MT; j0 += JG) {
+            long pixs[JG];
+            uint2 yv[NT][JG];
+#pragma unroll
+            for (int jj = 0; jj < JG; ++jj) {
+                const int m = mb + 16 * (j0 + jj) + fr;
+                const int mm = m < cd.M ? m : 0;
+                const int b = mm / HW, rem = mm - b * HW;
+                const int i = rem / cd.Wc, w = rem - i * cd.Wc;
+                pixs[jj] = ((long)b * a.Hd + cd.ph + (long)a.sdh * i) * a.Wd + cd.pw + (long)a.sdw * w;
+                if (mul) {
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) {
+                        const int nb = nb0 + 16 * t + 4 * fq;
+                        yv[t][jj] = (m < cd.M && nb < a.Nd) ? *(const uint2*)(a.mul_y + pixs[jj] * a.Nd + nb)
+                                                            : make_uint2(0, 0);
+                    }
+                }
+            }
+#pragma unroll
+            for (int jj = 0; jj < JG; ++jj) {
+                const int j = j0 + jj;
+                const int m = mb + 16 * j + fr;
+                if (m >= cd.M) continue;
+                bf16_t* drow = a.dst + pixs[jj] * a.Nd;
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    const int nb = nb0 + 16 * t + 4 * fq;
+                    if (nb >= a.Nd) continue;
+                    float v[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)             // channels beyond the weight rows are zero
+                        v[e] = nb + e < a.Nw ? act_apply_k<decltype(KA)::value>(acc[t][j][e] + bias_[t][e], a.act, a.alpha)
+                                             : 0.f;
+                    if (mul) {
+                        const float y4[4] = {__uint_as_float(yv[t][jj].x << 16), __uint_as_float(yv[t][jj].x & 0xffff0000u),
+                                             __uint_as_float(yv[t][jj].y << 16), __uint_as_float(yv[t][jj].y & 0xffff0000u)};
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = bf2f(f2bf(v[e])) * (y4[e] > 0.f ? 1.f : a.mul_slope);
+                    }
+                    if (vec_ok) {
+                        *(uint2*)(drow + nb) = make_uint2(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]));
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            if (nb + e < a.Nd) drow[nb + e] = f2bf(v[e]);
+                    }
+                }
+            }
+        }
+    });
+}
+
+typedef __attribute__((address_space(3))) void lds_void;
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(4))) const i32x4 const_i32x4;
+
+// accumulator registers per lane -> resident waves per SIMD asked of the register allocator (512 / 3 = 168 VGPRs
+// hold a 64 x 64 wave tile's 64 accumulators + 32 fragment registers; 128 accumulators get 256)
+constexpr int dma_min_waves(int acc_regs) { return acc_regs <= 64 ? 3 : 2; }
+
+template <int BM, int BN, int WAVES_M, int STAGES>
+__global__ __launch_bounds__(256, dma_min_waves((BM / WAVES_M) * (BN / (4 / WAVES_M)) / 64))
+void igemm_conv_kernel_dma(const ConvArgs a, const int n_ntiles) {
+    constexpr int WAVES_N = 4 / WAVES_M;
+    constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;      // pixels x channels per wave
+    constexpr int MT = WM / 16, NT = WN / 16;
+    constexpr int BNL = BN < 64 ? 64 : BN;                   // weight rows in LDS: every wave fills whole pieces
+    constexpr int PA = BM / 64, PW = BNL / 64;               // 16-row pieces per wave and stage
+    constexpr int P = PA + PW;
+    static_assert(WM % 64 == 0 && WN % 16 == 0 && BM % 64 == 0 && STAGES >= 2 && STAGES <= 4, "bad tile");
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* sA = smem;                                   // [STAGES][BM][64 B]
+    char* sW = smem + STAGES * BM * PITCH1;            // [STAGES][BNL][64 B]
+
+    const ClassDesc cd = a.classes[blockIdx.y];
+    const int xcd = blockIdx.x & 7, kblk = blockIdx.x >> 3;
+    const int n_tile = kblk % n_ntiles, m_tile = (kblk / n_ntiles) * 8 + xcd;
+    const int m0 = m_tile * BM;
+    if (m0 >= cd.M) return;
+    const int n0 = n_tile * BN;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave % WAVES_M, wn = wave / WAVES_M;
+
+    // ---- staging assignment: wave w fills pieces w*PA .. of A and w*PW .. of W; lane l lands in row l/4, slot l%4
+    const int prow = lane >> 2;
+    const int q = (lane & 3) ^ ((-(lane >> 4)) & 3);          // k-group fetched into this lane's slot
+    const int HW = cd.Hc * cd.Wc;
+    const int Cs = a.Cs;
+    const int minh = ((cd.pad >> 1) & 127) - 64, minw = ((cd.pad >> 8) & 127) - 64;
+    const int rw = (cd.pad >> 15) & 63, rh = (cd.pad >> 21) & 63;
+    unsigned vmask[PA], rowoff[PA], wrow[PW];
+#pragma unroll
+    for (int r = 0; r < PA; ++r) {
+        const int m = m0 + (wave * PA + r) * 16 + prow;
+        const bool v = m < cd.M;
+        const int mm = v ? m : 0;
+        const int b = mm / HW, rem = mm - b * HW;
+        const int i = rem / cd.Wc, j = rem - i * cd.Wc;
+        const int ih = v ? i * a.ssh : -(1 << 24), iw = j * a.ssw;
+        unsigned wmk = 0, m2 = 0;
+        for (int wb = 0; wb < rw; ++wb) wmk |= ((unsigned)(iw + minw + wb) < (unsigned)a.Ws ? 1u : 0u) << wb;
+        for (int hb = 0; hb < rh; ++hb) m2 |= ((unsigned)(ih + minh + hb) < (unsigned)a.Hs ? wmk : 0u) << (hb * rw);
+        vmask[r] = m2;
+        rowoff[r] = (unsigned)(b * a.Hs * a.Ws * Cs + (ih * a.Ws + iw) * Cs + q * 8) * 2u;
+    }
+#pragma unroll
+    for (int r = 0; r < PW; ++r) {
+        const int nl = (wave * PW + r) * 16 + prow, n = n0 + nl;
+        wrow[r] = (nl < BN && n < a.Nw) ? (unsigned)(n * a.Ttot * Cs + q * 8) * 2u : 0xF0000000u;
+    }
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)a.src, 0, (int)((unsigned)a.B * a.Hs * a.Ws * Cs * 2u), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)a.wgt, 0, (int)((unsigned)a.Nw * a.Ttot * Cs * 2u), 0x00020000);
+
+    // the tap table is read through the constant address space: beside the LDS-DMA (which the compiler treats as a
+    // store to unknown memory) an ordinary load of it is not provably invariant, becomes a VECTOR load and drags a
+    // vmcnt(0) into every K step
+    const_i32x4* gtaps = (const_i32x4*)(unsigned long)(a.taps + cd.tap_off);
+    const int last_tap = max(cd.ntaps - 1, 0);
+    const int nsteps = cd.ntaps * (Cs >> 5);
+    int ut_tap = 0, ut_c = 0;
+    i32x4 te = gtaps[0];             // uniform address: scalar loads (the table ends with a spare entry)
+    auto issue = [&](int buf) {
+        const bool tv = ut_tap < cd.ntaps;
+        const unsigned soffA = (unsigned)(((te.x * a.Ws + te.y) * Cs + ut_c) * 2);
+        const unsigned soffW = (unsigned)((te.z * Cs + ut_c) * 2);
+        const unsigned bit = tv ? 1u << te.w : 0u;
+#pragma unroll
+        for (int r = 0; r < PA; ++r) {
+            const unsigned off = (vmask[r] & bit) ? rowoff[r] + soffA : 0xFFFFFFF0u;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(
+                rsA, (lds_void*)(sA + ((buf * BM + (wave * PA + r) * 16) * PITCH1)), 16, off, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < PW; ++r) {
+            const unsigned off = tv ? wrow[r] + soffW : 0xFFFFFFF0u;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(
+                rsW, (lds_void*)(sW + ((buf * BNL + (wave * PW + r) * 16) * PITCH1)), 16, off, 0, 0, 0);
+        }
+        ut_c += 32;
+        if (ut_c >= Cs) {
+            ut_c = 0;
+            ++ut_tap;
+            te = gtaps[min(ut_tap, last_tap)];
+        }
+    };
+
+    f32x4 acc[NT][MT];
+#pragma unroll
+    for (int i = 0; i < NT; ++i)
+#pragma unroll
+        for (int j = 0; j < MT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    // prologue: STAGES - 1 stages in flight (stages beyond the reduction fetch zeros: the counts below stay uniform)
+#pragma unroll
+    for (int d = 0; d < STAGES - 1; ++d) issue(d);
+
+    const int fr = lane & 15, fq = lane >> 4;
+    const int fqsw = (fq ^ ((-(fr >> 2)) & 3)) * 16;
+    int cur = 0;
+    for (int s = 0; s < nsteps; ++s) {
+        // stage s has landed once at most (STAGES - 2) younger stages of this wave are still in flight; the barrier
+        // makes every wave's share visible and retires the reads of the buffer refilled below
+        asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"((STAGES - 2) * P) : "memory");
+        {
+            int nb = cur + STAGES - 1;
+            if (nb >= STAGES) nb -= STAGES;
+            issue(nb);
+        }
+        bf16x8_t wf[NT], xf[MT];
+#pragma unroll
+        for (int i = 0; i < NT; ++i)
+            wf[i] = *(const bf16x8_t*)(sW + (cur * BNL + wn * WN + 16 * i + fr) * PITCH1 + fqsw);
+#pragma unroll
+        for (int j = 0; j < MT; ++j)
+            xf[j] = *(const bf16x8_t*)(sA + (cur * BM + wm * WM + 16 * j + fr) * PITCH1 + fqsw);
+        // all fragment reads in flight before the first MFMA (left alone the scheduler reuses one weight register
+        // quad and serialises a read's latency with every group of MT MFMAs)
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < MT; ++j)
+#pragma unroll
+            for (int i = 0; i < NT; ++i)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], xf[j], acc[i][j], 0, 0, 0);
+        if (++cur == STAGES) cur = 0;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // trailing zero-fill stages: nothing may land after exit
+
+    igemm_epilogue<NT, MT>(a, cd, acc, m0 + wm * WM, n0 + wn * WN, lane);
+}
+
 // out[m][n] = act(bias[n] + sum_s slab[s][m][n]) for the split-K path (dst pixel index == m: single class, unit stride)
 __global__ void splitk_finish_kernel(const float* __restrict__ slab, const float* __restrict__ bias,
                                      bf16_t* __restrict__ dst, long MN, int Nd, int Nw, int ksplit, int act, float alpha) {
@@ -592,6 +826,27 @@ static int launch_igemm(const ConvArgs& a, int n_classes, int max_M, hipStream_t
         splitk_finish_kernel<<<(int)(g > 2048 ? 2048 : g), 256, 0, s>>>(a.slab, a.bias, a.dst, MN, a.Nd, a.Nw, a.ksplit,
                                                                     a.act, a.alpha);
     }
+    return 0;
+}
+
+template <int BM, int BN, int WAVES_M, int STAGES>
+static int launch_igemm_dma(const ConvArgs& a, int n_classes, int max_M, hipStream_t s) {
+    // needs the uniform-tap tables (every class descriptor carries its offset box: the caller vouches for that),
+    // whole 32-channel K stages and no split-K
+    if (a.ksplit > 1 || (a.Cs & 31)) return -6;
+    constexpr int BNL = BN < 64 ? 64 : BN;
+    const size_t smem = (size_t)STAGES * (BM + BNL) * PITCH1;
+    auto kern = igemm_conv_kernel_dma<BM, BN, WAVES_M, STAGES>;
+    if (smem > 64 * 1024) {
+        static bool done = false;
+        if (!done) {
+            hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            done = true;
+        }
+    }
+    const int mt = (max_M + BM - 1) / BM, nt = (a.Nd + BN - 1) / BN;
+    dim3 grid((unsigned)((mt + 7) / 8 * 8 * nt), n_classes, 1);
+    kern<<<grid, 256, smem, s>>>(a, nt);
     return 0;
 }
 
@@ -644,6 +899,16 @@ DDL_API int ddl_igemm_conv(const void* src, const void* wgt, const float* bias, 
         case 21: return launch_igemm<256, 64, false>(a, n_classes, max_M, s);
         case 22: return launch_igemm<128, 128, false>(a, n_classes, max_M, s);
         case 24: return launch_igemm<64, 128, false>(a, n_classes, max_M, s);
+        // 32 + : LDS-DMA staging (uniform-tap tables required)
+        case 33: return launch_igemm_dma<128, 128, 2, 3>(a, n_classes, max_M, s);   // wave tile 64 x 64
+        case 34: return launch_igemm_dma<256, 128, 2, 3>(a, n_classes, max_M, s);   // 128 x 64
+        case 35: return launch_igemm_dma<128, 64, 2, 3>(a, n_classes, max_M, s);    // 64 x 32
+        case 36: return launch_igemm_dma<256, 64, 4, 3>(a, n_classes, max_M, s);    // 64 x 64
+        case 37: return launch_igemm_dma<256, 64, 2, 3>(a, n_classes, max_M, s);    // 128 x 32
+        case 38: return launch_igemm_dma<128, 256, 2, 3>(a, n_classes, max_M, s);   // 64 x 128
+        case 39: return launch_igemm_dma<256, 32, 4, 3>(a, n_classes, max_M, s);    // 64 x 32
+        case 40: return launch_igemm_dma<128, 128, 2, 4>(a, n_classes, max_M, s);
+        case 41: return launch_igemm_dma<256, 128, 2, 4>(a, n_classes, max_M, s);
         default: return -4;
     }
 }

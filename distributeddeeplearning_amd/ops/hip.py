@@ -959,8 +959,9 @@ def _tables(g: ConvGeom, mode: str, B: int, device):
                     taps[k] = (t[0], t[1], t[2], (t[0] - minh) * rw + (t[1] - minw))
         classes.append((c[0], c[1], c[2], c[3], c[4], c[5], B * c[2] * c[3], pad))
     ct = torch.tensor(classes, dtype=torch.int32).to(device)
-    tt = torch.tensor(taps, dtype=torch.int32).to(device)
-    res = (ct, tt, len(classes), max(c[6] for c in classes), max(max(c[4] for c in classes), 1))
+    tt = torch.tensor(taps + [(0, 0, 0, 0)], dtype=torch.int32).to(device)   # spare entry: a tap-less class reads it
+    res = (ct, tt, len(classes), max(c[6] for c in classes), max(max(c[4] for c in classes), 1),
+           all(c[7] != 0 or c[4] == 0 for c in classes))
     _TAB_CACHE[key] = res
     return res
 
@@ -1248,27 +1249,30 @@ def _mul_slope(mul, dst):
 
 def _run_igemm(src, wgt, bias, dst, g, mode, B, Hs, Ws, Cs, Hd, Wd, Nd, Nw, ss, sd, act, alpha, tile=None, mul=None):
     """`mul` = (y, act, alpha): result *= act'(y) -- in the kernel's epilogue for linear / relu / leaky, else as a pass."""
-    ct, tt, ncls, maxM, maxT = _tables(g, mode, B, src.device)
+    ct, tt, ncls, maxM, maxT, ut_all = _tables(g, mode, B, src.device)
+    tile = IGEMM_TILE if tile is None else tile
+    if tile >= 32 and not (ut_all and Cs % 32 == 0):
+        raise ValueError(f"igemm tile {tile} (LDS-DMA staging) needs uniform-tap tables and Cs % 32 == 0: {g} Cs={Cs}")
     # split-K: a Dense / 1x1 fprop with few output tiles and a very long reduction (model0's 86528 -> 10
     # head at batch 512 is TWO 256-row blocks walking 2704 k-steps each) is spread over the K axis
     ksplit, slab = 1, None
     if mode == "fprop" and ncls == 1 and _is_1x1(g):
         nsteps = (g.KH * g.KW * Cs + 63) // 64
         blocks = -(-maxM // 256) * -(-Nd // 128)
-        if blocks < 128 and nsteps >= 32:
+        if blocks < 128 and nsteps >= 32 and tile < 32:
             ksplit = max(1, min(nsteps // 8, 512 // blocks))
             if ksplit > 1:
                 slab = torch.empty(ksplit * maxM * Nd, dtype=torch.float32, device=src.device)
     _ms = _mul_slope(mul, dst) if ACT_CODE[act] in (0, 1, 6) else None
     rc = _igemm(src.data_ptr(), wgt.data_ptr(), _p(bias), dst.data_ptr(), ct.data_ptr(), tt.data_ptr(), ncls,
                 maxM, maxT, B, Hs, Ws, Cs, Hd, Wd, Nd, Nw, ss[0], ss[1], sd[0], sd[1], g.KH * g.KW,
-                ACT_CODE[act], alpha, IGEMM_TILE if tile is None else tile, ksplit if slab is not None else 1,
+                ACT_CODE[act], alpha, tile, ksplit if slab is not None else 1,
                 _p(slab), *( (None, 0.0) if _ms is None else _ms ), _stream())
     if rc == -5:                        # no fused multiply for this shape: plain launch, separate pass
         _ms = None
         rc = _igemm(src.data_ptr(), wgt.data_ptr(), _p(bias), dst.data_ptr(), ct.data_ptr(), tt.data_ptr(), ncls,
                     maxM, maxT, B, Hs, Ws, Cs, Hd, Wd, Nd, Nw, ss[0], ss[1], sd[0], sd[1], g.KH * g.KW,
-                    ACT_CODE[act], alpha, IGEMM_TILE if tile is None else tile, ksplit if slab is not None else 1,
+                    ACT_CODE[act], alpha, tile, ksplit if slab is not None else 1,
                     _p(slab), None, 0.0, _stream())
     if rc != 0:
         raise ValueError(f"igemm_conv rejected the problem (rc={rc}): {g} mode={mode} B={B}")
@@ -1321,6 +1325,27 @@ def _time_us(fn, reps=4, inner=4):
 PCONV_STATS = os.environ.get("DDL_PCONV_STATS", "1") == "1"
 
 
+IGEMM_DMA = os.environ.get("DDL_IGEMM_DMA", "1") == "1"
+IGEMM_DMA_MIN_ROWS = int(os.environ.get("DDL_IGEMM_DMA_MIN_ROWS", "65536"))
+
+
+def _dma_tiles(g, mode, B, Cs, Nd, device):
+    """LDS-DMA staged tile candidates (igemm_conv.hip, ids 32+): uniform-tap tables, whole 32-channel K stages, and a
+    problem large enough (rows x classes) that the staging path, not launch latency, is what bounds it."""
+    if not IGEMM_DMA or Cs % 32:
+        return []
+    _, _, ncls, maxM, _, ut_all = _tables(g, mode, B, device)
+    if not ut_all or maxM * ncls < IGEMM_DMA_MIN_ROWS:
+        return []
+    if Nd <= 32:
+        return [39]
+    if Nd <= 64:
+        return [35, 36, 37]
+    if Nd <= 128:
+        return [33, 34, 35, 40]
+    return [33, 34, 38, 40, 41]
+
+
 def _igemm_call(src, wgt, bias, dst, g, mode, B, Hs, Ws, Cs, Hd, Wd, Nd, Nw, ss, sd, act, alpha, mul=None,
                 stats_out=None, bn_infer=None, in_affine=None, aff_sink=None):
     """Dispatch one class-grid convolution: the patch-resident kernel with a tuned plan, or the
@@ -1359,6 +1384,7 @@ def _igemm_call(src, wgt, bias, dst, g, mode, B, Hs, Ws, Cs, Hd, Wd, Nd, Nw, ss,
             if 64 < Nd <= 256:
                 tiles += [2, 4]          # 64-wide N tiles over a z-grid: more, smaller blocks for short pixel dims
             tiles = tiles + [t + 16 for t in tiles]          # deep (64-wide, 3 stages in flight) and shallow variants
+            tiles += _dma_tiles(g, mode, B, Cs, Nd, src.device)
             cands = [("igemm", t) for t in tiles] + \
                     [("pconv", pl) for pl in _pconv_candidates(g, mode, B, Cs, Nd, ss, src.device)]
             timed = []

@@ -207,6 +207,48 @@ def test_dgrad_fused_act_grad_is_bit_identical_to_the_separate_pass(hip, impl, p
     close(outs[0].float().cpu(), ref, atol=1e-2)
 
 
+DMA_CASES = [
+    # H, W, I, O, k, s, padding          B
+    ((14, 14, 32, 64, (5, 5), (2, 2), "same"), 37),      # D3 shape: asymmetric `same` padding, rows beyond M
+    ((8, 8, 128, 256, (5, 5), (2, 2), "same"), 9),       # wide N: two channel tiles per pixel tile
+    ((9, 9, 64, 72, (3, 3), (1, 1), "same"), 5),         # N tail beyond the weight rows
+    ((6, 7, 32, 16, (3, 2), (1, 1), "valid"), 11),       # narrow N (weight pieces past BN fetch zeros)
+]
+
+
+@pytest.mark.parametrize("tile", [33, 34, 35, 36, 37, 38, 39, 40, 41])
+@pytest.mark.parametrize("case", DMA_CASES)
+def test_igemm_lds_dma_tiles(hip, case, tile, monkeypatch):
+    """The LDS-DMA staged implicit-GEMM variants (buffer_load ... lds: source-side swizzle, zero fill through
+    out-of-range offsets, counted vmcnt across one raw barrier per K step) against the register-staged kernel of the
+    same reduction order (bit for bit) and the fp32 oracle, for forward, data gradient (parity classes) and the fused
+    act'(y) epilogue."""
+    (H, W, I, O, k, s, pad), B = case
+    g = G.conv2d_geom(H, W, I, O, k, s, (1, 1), pad)
+    torch.manual_seed(7)
+    x = r16(torch.randn(B, H, W, I))
+    w = r16(torch.randn(O, k[0], k[1], I) / math.sqrt(k[0] * k[1] * I))
+    b = torch.randn(O)
+    dy = r16(torch.randn(B, g.OH, g.OW, O))
+    wB = padw(hip, w.permute(3, 1, 2, 0).contiguous())
+    monkeypatch.setattr(hip, "CONV_IMPL", "igemm")
+    monkeypatch.setattr(hip, "AUTOTUNE", False)
+    ypre = torch.randn(B, H, W, hip.pad8(I)).bfloat16().cuda()
+    outs = {}
+    for t in (22, tile):
+        monkeypatch.setattr(hip, "IGEMM_TILE", t)
+        y = hip.conv_fprop(dev(hip, x), padw(hip, w), b.cuda(), g, "leaky", 0.3)
+        outs[t] = [y]
+        if hip.pad8(O) % 32 == 0:           # the data gradient reduces over the output channels
+            dx = hip.conv_dgrad(dev(hip, dy), wB, g)
+            outs[t] += [dx, hip.conv_dgrad(dev(hip, dy), wB, g, mul=(ypre, "leaky", 0.2))]
+    close(host(hip, outs[tile][0], O), cpu_ref.conv_fprop(x, w, b, g, "leaky", 0.3))
+    if len(outs[tile]) > 1:
+        close(host(hip, outs[tile][1], I), cpu_ref.conv_dgrad(dy, w, g))
+    for a, r in zip(outs[tile], outs[22]):
+        assert torch.equal(a, r)
+
+
 CONVT_CASES = [
     # H, W, Cin, filters, k, s, d, padding, act   (layer view)
     (7, 7, 128, 64, (5, 5), (2, 2), (1, 1), "same", "relu"),         # G2
