@@ -24,7 +24,7 @@ struct TapFoldArgs {
     int mul_act; float mul_alpha;
     int B, H, W, OH, OW, C, KH, KW, sh, sw, dh, dw, pt, pl, T, act;
     float alpha;
-    int band_rows;
+    int band_rows, span_rows, ring_rows;     // rows per fold band, rows a block walks, z rows in the LDS ring
     // optional per-channel affine applied to x as it is loaded (the BatchNorm in front of this layer, never
     // materialised): x' = bf16(x * in_scale[grp][c] + in_shift[grp][c]), grp = (in_b_off + b) / in_group_rows
     const float* in_scale; const float* in_shift;
@@ -36,22 +36,26 @@ struct TapFoldArgs {
 
 __device__ __forceinline__ int tf_fdiv(int x, float inv) { return __float2int_rz(((float)x + 0.5f) * inv); }
 
+// A block owns (image, span of output rows) and WALKS the span in bands of `band_rows` rows: the z rows live in an
+// LDS ring of `ring_rows` rows (row oh in slot oh % ring_rows), each band computes only the z rows the previous one
+// did not leave behind, so every x pixel is read and multiplied ONCE per span.  (The first version gave every band
+// its own block: with a 5 x 5 stride-1 kernel and the 4-row bands a 64-wide image allows, each block recomputed a
+// 4-row halo -- x was read twice and the layer ran at 1.3 TB/s of useful traffic.)  The x fragments of the next
+// band are requested before the fold of the current one.
 template <int KS, int SH, int SW>
 __global__ __launch_bounds__(256) void tapfold_kernel(const TapFoldArgs a) {
     constexpr int KP = KS * 32, WP = TF_WP(KP);
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* sW = smem;                            // [32][WP]
-    char* sZ = smem + 32 * WP;                  // [npix16][TF_ZP]
+    char* sZ = smem + 32 * WP;                  // [ring_rows][OW][TF_ZP]
     const int sh = SH ? SH : a.sh, sw = SW ? SW : a.sw;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int fr = lane & 15, fq = lane >> 4;
     const int b = blockIdx.x;
-    const int h0 = blockIdx.y * a.band_rows, h1 = min(a.H, h0 + a.band_rows);
-    const int lo = h0 + a.pt - (a.KH - 1) * a.dh;
-    const int oh_lo = lo <= 0 ? 0 : (lo + sh - 1) / sh;
-    const int oh_hi = min(a.OH - 1, (h1 - 1 + a.pt) / sh);
-    const int nrows = oh_hi - oh_lo + 1;
-    const int npix = nrows > 0 ? nrows * a.OW : 0;
+    const int H0 = blockIdx.y * a.span_rows, H1 = min(a.H, H0 + a.span_rows);
+    const int RING = a.ring_rows;
+    const float invRING = 1.0f / (float)RING, invOW = 1.0f / (float)a.OW;
+    auto slot_of = [&](int oh) { return oh - RING * tf_fdiv(oh, invRING); };     // oh >= 0
 
     // ---- weights -> LDS (zero rows beyond T, zero k beyond C)
     for (int u = tid; u < 32 * (KP / 8); u += 256) {
@@ -83,16 +87,16 @@ __global__ __launch_bounds__(256) void tapfold_kernel(const TapFoldArgs a) {
             }
     }
 
-    // ---- z rows of the band: 16 pixels per MFMA column block, two fragments of loads in flight per wave
     typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
     const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc(
         (void*)a.x, 0, (int)((unsigned)a.B * a.OH * a.OW * a.C * 2u), 0x00020000);
-    const unsigned xb = (unsigned)((b * a.OH + oh_lo) * a.OW * a.C);      // element offset of the band's first z row
     // NF fragments (16 pixels x KS 16-byte loads each) in flight per wave: the kernel streams x once and is bound
     // by how many loads it keeps outstanding (two fragments: 41 us for 100 MB; see profiles/r2_dcgan28_*)
     constexpr int NF = KS == 1 ? 4 : 2;
-    for (int f0 = wave * NF; f0 * 16 < npix; f0 += 4 * NF) {
-        bf16x8_t xf[NF][KS];
+
+    // z rows [zs, ze] of the image, 16 pixels per MFMA column block; pixel p of the range sits in z row zs + p / OW
+    auto z_load = [&](int zs, int npix, int f0, u32x4_t (&xr)[NF][KS]) {
+        const unsigned xb = (unsigned)((b * a.OH + zs) * a.OW * a.C);
 #pragma unroll
         for (int j = 0; j < NF; ++j) {
             const int p = (f0 + j) * 16 + fr;
@@ -101,8 +105,21 @@ __global__ __launch_bounds__(256) void tapfold_kernel(const TapFoldArgs a) {
                 const int k = ks * 32 + fq * 8;
                 const bool ok = (p < npix) & (k < a.C);
                 const unsigned off = ok ? (xb + (unsigned)(p * a.C + k)) * 2u : 0xFFFFFFF0u;
-                u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(rsX, off, 0, 2);     // nt: read once
+                xr[j][ks] = __builtin_amdgcn_raw_buffer_load_b128(rsX, off, 0, 2);     // nt: read once
+            }
+        }
+    };
+    auto z_mma = [&](int zs, int npix, int f0, u32x4_t (&xr)[NF][KS]) {
+#pragma unroll
+        for (int j = 0; j < NF; ++j) {
+            const int p = (f0 + j) * 16 + fr;
+            const bool okp = p < npix;
+            bf16x8_t xf[KS];
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                u32x4_t v = xr[j][ks];
                 if (aff) {
+                    const bool ok = okp & (ks * 32 + fq * 8 < a.C);
                     float f[8];
                     unpack8(make_uint4(v[0], v[1], v[2], v[3]), f);
 #pragma unroll
@@ -110,32 +127,34 @@ __global__ __launch_bounds__(256) void tapfold_kernel(const TapFoldArgs a) {
                     const uint4 r = pack8(f);
                     v = (u32x4_t){r.x, r.y, r.z, r.w};
                 }
-                xf[j][ks] = __builtin_bit_cast(bf16x8_t, v);
+                xf[ks] = __builtin_bit_cast(bf16x8_t, v);
             }
-        }
-#pragma unroll
-        for (int j = 0; j < NF; ++j) {
-            const int p = (f0 + j) * 16 + fr;
             f32x4 acc[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
                 for (int tt = 0; tt < 2; ++tt)
-                    acc[tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[tt][ks], xf[j][ks], acc[tt], 0, 0, 0);
-            if (p < npix) {
+                    acc[tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[tt][ks], xf[ks], acc[tt], 0, 0, 0);
+            if (okp) {
                 // a lane holds taps 16tt + 4fq .. +3 of pixel p
+                const int zr = tf_fdiv(p, invOW), zc = p - zr * a.OW;
+                char* zp = sZ + (slot_of(zs + zr) * a.OW + zc) * TF_ZP;
 #pragma unroll
                 for (int tt = 0; tt < 2; ++tt) {
-                    uint32_t* d = (uint32_t*)(sZ + p * TF_ZP + (16 * tt + 4 * fq) * 2);
+                    uint32_t* d = (uint32_t*)(zp + (16 * tt + 4 * fq) * 2);
                     d[0] = pack2bf(acc[tt][0], acc[tt][1]);
                     d[1] = pack2bf(acc[tt][2], acc[tt][3]);
                 }
             }
         }
-    }
-    __syncthreads();
+    };
+    // the z rows the band of output rows [h0, h1) folds from
+    auto z_range = [&](int h0, int h1, int& lo_, int& hi_) {
+        const int lo = h0 + a.pt - (a.KH - 1) * a.dh;
+        lo_ = lo <= 0 ? 0 : (lo + sh - 1) / sh;
+        hi_ = min(a.OH - 1, (h1 - 1 + a.pt) / sh);
+    };
 
-    // ---- fold (identical to col2im_1ch_kernel)
     const float b0 = a.bias ? a.bias[0] : 0.f;
     const float invW = 1.0f / (float)a.W;
     // Branch-free fold for the compile-time strides with kernels up to 5x5 (stride 1) / 6x6 (stride 2): every candidate
@@ -144,60 +163,93 @@ __global__ __launch_bounds__(256) void tapfold_kernel(const TapFoldArgs a) {
     // tapfold launches).  Same taps in the same order: same bits.
     constexpr bool FASTS = (SH == 1 && SW == 1) || (SH == 2 && SW == 2);
     const bool fast_fold = FASTS && a.dh == 1 && a.dw == 1 && a.KH <= (SH == 1 ? 5 : 6) && a.KW <= (SW == 1 ? 5 : 6);
-    auto fold = [&](auto KA) {
-    for (int i = tid; i < (h1 - h0) * a.W; i += 256) {
-        int hl = tf_fdiv(i, invW), w = i - hl * a.W, h = h0 + hl;
-        float acc = 0.f;
-        if (FASTS && fast_fold) {
-            constexpr int NI = SH == 1 ? 5 : 3, ST = SH == 1 ? 1 : 2;
-            const int hh = h + a.pt, ww = w + a.pl;
-            const int ph = ST == 1 ? 0 : (hh & 1), pw = ST == 1 ? 0 : (ww & 1);
-            const int ohb = (ST == 1 ? hh : (hh >> 1)) - oh_lo, owb = ST == 1 ? ww : (ww >> 1);
-            const int nz = oh_hi - oh_lo + 1;
-            int roff[NI], coff[NI];
-            bool rv[NI], cv[NI];
-#pragma unroll
-            for (int q = 0; q < NI; ++q) {
-                const int kh = ph + ST * q, ol = ohb - q;
-                rv[q] = (kh < a.KH) & ((unsigned)ol < (unsigned)nz);
-                roff[q] = ol * a.OW * TF_ZP + kh * a.KW * 2;
-                const int kw = pw + ST * q, oc = owb - q;
-                cv[q] = (kw < a.KW) & ((unsigned)oc < (unsigned)a.OW);
-                coff[q] = oc * TF_ZP + kw * 2;
-            }
-            float tv[NI * NI];
-#pragma unroll
-            for (int q = 0; q < NI; ++q)
-#pragma unroll
-                for (int r = 0; r < NI; ++r) {
-                    const bool ok = rv[q] & cv[r];
-                    const bf16_t z = *(const bf16_t*)(sZ + (ok ? roff[q] + coff[r] : 0));
-                    tv[q * NI + r] = ok ? bf2f(z) : 0.f;
-                }
-#pragma unroll
-            for (int t = 0; t < NI * NI; ++t) acc += tv[t];
-        } else
-        for (int kh = 0; kh < a.KH; ++kh) {
-            int th = h + a.pt - kh * a.dh;
-            if (th < 0 || th % sh) continue;
-            int oh = th / sh;
-            if (oh > oh_hi) continue;
-            const char* row = sZ + (oh - oh_lo) * a.OW * TF_ZP + kh * a.KW * 2;
-            for (int kw = 0; kw < a.KW; ++kw) {
-                int tw = w + a.pl - kw * a.dw;
-                if (tw < 0 || tw % sw) continue;
-                int ow = tw / sw;
-                if (ow >= a.OW) continue;
-                acc += bf2f(*(const bf16_t*)(row + ow * TF_ZP + kw * 2));
-            }
+
+    auto walk = [&](auto KA) {
+    int z_next = 0;                             // first z row not yet in the ring
+    u32x4_t xr[NF][KS];
+    int pre_zs = 0, pre_np = -1;                // the range whose first pass of loads is already in flight
+    {
+        int lo_, hi_;
+        z_range(H0, min(H1, H0 + a.band_rows), lo_, hi_);
+        z_next = lo_;
+        pre_zs = lo_;
+        pre_np = max(0, hi_ - lo_ + 1) * a.OW;
+        z_load(pre_zs, pre_np, wave * NF, xr);
+    }
+    for (int h0 = H0; h0 < H1; h0 += a.band_rows) {
+        const int h1 = min(H1, h0 + a.band_rows);
+        int oh_lo, oh_hi;
+        z_range(h0, h1, oh_lo, oh_hi);
+        // ---- new z rows [zs, oh_hi] (the loads of the first pass were requested before the previous fold)
+        const int zs = pre_zs, npix = pre_np;
+        for (int f0 = wave * NF; f0 * 16 < npix; f0 += 4 * NF) {
+            if (f0 != wave * NF) z_load(zs, npix, f0, xr);
+            z_mma(zs, npix, f0, xr);
         }
-        float v = act_apply_k<decltype(KA)::value>(acc + b0, a.act, a.alpha);
-        const long pix = ((long)b * a.H + h) * a.W + w;
-        if (a.mul_y) v = bf2f(f2bf(v)) * act_grad_y(bf2f(a.mul_y[pix * 8]), a.mul_act, a.mul_alpha);
-        a.img[pix] = make_uint4((uint32_t)f2bf(v), 0, 0, 0);
+        z_next = max(z_next, oh_hi + 1);
+        __syncthreads();
+        if (h1 < H1) {                          // next band's first pass of loads rides under this band's fold
+            int lo_, hi_;
+            z_range(h1, min(H1, h1 + a.band_rows), lo_, hi_);
+            pre_zs = max(z_next, lo_);
+            pre_np = max(0, hi_ - pre_zs + 1) * a.OW;
+            z_load(pre_zs, pre_np, wave * NF, xr);
+        }
+        // ---- fold (identical to col2im_1ch_kernel)
+        for (int i = tid; i < (h1 - h0) * a.W; i += 256) {
+            int hl = tf_fdiv(i, invW), w = i - hl * a.W, h = h0 + hl;
+            float acc = 0.f;
+            if (FASTS && fast_fold) {
+                constexpr int NI = SH == 1 ? 5 : 3, ST = SH == 1 ? 1 : 2;
+                const int hh = h + a.pt, ww = w + a.pl;
+                const int ph = ST == 1 ? 0 : (hh & 1), pw = ST == 1 ? 0 : (ww & 1);
+                const int ohb = ST == 1 ? hh : (hh >> 1), owb = ST == 1 ? ww : (ww >> 1);
+                int roff[NI], coff[NI];
+                bool rv[NI], cv[NI];
+#pragma unroll
+                for (int q = 0; q < NI; ++q) {
+                    const int kh = ph + ST * q, ol = ohb - q;
+                    rv[q] = (kh < a.KH) & (ol >= oh_lo) & (ol <= oh_hi);
+                    roff[q] = slot_of(max(ol, 0)) * a.OW * TF_ZP + kh * a.KW * 2;
+                    const int kw = pw + ST * q, oc = owb - q;
+                    cv[q] = (kw < a.KW) & ((unsigned)oc < (unsigned)a.OW);
+                    coff[q] = oc * TF_ZP + kw * 2;
+                }
+                float tv[NI * NI];
+#pragma unroll
+                for (int q = 0; q < NI; ++q)
+#pragma unroll
+                    for (int r = 0; r < NI; ++r) {
+                        const bool ok = rv[q] & cv[r];
+                        const bf16_t z = *(const bf16_t*)(sZ + (ok ? roff[q] + coff[r] : 0));
+                        tv[q * NI + r] = ok ? bf2f(z) : 0.f;
+                    }
+#pragma unroll
+                for (int t = 0; t < NI * NI; ++t) acc += tv[t];
+            } else
+            for (int kh = 0; kh < a.KH; ++kh) {
+                int th = h + a.pt - kh * a.dh;
+                if (th < 0 || th % sh) continue;
+                int oh = th / sh;
+                if (oh > oh_hi) continue;
+                const char* row = sZ + slot_of(oh) * a.OW * TF_ZP + kh * a.KW * 2;
+                for (int kw = 0; kw < a.KW; ++kw) {
+                    int tw = w + a.pl - kw * a.dw;
+                    if (tw < 0 || tw % sw) continue;
+                    int ow = tw / sw;
+                    if (ow >= a.OW) continue;
+                    acc += bf2f(*(const bf16_t*)(row + ow * TF_ZP + kw * 2));
+                }
+            }
+            float v = act_apply_k<decltype(KA)::value>(acc + b0, a.act, a.alpha);
+            const long pix = ((long)b * a.H + h) * a.W + w;
+            if (a.mul_y) v = bf2f(f2bf(v)) * act_grad_y(bf2f(a.mul_y[pix * 8]), a.mul_act, a.mul_alpha);
+            a.img[pix] = make_uint4((uint32_t)f2bf(v), 0, 0, 0);
+        }
+        __syncthreads();                        // the next band overwrites the ring rows this fold no longer needs
     }
     };
-    act_switch(a.act, fold);                    // the loop compiled per activation: no branch chain per pixel
+    act_switch(a.act, walk);                    // the loops compiled per activation: no branch chain per pixel
 }
 
 template <int KS, int SH, int SW>
@@ -241,7 +293,14 @@ DDL_API int ddl_tapfold_1ch(const void* x, const void* w, const float* bias, voi
     const size_t smem = 32 * (size_t)TF_WP(KS * 32) + zbytes;
     if (smem > 160 * 1024 || (long)band * W >= (1L << 21)) return 1;
     a.band_rows = band;
-    const int bands = (H + band - 1) / band;
+    a.ring_rows = (int)zrows;
+    // a block walks `span` rows band by band (ring of z rows: no halo recomputed inside a span); spans only split the
+    // image when the batch alone would leave CUs idle
+    int spans = 1;
+    const int nb = (H + band - 1) / band;
+    while ((long)B * spans < 1024 && spans < nb) spans *= 2;
+    a.span_rows = ((nb + spans - 1) / spans) * band;
+    const int bands = (H + a.span_rows - 1) / a.span_rows;
     const int sv = (sh == 1 && sw == 1) ? 1 : ((sh == 2 && sw == 2) ? 2 : 0);
 #define TF_CASE(KS_) \
     if (KS == KS_) { \
