@@ -405,6 +405,39 @@ __global__ __launch_bounds__(256) void bn_stats_finalize_wide_kernel(
     }
 }
 
+// Hundreds of thousands of partials per channel (a patch-resident conv over a batch sized to HBM: one column per
+// (image, row band)): one block per channel walks them in ~0.4 ms on 32 of 256 CUs.  Fold them first: block
+// (row, group * S + s) sums the s-th of S ranges of one batch group's columns of one partial row (fp64 inside, fixed
+// order -> deterministic) into out[row][group * S + s]; the ordinary finalize then reads `S` partials per group.
+__global__ __launch_bounds__(256) void fold_partials_kernel(const float* __restrict__ part, int nbg, int groups, int S,
+                                                            float* __restrict__ out) {
+    __shared__ double red[4];
+    const int row = blockIdx.x, z = blockIdx.y / S, sidx = blockIdx.y - z * S;
+    const int len = (nbg + S - 1) / S;
+    const int b0 = sidx * len, b1 = min(nbg, b0 + len);
+    const float* p = part + ((size_t)row * groups + z) * nbg;
+    double a0 = 0;
+    int b = b0 + threadIdx.x;
+    for (; b + 768 < b1; b += 1024) {
+        float u[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) u[k] = p[b + 256 * k];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) a0 += u[k];
+    }
+    for (; b < b1; b += 256) a0 += p[b];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) a0 += __shfl_down(a0, o, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = a0;
+    __syncthreads();
+    if (threadIdx.x == 0) out[(size_t)row * groups * S + blockIdx.y] = (float)(((red[0] + red[1]) + red[2]) + red[3]);
+}
+
+// rows = partial rows (2 * C for forward statistics); part[row][groups][nbg] -> out[row][groups][S]
+DDL_API void ddl_fold_partials(const float* part, int rows, int nbg, int groups, int S, float* out, hipStream_t s) {
+    fold_partials_kernel<<<dim3(rows, groups * S), 256, 0, s>>>(part, nbg, groups, S, out);
+}
+
 // `groups` batch groups of `rows` rows (and `nblocks` partials) EACH; outputs [groups][C].
 DDL_API void ddl_bn_stats_from_part(const float* part, int nblocks, long rows, int C, const float* gamma,
                                     const float* beta, float* mm, float* mv, float momentum, float eps, int bessel,

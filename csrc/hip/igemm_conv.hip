@@ -27,6 +27,9 @@
 
 struct ClassDesc { int ph, pw, Hc, Wc, ntaps, tap_off, M, pad; };
 
+#define BK 64                 // K elements per LDS stage
+#define PITCH 128             // bytes per LDS row (64 bf16 K-elements, XOR-swizzled 16-B slots)
+
 struct ConvArgs {
     const bf16_t* src; const bf16_t* wgt; const float* bias; bf16_t* dst;
     const ClassDesc* classes; const int4* taps;     // tap = {offh, offw, wtap, 0}
@@ -41,12 +44,84 @@ struct ConvArgs {
     // optional: dst = bf16(bf16(conv) * (y > 0 ? 1 : mul_slope)), y laid out like dst -- act'(y) of the layer below
     // (linear / relu / leaky) fused into an input gradient; the same two roundings as the separate act_bwd pass
     const bf16_t* mul_y; float mul_slope;
+    // optional: per-block column sums / sums of squares of the STORED (bf16-rounded) output for the BatchNorm behind
+    // the layer: stats[(s * Nd + n) * stats_stride + stats_off + col], s = 0 | 1, col = pixel tile * classes + class
+    // (pixel-tile-major = batch-major); blocks past a class's rows write zeros
+    float* stats; int stats_stride, stats_off;
 };
 
-#define BK 64                 // K elements per LDS stage
-#define PITCH 128             // bytes per LDS row (64 bf16 K-elements, XOR-swizzled 16-B slots)
-#define DEPTH 3               // global loads are issued DEPTH K-steps ahead of their use
+#define PITCH1 64
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void igemm_stats_zero(const ConvArgs& a, int n0, int BN, int col) {
+    for (int c = threadIdx.x; c < BN; c += 256)
+        if (n0 + c < a.Nd) {
+            a.stats[(size_t)(n0 + c) * a.stats_stride + a.stats_off + col] = 0.f;
+            a.stats[(size_t)(a.Nd + n0 + c) * a.stats_stride + a.stats_off + col] = 0.f;
+        }
+}
+
+// Column sums / sums of squares of the block's stored tile: one 16-channel MFMA tile at a time (eight live sums),
+// the 16 pixel lanes by shuffles, the `waves_m` waves that share a channel range through LDS in a fixed order.
+// RAW: `acc` still holds the plain sums (bias and activation are applied here as the store applies them); else the
+// activated values.  `red` ([waves_m][BN][2] floats) aliases the staging buffers: the leading barrier waits for
+// every wave's last fragment read.
+template <int NT, int MT, bool RAW>
+__device__ __forceinline__ void igemm_stats_pass(const ConvArgs& a, const ClassDesc& cd, const f32x4 (&acc)[NT][MT], int mb,
+                                                 int wch0, int n0, int BN, int wm, int waves_m, int lane, float* red,
+                                                 int col) {
+    const int fr = lane & 15, fq = lane >> 4;
+    __syncthreads();
+    act_switch(RAW ? a.act : ACT_LINEAR, [&](auto KA) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            float s_[4] = {0.f, 0.f, 0.f, 0.f}, q_[4] = {0.f, 0.f, 0.f, 0.f}, bias_[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int n = n0 + wch0 + 16 * t + 4 * fq + e;
+                bias_[e] = (RAW && n < a.Nw && a.bias) ? a.bias[n] : 0.f;
+            }
+#pragma unroll
+            for (int j = 0; j < MT; ++j) {
+                const bool ok = mb + 16 * j + fr < cd.M;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float v = acc[t][j][e];
+                    if (RAW) v = n0 + wch0 + 16 * t + 4 * fq + e < a.Nw
+                                     ? act_apply_k<decltype(KA)::value>(v + bias_[e], a.act, a.alpha) : 0.f;
+                    const float r = ok ? bf2f(f2bf(v)) : 0.f;           // what the stored tensor holds
+                    s_[e] += r;
+                    q_[e] = fmaf(r, r, q_[e]);
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int o = 1; o < 16; o <<= 1) {
+                    s_[e] += __shfl_xor(s_[e], o, 64);
+                    q_[e] += __shfl_xor(q_[e], o, 64);
+                }
+            if (fr == 0) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int c = wch0 + 16 * t + 4 * fq + e;
+                    red[(wm * BN + c) * 2 + 0] = s_[e];
+                    red[(wm * BN + c) * 2 + 1] = q_[e];
+                }
+            }
+        }
+    });
+    __syncthreads();
+    for (int c = threadIdx.x; c < BN; c += 256)
+        if (n0 + c < a.Nd) {
+            float s0 = 0.f, s1 = 0.f;
+            for (int w = 0; w < waves_m; ++w) { s0 += red[(w * BN + c) * 2]; s1 += red[(w * BN + c) * 2 + 1]; }
+            a.stats[(size_t)(n0 + c) * a.stats_stride + a.stats_off + col] = s0;
+            a.stats[(size_t)(a.Nd + n0 + c) * a.stats_stride + a.stats_off + col] = s1;
+        }
+}
+
+#define DEPTH 3               // global loads are issued DEPTH K-steps ahead of their use
 
 template <int BM, int BN>
 __global__ __launch_bounds__(256) void igemm_conv_kernel(const ConvArgs a) {
@@ -66,8 +141,11 @@ __global__ __launch_bounds__(256) void igemm_conv_kernel(const ConvArgs a) {
     const int split = a.ksplit > 1 ? blockIdx.y : 0;
     const ClassDesc cd = a.classes[a.ksplit > 1 ? 0 : blockIdx.y];
     const int m0 = blockIdx.x * BM;
-    if (m0 >= cd.M) return;
     const int n0 = blockIdx.z * BN;
+    if (m0 >= cd.M) {
+        if (a.stats) igemm_stats_zero(a, n0, BN, blockIdx.x * gridDim.y + blockIdx.y);
+        return;
+    }
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave % WAVES_M, wn = wave / WAVES_M;
 
@@ -230,6 +308,9 @@ __global__ __launch_bounds__(256) void igemm_conv_kernel(const ConvArgs a) {
                     acc[t][j][e] = live ? act_apply_k<decltype(KA)::value>(acc[t][j][e] + bn_, a.act, a.alpha) : 0.f;
             }
     });
+    if (a.stats)                         // uniform; never together with the fused multiply (host-checked)
+        igemm_stats_pass<NT, 4, false>(a, cd, acc, m0 + wm * 64, wn * WN, n0, BN, wm, WAVES_M, lane, (float*)smem,
+                                       blockIdx.x * gridDim.y + blockIdx.y);
     const bool vec_ok = (a.Nd & 3) == 0;
     if (a.mul_y && vec_ok) {            // uniform.  All y loads first (one round trip), then the multiplies
         uint2 yv[NT][4];
@@ -290,7 +371,6 @@ __global__ __launch_bounds__(256) void igemm_conv_kernel(const ConvArgs a) {
 // four 16-lane groups {0-3,12-15,20-27},... over 64 banks, and this XOR sends the four lanes of a group that
 // share (row mod 4) to four different slots.  The padded layout (96 B) conflicted 2-way on every store
 // (30 % of LDS cycles, profiles/r1_dcgan64_pmc_counters.md) and used 1.5x the LDS.
-#define PITCH1 64
 
 template <int BM, int BN>
 __global__ __launch_bounds__(256) void igemm_conv_kernel_k32(const ConvArgs a) {
@@ -310,8 +390,11 @@ __global__ __launch_bounds__(256) void igemm_conv_kernel_k32(const ConvArgs a) {
     const int split = a.ksplit > 1 ? blockIdx.y : 0;
     const ClassDesc cd = a.classes[a.ksplit > 1 ? 0 : blockIdx.y];
     const int m0 = blockIdx.x * BM;
-    if (m0 >= cd.M) return;
     const int n0 = blockIdx.z * BN;
+    if (m0 >= cd.M) {
+        if (a.stats) igemm_stats_zero(a, n0, BN, blockIdx.x * gridDim.y + blockIdx.y);
+        return;
+    }
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave % WAVES_M, wn = wave / WAVES_M;
 
@@ -500,6 +583,9 @@ __global__ __launch_bounds__(256) void igemm_conv_kernel_k32(const ConvArgs a) {
                     acc[t][j][e] = live ? act_apply_k<decltype(KA)::value>(acc[t][j][e] + bn_, a.act, a.alpha) : 0.f;
             }
     });
+    if (a.stats)                         // uniform; never together with the fused multiply (host-checked)
+        igemm_stats_pass<NT, 4, false>(a, cd, acc, m0 + wm * 64, wn * WN, n0, BN, wm, WAVES_M, lane, (float*)smem,
+                                       blockIdx.x * gridDim.y + blockIdx.y);
     const bool vec_ok = (a.Nd & 3) == 0;
     if (a.mul_y && vec_ok) {            // uniform.  All y loads first (one round trip), then the multiplies
         uint2 yv[NT][4];
@@ -570,7 +656,7 @@ __global__ __launch_bounds__(256) void igemm_conv_kernel_k32(const ConvArgs a) {
 // serves the second gather of the same pixels): id = blockIdx.x, xcd = id % 8, k = id / 8,
 // (n tile, m tile) = (k % n_ntiles, (k / n_ntiles) * 8 + xcd).
 template <int NT, int MT>
-__device__ __forceinline__ void igemm_epilogue(const ConvArgs& a, const ClassDesc& cd, f32x4 (&acc)[NT][MT],
+__device__ __forceinline__ void igemm_epilogue(const ConvArgs& a, const ClassDesc& cd, const f32x4 (&acc)[NT][MT],
                                                int mb, int nb0, int lane) {
     const int fr = lane & 15, fq = lane >> 4;
     const int HW = cd.Hc * cd.Wc;
@@ -653,7 +739,7 @@ constexpr int dma_min_waves(int acc_regs) { return acc_regs <= 64 ? 3 : 2; }
 
 template <int BM, int BN, int WAVES_M, int STAGES>
 __global__ __launch_bounds__(256, dma_min_waves((BM / WAVES_M) * (BN / (4 / WAVES_M)) / 64))
-void igemm_conv_kernel_dma(const ConvArgs a, const int n_ntiles) {
+void igemm_conv_kernel_dma(const ConvArgs a, const int n_ntiles, const int n_mtiles) {
     constexpr int WAVES_N = 4 / WAVES_M;
     constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;      // pixels x channels per wave
     constexpr int MT = WM / 16, NT = WN / 16;
@@ -670,8 +756,12 @@ void igemm_conv_kernel_dma(const ConvArgs a, const int n_ntiles) {
     const int xcd = blockIdx.x & 7, kblk = blockIdx.x >> 3;
     const int n_tile = kblk % n_ntiles, m_tile = (kblk / n_ntiles) * 8 + xcd;
     const int m0 = m_tile * BM;
-    if (m0 >= cd.M) return;
     const int n0 = n_tile * BN;
+    const int scol = m_tile * gridDim.y + blockIdx.y;
+    if (m0 >= cd.M) {
+        if (a.stats && m_tile < n_mtiles) igemm_stats_zero(a, n0, BN, scol);
+        return;
+    }
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave % WAVES_M, wn = wave / WAVES_M;
@@ -782,6 +872,8 @@ void igemm_conv_kernel_dma(const ConvArgs a, const int n_ntiles) {
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // trailing zero-fill stages: nothing may land after exit
 
+    if (a.stats)                         // uniform
+        igemm_stats_pass<NT, MT, true>(a, cd, acc, m0 + wm * WM, wn * WN, n0, BN, wm, WAVES_M, lane, (float*)smem, scol);
     igemm_epilogue<NT, MT>(a, cd, acc, m0 + wm * WM, n0 + wn * WN, lane);
 }
 
@@ -846,7 +938,7 @@ static int launch_igemm_dma(const ConvArgs& a, int n_classes, int max_M, hipStre
     }
     const int mt = (max_M + BM - 1) / BM, nt = (a.Nd + BN - 1) / BN;
     dim3 grid((unsigned)((mt + 7) / 8 * 8 * nt), n_classes, 1);
-    kern<<<grid, 256, smem, s>>>(a, nt);
+    kern<<<grid, 256, smem, s>>>(a, nt, mt);
     return 0;
 }
 
@@ -856,7 +948,7 @@ DDL_API int ddl_igemm_conv(const void* src, const void* wgt, const float* bias, 
                            const void* taps, int n_classes, int max_M, int max_taps, int B, int Hs, int Ws,
                            int Cs, int Hd, int Wd, int Nd, int Nw, int ssh, int ssw, int sdh, int sdw, int Ttot,
                            int act, float alpha, int tile, int ksplit, float* slab, const void* mul_y,
-                           float mul_slope, hipStream_t s) {
+                           float mul_slope, float* stats, int stats_stride, int stats_off, hipStream_t s) {
     if (Cs % 8 != 0 || Cs <= 0 || Nd <= 0 || n_classes <= 0 || max_M <= 0) return -1;
     if ((long)B * Hs * Ws * Cs >= (1L << 31) || (long)B * Hd * Wd * Nd >= (1L << 31) ||
         (long)Nw * Ttot * Cs >= (1L << 31)) return -3;
@@ -868,6 +960,8 @@ DDL_API int ddl_igemm_conv(const void* src, const void* wgt, const float* bias, 
     a.max_taps = max_taps;
     a.mul_y = (ksplit > 1 || (Nd & 3)) ? nullptr : (const bf16_t*)mul_y; a.mul_slope = mul_slope;
     if (mul_y && !a.mul_y) return -5;       // the caller runs the separate pass
+    a.stats = stats; a.stats_stride = stats_stride; a.stats_off = stats_off;
+    if (stats && (mul_y || ksplit > 1 || stats_stride <= 0 || stats_off < 0)) return -7;
     a.ksplit = 1; a.slab = nullptr;
     if (ksplit > 1) {
         // split-K needs one class whose destination pixel index equals the row index (fprop, unit dst stride,

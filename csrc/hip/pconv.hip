@@ -43,7 +43,7 @@ struct PConvArgs {
     // STATS instantiation: per-block partial sums of the (bf16-rounded) outputs and their squares, laid out
     // part[2][Nd][gridDim.x] like the column-reduction kernels' partials -- the BatchNorm that follows reads
     // its batch statistics from here instead of making a pass over the output tensor.
-    float* stats;
+    float* stats; int stats_stride, stats_off;     // partial column = stats_off + block; row pitch stats_stride
     // MULY instantiation: dst = bf16(bf16(conv) * (y > 0 ? 1 : mul_slope)) -- linear / relu / leaky of the layer below,
     // the same two roundings as the separate act_bwd pass (bit-identical)
     const bf16_t* mul_y; float mul_slope;
@@ -453,9 +453,9 @@ __global__ __launch_bounds__(256, (BN * FR >= 512 ? 1 : 2)) void pconv_kernel(co
             float s0 = 0.f, s1 = 0.f;
 #pragma unroll
             for (int w = 0; w < 4; ++w) { s0 += red[(w * BN + tid) * 2]; s1 += red[(w * BN + tid) * 2 + 1]; }
-            const size_t nb = gridDim.x;
-            a.stats[((size_t)(n0 + tid)) * nb + blockIdx.x] = s0;
-            a.stats[((size_t)(a.Nd + n0 + tid)) * nb + blockIdx.x] = s1;
+            const size_t nb = a.stats_stride, col = (size_t)a.stats_off + blockIdx.x;
+            a.stats[((size_t)(n0 + tid)) * nb + col] = s0;
+            a.stats[((size_t)(a.Nd + n0 + tid)) * nb + col] = s1;
         }
     }
 }
@@ -503,7 +503,8 @@ DDL_API int ddl_pconv(const void* src, const void* wgt, const float* bias, void*
                       int IMG, int BR, int bands, int omin_h, int omin_w, int PH, int PW, int pitch, int BN, int FR,
                       float* stats, const float* bn_gamma, const float* bn_beta, const float* bn_mean,
                       const float* bn_var, float bn_eps, const float* in_scale, const float* in_shift,
-                      int in_group_rows, int in_ctrue, const void* mul_y, float mul_slope, hipStream_t s) {
+                      int in_group_rows, int in_ctrue, const void* mul_y, float mul_slope, int stats_stride,
+                      int stats_off, hipStream_t s) {
     if (Cs % 8 != 0 || Cs <= 0 || Nd <= 0 || Nd % 8 != 0 || n_classes <= 0 || B <= 0 || IMG <= 0 || BR <= 0) return -1;
     if (pitch % 16 != 0 || pitch < Cs * 2) return -1;
     if ((long)B * Hs * Ws * Cs >= (1L << 31) || (long)B * Hd * Wd * Nd >= (1L << 31)) return -3;
@@ -512,6 +513,10 @@ DDL_API int ddl_pconv(const void* src, const void* wgt, const float* bias, void*
     a.src = (const bf16_t*)src; a.wgt = (const bf16_t*)wgt; a.bias = bias; a.dst = (bf16_t*)dst;
     a.classes = (const PClass*)classes; a.ktab = (const int2*)ktab;
     a.stats = stats;
+    // partials of several launches (batch slices) side by side in one [2][Nd][stats_stride] array; 0 = this launch alone
+    a.stats_stride = stats_stride > 0 ? stats_stride : ((B + IMG - 1) / IMG) * bands;
+    a.stats_off = stats_stride > 0 ? stats_off : 0;
+    if (stats && (a.stats_off < 0 || a.stats_off + ((B + IMG - 1) / IMG) * bands > a.stats_stride)) return -1;
     if (stats && bn_gamma) return -1;
     if (mul_y && (stats || bn_gamma)) return -1;
     a.mul_y = (const bf16_t*)mul_y; a.mul_slope = mul_slope;

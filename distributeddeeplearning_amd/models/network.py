@@ -349,7 +349,7 @@ class ConvOp(Op):
             return self._fwd_onech(x, training)
         # a batch-statistics BN right behind this layer: let the conv kernel emit the statistics' partial sums
         bn = self.next_bn
-        so = {} if (training and bn is not None and bn.mode == "batch" and x.is_cuda) else None
+        so = {"groups": bn.groups} if (training and bn is not None and bn.mode == "batch" and x.is_cuda) else None
         # pure inference with a plain BN behind: the conv epilogue can apply the BN's affine itself
         bi = None
         if not training and bn is not None and bn.post_act in (None, "linear") and x.is_cuda:

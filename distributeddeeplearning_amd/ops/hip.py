@@ -47,6 +47,7 @@ _act_bwd = _sig("ddl_act_bwd", None, vp, vp, vp, cl, ci, cf, vp)
 _colreduce_blocks = _sig("ddl_colreduce_blocks", ci, cl, ci)
 _bn_batch_stats = _sig("ddl_bn_batch_stats", None, vp, cl, ci, vp, vp, vp, vp, vp, cf, cf, ci, ci, vp, vp, vp, vp, ci, vp)
 _bn_stats_from_part = _sig("ddl_bn_stats_from_part", None, vp, ci, cl, ci, vp, vp, vp, vp, cf, cf, ci, ci, vp, vp, vp, vp, ci, vp)
+_fold_partials = _sig("ddl_fold_partials", None, vp, ci, ci, ci, ci, vp, vp)
 _bn_infer_affine = _sig("ddl_bn_infer_affine", None, vp, vp, vp, vp, cf, ci, vp, vp, vp, vp)
 _bn_apply = _sig("ddl_bn_apply", None, vp, vp, vp, vp, cl, ci, ci, ci, cf, ci, vp)
 _bn_apply_infer = _sig("ddl_bn_apply_infer", None, vp, vp, vp, vp, vp, vp, cf, cl, ci, ci, ci, cf, vp)
@@ -83,9 +84,9 @@ _relayout_both = _sig("ddl_relayout_both", None, vp, vp, vp, ci, vp, vp, ci, cl,
 _gemm_sk = _sig("ddl_gemm_sk", ci, vp, vp, vp, vp, cl, ci, ci, ci, ci, cf, vp)
 _philox = _sig("ddl_philox_uniform", None, vp, cl, vp, cf, cf, vp)
 _igemm = _sig("ddl_igemm_conv", ci, vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci,
-              ci, ci, ci, ci, cf, ci, ci, vp, vp, cf, vp)
+              ci, ci, ci, ci, cf, ci, ci, vp, vp, cf, vp, ci, ci, vp)
 _pconv = _sig("ddl_pconv", ci, vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, cf,
-              ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, vp, vp, vp, vp, vp, cf, vp, vp, ci, ci, vp, cf, vp)
+              ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, vp, vp, vp, vp, vp, cf, vp, vp, ci, ci, vp, cf, ci, ci, vp)
 _pconv_lds = _sig("ddl_pconv_lds_bytes", ci, ci, ci, cl)
 _wgrad_ksplit = _sig("ddl_wgrad_ksplit", ci, ci, ci, ci, ci)
 _wgrad = _sig("ddl_conv_wgrad", ci, vp, vp, vp, vp, cl, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci,
@@ -227,6 +228,9 @@ def bn_train_affine(x, gamma, beta, mm, mv, momentum, eps, bessel, update_moving
     return out[0], out[1], out[2], out[3]
 
 
+FOLD_PARTIALS_MIN = int(os.environ.get("DDL_FOLD_PARTIALS_MIN", "16384"))
+
+
 def bn_train_affine_from_part(part, nb, rows, gamma, beta, mm, mv, momentum, eps, bessel, update_moving=True,
                               groups=1):
     """`bn_train_affine` when the producer kernel already left per-block partial sums part[2][Cp][nb].
@@ -239,6 +243,11 @@ def bn_train_affine_from_part(part, nb, rows, gamma, beta, mm, mv, momentum, eps
     for t, n in ((gamma, "gamma"), (beta, "beta"), (mm, "moving_mean"), (mv, "moving_var")):
         _chk_f32(t, Cp, n)
     out = torch.empty(4, groups, Cp, dtype=torch.float32, device=gamma.device)
+    if nb // groups >= FOLD_PARTIALS_MIN:          # very many columns: fold them 64-fold across the chip first
+        S = 64
+        folded = torch.empty(2 * Cp * groups * S, dtype=torch.float32, device=gamma.device)
+        _fold_partials(part.data_ptr(), 2 * Cp, nb // groups, groups, S, folded.data_ptr(), _stream())
+        part, nb = folded, groups * S
     _bn_stats_from_part(part.data_ptr(), nb // groups, rows // groups, Cp, gamma.data_ptr(), beta.data_ptr(),
                         mm.data_ptr(), mv.data_ptr(), momentum, eps, int(bool(bessel)), int(bool(update_moving)),
                         out[0].data_ptr(), out[1].data_ptr(), out[2].data_ptr(), out[3].data_ptr(), groups, _stream())
@@ -1200,9 +1209,10 @@ IGEMM_MULY = os.environ.get("DDL_IGEMM_MULY", "1") == "1"
 
 
 def _run_pconv(pl, src, wgt, bias, dst, g, B, Hs, Ws, Cs, Hd, Wd, Nd, Nw, ss, sd, act, alpha, mul=None, stats=None,
-               bn_infer=None, in_affine=None):
+               bn_infer=None, in_affine=None, stats_at=(0, 0)):
     """`stats`: fp32 tensor of 2 * Nd * units elements that receives per-block column sums / sums of squares
-    of the output (layout [2][Nd][units]) for the BatchNorm that follows.
+    of the output (layout [2][Nd][units]) for the BatchNorm that follows; `stats_at` = (row pitch, first column) when
+    the partials of several launches (batch slices) share one [2][Nd][pitch] array.
     `bn_infer` = (gamma, beta, moving_mean, moving_var, eps): fold an inference-phase BatchNorm into the epilogue."""
     bg = bb = bm = bvv = None
     beps = 0.0
@@ -1231,7 +1241,7 @@ def _run_pconv(pl, src, wgt, bias, dst, g, B, Hs, Ws, Cs, Hd, Wd, Nd, Nw, ss, sd
                 pl["ktab"].data_ptr(), pl["ncls"], pl["nst"], B, Hs, Ws, Cs, Hd, Wd, Nd, Nw, ss[0], ss[1],
                 sd[0], sd[1], g.KH * g.KW, ACT_CODE[act], alpha, pl["IMG"], pl["BR"], pl["bands"],
                 pl["omin_h"], pl["omin_w"], pl["PH"], pl["PW"], pl["pitch"], pl["BN"], pl["FR"], _p(stats), bg, bb, bm,
-                bvv, beps, isc, ish, igr, ict, my, ms, _stream())
+                bvv, beps, isc, ish, igr, ict, my, ms, stats_at[0], stats_at[1], _stream())
     if rc != 0:
         raise ValueError(f"pconv rejected its plan (rc={rc}): {g} B={B} "
                          f"{ {k: v for k, v in pl.items() if k not in ('classes', 'ktab')} }")
@@ -1247,8 +1257,35 @@ def _mul_slope(mul, dst):
     return None
 
 
-def _run_igemm(src, wgt, bias, dst, g, mode, B, Hs, Ws, Cs, Hd, Wd, Nd, Nw, ss, sd, act, alpha, tile=None, mul=None):
-    """`mul` = (y, act, alpha): result *= act'(y) -- in the kernel's epilogue for linear / relu / leaky, else as a pass."""
+_IGEMM_BM = {1: 256, 2: 64, 3: 256, 4: 128, 5: 256, 6: 128, 8: 64, 33: 128, 34: 256, 35: 128, 36: 256, 37: 256, 38: 128,
+             39: 256, 40: 128, 41: 256}
+_IGEMM_NO_STATS = ()
+
+
+def _igemm_stats_cols(tile, g, mode, B, device):
+    """(partial columns, images per column) of the implicit-GEMM kernels' statistics epilogue for this tile, or None
+    when the tile has none (heuristic tile, classes of different sizes).  A column is one pixel tile of one class
+    (pixel-tile-major = batch-major); `images per column` is what a consumer with per-group statistics checks the
+    group size against -- B + 1 when pixel tiles do not line up with images at all."""
+    if tile is None:
+        return None
+    t = tile - 16 if 16 < tile < 32 else tile
+    if t not in _IGEMM_BM or t in _IGEMM_NO_STATS:
+        return None
+    cl_, _ = _class_taps(g, mode)
+    hw = {c[2] * c[3] for c in cl_}
+    if len(hw) != 1:
+        return None
+    hw, BM = hw.pop(), _IGEMM_BM[t]
+    img = BM // hw if BM % hw == 0 else (1 if hw % BM == 0 else B + 1)
+    return -(-(B * hw) // BM) * len(cl_), img
+
+
+def _run_igemm(src, wgt, bias, dst, g, mode, B, Hs, Ws, Cs, Hd, Wd, Nd, Nw, ss, sd, act, alpha, tile=None, mul=None,
+               stats=None):
+    """`mul` = (y, act, alpha): result *= act'(y) -- in the kernel's epilogue for linear / relu / leaky, else as a pass.
+    `stats` = (fp32 tensor, row pitch, first column): per-block column sums / sums of squares of the stored output,
+    [2][Nd][pitch] (see _igemm_stats_cols)."""
     ct, tt, ncls, maxM, maxT, ut_all = _tables(g, mode, B, src.device)
     tile = IGEMM_TILE if tile is None else tile
     if tile >= 32 and not (ut_all and Cs % 32 == 0):
@@ -1264,16 +1301,21 @@ def _run_igemm(src, wgt, bias, dst, g, mode, B, Hs, Ws, Cs, Hd, Wd, Nd, Nw, ss, 
             if ksplit > 1:
                 slab = torch.empty(ksplit * maxM * Nd, dtype=torch.float32, device=src.device)
     _ms = _mul_slope(mul, dst) if ACT_CODE[act] in (0, 1, 6) else None
+    if stats is not None:
+        if mul is not None or slab is not None:
+            raise ValueError("igemm statistics epilogue: not with a fused multiply or split-K")
+        _chk_f32(stats[0], 2 * Nd * stats[1], "stats partials")
+    st = (None, 0, 0) if stats is None else (stats[0].data_ptr(), stats[1], stats[2])
     rc = _igemm(src.data_ptr(), wgt.data_ptr(), _p(bias), dst.data_ptr(), ct.data_ptr(), tt.data_ptr(), ncls,
                 maxM, maxT, B, Hs, Ws, Cs, Hd, Wd, Nd, Nw, ss[0], ss[1], sd[0], sd[1], g.KH * g.KW,
                 ACT_CODE[act], alpha, tile, ksplit if slab is not None else 1,
-                _p(slab), *( (None, 0.0) if _ms is None else _ms ), _stream())
+                _p(slab), *( (None, 0.0) if _ms is None else _ms ), *st, _stream())
     if rc == -5:                        # no fused multiply for this shape: plain launch, separate pass
         _ms = None
         rc = _igemm(src.data_ptr(), wgt.data_ptr(), _p(bias), dst.data_ptr(), ct.data_ptr(), tt.data_ptr(), ncls,
                     maxM, maxT, B, Hs, Ws, Cs, Hd, Wd, Nd, Nw, ss[0], ss[1], sd[0], sd[1], g.KH * g.KW,
                     ACT_CODE[act], alpha, tile, ksplit if slab is not None else 1,
-                    _p(slab), None, 0.0, _stream())
+                    _p(slab), None, 0.0, *st, _stream())
     if rc != 0:
         raise ValueError(f"igemm_conv rejected the problem (rc={rc}): {g} mode={mode} B={B}")
     if _ms is None:
@@ -1346,25 +1388,12 @@ def _dma_tiles(g, mode, B, Cs, Nd, device):
     return [33, 34, 38, 40, 41]
 
 
-def _igemm_call(src, wgt, bias, dst, g, mode, B, Hs, Ws, Cs, Hd, Wd, Nd, Nw, ss, sd, act, alpha, mul=None,
-                stats_out=None, bn_infer=None, in_affine=None, aff_sink=None):
-    """Dispatch one class-grid convolution: the patch-resident kernel with a tuned plan, or the
-    global-gather kernel.  The first (non-captured) call of each problem times the candidates on the
-    real operands and caches the winner -- these shapes are static for a whole training run."""
-    def materialise():                  # the global-gather kernel has no affine on load: apply the BatchNorm first
-        sc_t, sh_t, (igr,), ict = in_affine
-        m = bn_apply(src, sc_t, sh_t, None, 0.3, ict, B // igr)
-        if aff_sink is not None:        # the caller keeps it (weight gradient) instead of rebuilding it
-            aff_sink["x"] = m
-        return m
-    args = (src, wgt, bias, dst, g)
+def _conv_choice(src, wgt, bias, dst, g, mode, B, Hs, Ws, Cs, Hd, Wd, Nd, Nw, ss, sd, act, alpha, mul=None,
+                 want_stats=False):
+    """("pconv", plan) | ("igemm", tile) for one class-grid convolution.  The first (non-captured) call of each
+    problem times the candidates on the real operands and caches the winner -- these shapes are static for a whole
+    training run."""
     tail = (B, Hs, Ws, Cs, Hd, Wd, Nd, Nw, ss, sd, act, alpha)
-    if CONV_IMPL != "pconv":
-        if in_affine is not None:
-            src = materialise()
-        _run_igemm(src, wgt, bias, dst, g, mode, *tail, mul=mul)
-        _done()
-        return
     slow = ACT_CODE[act] not in (0, 1, 6)
     key = (g, mode, B, Cs, Nd, slow, str(src.device))
     kstr = _kstr("conv", g, mode, B, Cs, Nd, int(slow))
@@ -1392,9 +1421,10 @@ def _igemm_call(src, wgt, bias, dst, g, mode, B, Hs, Ws, Cs, Hd, Wd, Nd, Nw, ss,
                 fn = (lambda pl=pl: _run_igemm(src, wgt, bias, dst, g, mode, *tail, tile=pl, mul=mul)) \
                     if kind == "igemm" else (lambda pl=pl: _run_pconv(pl, src, wgt, bias, dst, g, *tail, mul=mul))
                 t_us = _time_us(fn)
-                if kind == "igemm" and stats_out is not None and PCONV_STATS and mul is None:
-                    # a BatchNorm behind this layer: pconv's epilogue emits its statistics, the gather kernel leaves
-                    # them to a pass over the output (launch + streaming read)
+                if (kind == "igemm" and want_stats and PCONV_STATS and mul is None
+                        and _igemm_stats_cols(pl, g, mode, B, src.device) is None):
+                    # a BatchNorm behind this layer and a tile without the statistics epilogue: it leaves them to a
+                    # pass over the output (launch + streaming read)
                     t_us += 4.0 + B * Hd * Wd * Nd * 2 / 3.0e6
                 timed.append((t_us, kind, pl))
             timed.sort(key=lambda t: t[0])
@@ -1410,21 +1440,58 @@ def _igemm_call(src, wgt, bias, dst, g, mode, B, Hs, Ws, Cs, Hd, Wd, Nd, Nw, ss,
             pl = _pconv_plan(g, mode, B, Cs, Nd, ss, src.device)
             choice = ("pconv", pl) if pl is not None else ("igemm", None)
         _CONV_CHOICE[key] = choice
+    return choice
+
+
+def _choice_stats_cols(choice, g, mode, B, device):
+    """(partial columns, images per column) of the chosen kernel's statistics epilogue, or None."""
     if choice[0] == "pconv":
-        stats = None
+        return _pconv_units(choice[1], B), choice[1]["IMG"]
+    return _igemm_stats_cols(choice[1], g, mode, B, device)
+
+
+def _igemm_call(src, wgt, bias, dst, g, mode, B, Hs, Ws, Cs, Hd, Wd, Nd, Nw, ss, sd, act, alpha, mul=None,
+                stats_out=None, bn_infer=None, in_affine=None, aff_sink=None, stats_into=None):
+    """Dispatch one class-grid convolution: the patch-resident kernel with a tuned plan, or the global-gather kernel
+    (_conv_choice).  `stats_out`: dict that receives the BatchNorm partials the kernel's epilogue leaves ("part", "nb",
+    "img"); `stats_into` = (tensor, row pitch, first column): write them there instead (one slice of a batch-split
+    layer: the caller made sure this slice's kernel has the epilogue)."""
+    def materialise():                  # the global-gather kernel has no affine on load: apply the BatchNorm first
+        sc_t, sh_t, (igr,), ict = in_affine
+        m = bn_apply(src, sc_t, sh_t, None, 0.3, ict, B // igr)
+        if aff_sink is not None:        # the caller keeps it (weight gradient) instead of rebuilding it
+            aff_sink["x"] = m
+        return m
+    args = (src, wgt, bias, dst, g)
+    tail = (B, Hs, Ws, Cs, Hd, Wd, Nd, Nw, ss, sd, act, alpha)
+    if CONV_IMPL != "pconv":
+        if in_affine is not None:
+            src = materialise()
+        _run_igemm(src, wgt, bias, dst, g, mode, *tail, mul=mul)
+        _done()
+        return
+    want_stats = (stats_out is not None or stats_into is not None) and PCONV_STATS and mul is None
+    choice = _conv_choice(*args, mode, *tail, mul=mul, want_stats=want_stats)
+    stats = stats_into
+    if choice[0] == "pconv":
         if bn_infer is not None and (stats_out is None or mul is not None or not PCONV_STATS):
             bn_infer = None
         if bn_infer is not None:
             stats_out["affine"] = True                   # the caller skips its BatchNorm pass
-        elif stats_out is not None and PCONV_STATS and mul is None:
-            nb = _pconv_units(choice[1], B)
-            stats = torch.empty(2 * Nd * nb, dtype=torch.float32, device=src.device)
-            stats_out["part"], stats_out["nb"], stats_out["img"] = stats, nb, choice[1]["IMG"]
-        _run_pconv(choice[1], *args, *tail, mul=mul, stats=stats, bn_infer=bn_infer, in_affine=in_affine)
+            stats = None
+    if stats is None and want_stats and stats_out is not None and not stats_out.get("affine"):
+        cols = _choice_stats_cols(choice, g, mode, B, src.device)
+        if cols is not None:
+            part = torch.empty(2 * Nd * cols[0], dtype=torch.float32, device=src.device)
+            stats = (part, cols[0], 0)
+            stats_out["part"], stats_out["nb"], stats_out["img"] = part, cols[0], cols[1]
+    if choice[0] == "pconv":
+        _run_pconv(choice[1], *args, *tail, mul=mul, stats=None if stats is None else stats[0], bn_infer=bn_infer,
+                   in_affine=in_affine, stats_at=(0, 0) if stats is None else (stats[1], stats[2]))
     else:
         if in_affine is not None:
             src = materialise()
-        _run_igemm(src, wgt, bias, dst, g, mode, *tail, tile=choice[1], mul=mul)
+        _run_igemm(src, wgt, bias, dst, g, mode, *tail, tile=choice[1], mul=mul, stats=stats)
     _done()
 
 
@@ -1451,14 +1518,82 @@ def _is_1x1(g: ConvGeom) -> bool:
 ELEM_LIMIT = int(os.environ.get("DDL_CONV_ELEM_LIMIT", str((1 << 31) - 1)))
 
 
-def _batch_ranges(B: int, per_image: int):
-    """[(b0, b1)] so that no slice has more than ELEM_LIMIT elements in its largest operand (None: no split)."""
+def _batch_ranges(B: int, per_image: int, align: int = 0):
+    """[(b0, b1)] so that no slice has more than ELEM_LIMIT elements in its largest operand (None: no split).
+    `align` > 0: no slice crosses a multiple of `align` images (batch groups with their own BatchNorm statistics)."""
     if B * per_image <= ELEM_LIMIT:
         return None
     step = max(1, ELEM_LIMIT // per_image)
     if step >= 8:
         step -= step % 8
-    return [(b, min(b + step, B)) for b in range(0, B, step)]
+    segs = [(a, min(a + align, B)) for a in range(0, B, align)] if align > 0 else [(0, B)]
+    out = []
+    for a0, a1 in segs:                 # equal slices (one tuned plan serves them all), not full ones + a sliver
+        n = -(-(a1 - a0) // step)
+        sz = -(-(a1 - a0) // n)
+        if sz % 8 and sz + 8 - sz % 8 <= step:
+            sz += 8 - sz % 8
+        out += [(b, min(b + sz, a1)) for b in range(a0, a1, sz)]
+    return out
+
+
+def _conv_slices(kind, x, w, bias, y, g, act, alpha, mul, stats_out, ranges, groups, in_affine=None, aff_sink=None):
+    """A convolution whose operands exceed the 32-bit element offsets of one launch, as batch slices -- with the
+    fusions of the unsliced path kept: every slice's kernel is chosen first (tuning it if this is its first call), then
+      * the BatchNorm statistics epilogue runs in every slice, all writing their partial columns side by side into
+        one [2][Nd][columns] array (when every chosen kernel has the epilogue), and
+      * a BatchNorm applied on load stays on load (when every chosen kernel is the patch-resident one), each slice
+        with the (scale, shift) row of the batch group it lies in; otherwise the operand is materialised once.
+    `ranges` never cross a batch-group boundary (`groups` equal parts).  `in_affine` = (scale, shift, groups, c_true)
+    as given to conv_dgrad."""
+    B = x.shape[0]
+    Ip, Op = pad8(g.I), pad8(g.O)
+
+    def grid_args(b0, b1):
+        xs, ys = x[b0:b1], y[b0:b1]
+        if kind == "fprop":
+            return (xs, w, bias, ys, g, "fprop", b1 - b0, g.H, g.W, Ip, g.OH, g.OW, Op, min(w.shape[0], g.O),
+                    (g.sh, g.sw), (1, 1), act, alpha)
+        return (xs, w, bias, ys, g, "dgrad", b1 - b0, g.OH, g.OW, Op, g.H, g.W, Ip, min(w.shape[0], g.I),
+                (1, 1), (g.sh, g.sw), act, alpha)
+
+    want_stats = stats_out is not None and PCONV_STATS and mul is None and CONV_IMPL == "pconv"
+    choices, cols = [], []
+    if CONV_IMPL == "pconv":
+        for b0, b1 in ranges:
+            ga = grid_args(b0, b1)
+            ch = _conv_choice(*ga, mul=_mul_slice(mul, b0, b1), want_stats=want_stats)
+            choices.append(ch)
+            cols.append(_choice_stats_cols(ch, g, ga[5], b1 - b0, x.device))
+    if in_affine is not None:
+        sc_t, sh_t, agr, ict = in_affine
+        on_load = bool(choices) and all(c[0] == "pconv" for c in choices) and groups % agr == 0
+        if not on_load:
+            x = bn_apply(x, sc_t, sh_t, None, 0.3, ict, agr)
+            if aff_sink is not None:
+                aff_sink["x"] = x
+            in_affine = None
+    part, nb = None, 0
+    if want_stats and all(c is not None for c in cols):
+        nb = sum(c[0] for c in cols)
+        Nd = Op if kind == "fprop" else Ip
+        part = torch.empty(2 * Nd * nb, dtype=torch.float32, device=x.device)
+        # every slice, and so every partial column, lies inside one of the `groups` aligned batch parts: that is all
+        # a consumer with per-group statistics may assume ("img" = images per indivisible run of columns)
+        stats_out["part"], stats_out["nb"], stats_out["img"] = part, nb, B // max(groups, 1)
+    off = 0
+    for k, (b0, b1) in enumerate(ranges):
+        aff = None
+        if in_affine is not None:
+            z = b0 // (B // agr)
+            aff = (sc_t.view(agr, -1)[z], sh_t.view(agr, -1)[z], (b1 - b0,), ict)
+        _igemm_call(*grid_args(b0, b1), _mul_slice(mul, b0, b1), None, None, aff, None,
+                    None if part is None else (part, nb, off))
+        if part is not None:
+            off += cols[k][0]
+    return y
+
+
 
 
 def _mul_slice(mul, b0, b1):
@@ -1489,11 +1624,17 @@ def conv_fprop(x, wA, bias, g: ConvGeom, act=None, alpha=0.3, mul=None, stats_ou
         if tuple(out.shape) != (B, g.OH, g.OW, Op):
             raise ValueError(f"conv_fprop: out {tuple(out.shape)} != {(B, g.OH, g.OW, Op)}")
     y = out if out is not None else torch.empty(B, g.OH, g.OW, Op, dtype=torch.bfloat16, device=x.device)
-    ranges = _batch_ranges(B, max(g.H * g.W * Ip, g.OH * g.OW * Op))
+    sgroups = int(stats_out.get("groups", 1)) if stats_out is not None else 1
+    ranges = _batch_ranges(B, max(g.H * g.W * Ip, g.OH * g.OW * Op), B // sgroups if sgroups > 1 and B % sgroups == 0 else 0)
     if ranges is not None:
-        for b0, b1 in ranges:           # no BN statistics / folded BN across slices: the caller runs its own pass
-            conv_fprop(x[b0:b1], wA, bias, g, act, alpha, _mul_slice(mul, b0, b1), None, None, y[b0:b1], in_affine)
-        return y
+        if g.depthwise or (_is_1x1(g) and GEMM_SK) or wA.dim() != 4:
+            for b0, b1 in ranges:       # no BN statistics / folded BN across slices: the caller runs its own pass
+                conv_fprop(x[b0:b1], wA, bias, g, act, alpha, _mul_slice(mul, b0, b1), None, None, y[b0:b1], in_affine)
+            return y
+        if wA.shape[1:] != (g.KH, g.KW, Ip) or wA.shape[0] > Op:
+            raise ValueError(f"conv_fprop: weight {tuple(wA.shape)} vs geometry {g}")
+        _chk_w(wA, wA.shape, "kernel")
+        return _conv_slices("fprop", x, wA, bias, y, g, act, alpha, mul, stats_out, ranges, sgroups)
     if g.depthwise:
         _chk_w(wA, (g.KH, g.KW, Ip), "depthwise kernel")
         isc = ish = None
@@ -1551,23 +1692,32 @@ def conv_dgrad(dy, wB, g: ConvGeom, bias=None, act=None, alpha=0.3, mul=None, st
         if tuple(out.shape) != (B, g.H, g.W, Ip):
             raise ValueError(f"conv_dgrad: out {tuple(out.shape)} != {(B, g.H, g.W, Ip)}")
     dx = out if out is not None else torch.empty(B, g.H, g.W, Ip, dtype=torch.bfloat16, device=dy.device)
+    sgroups = int(stats_out.get("groups", 1)) if stats_out is not None else 1
+    agroups = in_affine[2] if in_affine is not None else 1
+    if B % agroups:
+        raise ValueError(f"conv_dgrad: batch {B} does not split into {agroups} groups")
+    # slices (operands beyond one launch's 32-bit offsets) never cross a batch-group boundary
+    ngr = max(sgroups, agroups) if (B % sgroups == 0 and max(sgroups, agroups) % min(sgroups, agroups) == 0) else agroups
+    ranges = _batch_ranges(B, max(g.H * g.W * Ip, g.OH * g.OW * Op), B // ngr if ngr > 1 else 0)
+    plain = g.depthwise or (_is_1x1(g) and GEMM_SK)
     if in_affine is not None:
         sc_t, sh_t, groups, ictrue = in_affine
-        if B % groups:
-            raise ValueError(f"conv_dgrad: batch {B} does not split into {groups} groups")
-        ranges0 = _batch_ranges(B, max(g.H * g.W * Ip, g.OH * g.OW * Op))
-        if g.depthwise or (_is_1x1(g) and GEMM_SK) or ranges0 is not None:
+        if plain:
             dy = bn_apply(dy, sc_t, sh_t, None, 0.3, ictrue, groups)        # no on-load path there
             in_affine = None
             if aff_sink is not None:    # `aff_sink["x"]`: the materialised operand, kept by the caller
                 aff_sink["x"] = dy
-        else:
+        elif ranges is None:
             in_affine = (sc_t, sh_t, (B // groups,), ictrue)
-    ranges = _batch_ranges(B, max(g.H * g.W * Ip, g.OH * g.OW * Op))
     if ranges is not None:
-        for b0, b1 in ranges:
-            conv_dgrad(dy[b0:b1], wB, g, bias, act, alpha, _mul_slice(mul, b0, b1), None, None, dx[b0:b1])
-        return dx
+        if plain or wB.dim() != 4:
+            for b0, b1 in ranges:
+                conv_dgrad(dy[b0:b1], wB, g, bias, act, alpha, _mul_slice(mul, b0, b1), None, None, dx[b0:b1])
+            return dx
+        if wB.shape[1:] != (g.KH, g.KW, Op) or wB.shape[0] > Ip:
+            raise ValueError(f"conv_dgrad: weight {tuple(wB.shape)} vs geometry {g}")
+        _chk_w(wB, wB.shape, "kernel")
+        return _conv_slices("dgrad", dy, wB, bias, dx, g, act, alpha, mul, stats_out, ranges, ngr, in_affine, aff_sink)
     if g.depthwise:
         _chk_w(wB, (g.KH, g.KW, Ip), "depthwise kernel")
         if bias is not None or act not in (None, "linear"):

@@ -841,6 +841,124 @@ def test_pconv_emits_batchnorm_statistics(hip, shape, B):
     assert torch.allclose(mm1, mm2, rtol=1e-4, atol=1e-6) and torch.allclose(mv1, mv2, rtol=1e-4, atol=1e-6)
 
 
+@pytest.mark.parametrize("tile", [6, 2, 22, 20, 33, 34, 35, 36, 37, 38])
+@pytest.mark.parametrize("mode", ["fprop", "dgrad"])
+def test_igemm_emits_batchnorm_statistics(hip, tile, mode):
+    """The statistics epilogue of the implicit-GEMM kernels (register-staged deep / shallow, LDS-DMA): per-block
+    partial sums of the stored (bf16) output, one column per (pixel tile, class), == a column reduction of it; the
+    output itself is untouched by the epilogue.  dgrad: four parity classes, rows past a class's end."""
+    g = G.conv2d_geom(14, 14, 64, 64, (5, 5), (2, 2), (1, 1), "same")
+    B = 37
+    torch.manual_seed(22)
+    w = r16(torch.randn(64, 5, 5, 64) / 30)
+    bias = torch.randn(64).cuda()
+    if mode == "fprop":
+        src, wgt = dev(hip, r16(torch.randn(B, 14, 14, 64))), padw(hip, w)
+        geo = (B, 14, 14, 64, 7, 7, 64, 64, (2, 2), (1, 1))
+        shape = (B, 7, 7, 64)
+    else:
+        src, wgt = dev(hip, r16(torch.randn(B, 7, 7, 64))), padw(hip, w.permute(3, 1, 2, 0).contiguous())
+        geo = (B, 7, 7, 64, 14, 14, 64, 64, (1, 1), (2, 2))
+        shape = (B, 14, 14, 64)
+    cols = hip._igemm_stats_cols(tile, g, mode, B, src.device)
+    assert cols is not None
+    nb = cols[0]
+    y = torch.empty(shape, dtype=torch.bfloat16, device="cuda")
+    y0 = torch.empty_like(y)
+    part = torch.full((2 * 64 * (nb + 3),), float("nan"), device="cuda")
+    hip._run_igemm(src, wgt, bias, y, g, mode, *geo, "leaky", 0.3, tile=tile, stats=(part, nb + 3, 2))
+    hip._run_igemm(src, wgt, bias, y0, g, mode, *geo, "leaky", 0.3, tile=tile)
+    assert torch.equal(y, y0)
+    pv = part.view(2, 64, nb + 3)
+    assert bool(torch.isnan(pv[:, :, :2]).all()) and bool(torch.isnan(pv[:, :, -1]).all())   # only its own columns
+    sums = pv[:, :, 2:2 + nb].double().sum(-1).cpu()
+    yf = y.float().reshape(-1, 64).double().cpu()
+    assert torch.allclose(sums[0], yf.sum(0), rtol=1e-4, atol=1e-2)
+    assert torch.allclose(sums[1], (yf * yf).sum(0), rtol=1e-4, atol=1e-2)
+
+
+@pytest.mark.parametrize("choice", ["pconv", 22, 34])
+def test_batch_slices_keep_statistics_and_on_load_batchnorm(hip, choice, monkeypatch):
+    """A layer split into batch slices (operands beyond one launch's offsets) keeps its fusions: every slice's
+    statistics epilogue writes into one partial array (two batch groups, slices never cross the group boundary) and
+    a BatchNorm in front of a transposed conv stays applied on load when every slice runs the patch-resident kernel
+    -- same output bits as the unsliced layer, same batch statistics."""
+    torch.manual_seed(4)
+    g = G.conv2d_geom(14, 14, 32, 64, (5, 5), (2, 2), (1, 1), "same")      # transposed: 7x7x64 -> 14x14x32
+    B, groups = 48, 2
+    dy = dev(hip, r16(torch.randn(B, 7, 7, 64)))
+    wB = padw(hip, r16(torch.randn(64, 5, 5, 32) * 0.05).permute(3, 1, 2, 0).contiguous())
+    scale = (torch.rand(groups, 64) + 0.5).cuda().reshape(-1)
+    shift = torch.randn(groups, 64).cuda().reshape(-1)
+    monkeypatch.setattr(hip, "AUTOTUNE", False)
+    if choice != "pconv":
+        monkeypatch.setattr(hip, "_conv_choice", lambda *a, **k: ("igemm", choice))
+    else:
+        def pick(src, wgt, bias, dst, g_, mode, B_, Hs, Ws, Cs, Hd, Wd, Nd, Nw, ss, *rest, **kw):
+            pl = hip._pconv_plan(g_, mode, B_, Cs, Nd, ss, src.device, min_rows=16)
+            assert pl is not None
+            return ("pconv", pl)
+        monkeypatch.setattr(hip, "_conv_choice", pick)
+
+    def run():
+        so, sink = {"groups": groups}, {}
+        out = hip.conv_dgrad(dy, wB, g, None, "relu", 0.3, stats_out=so, in_affine=(scale, shift, groups, 64),
+                             aff_sink=sink)
+        assert "part" in so
+        gamma, beta = torch.ones(32).cuda(), torch.zeros(32).cuda()
+        mm, mv = torch.zeros(32).cuda(), torch.ones(32).cuda()
+        if B % (so["img"] * groups) == 0:       # what a consumer with per-group statistics checks (network.py)
+            st = hip.bn_train_affine_from_part(so["part"], so["nb"], B * 14 * 14, gamma, beta, mm, mv, 0.99, 1e-3, True,
+                                               True, groups)
+        else:                                   # one launch, pixel tiles straddling images: the plain pass
+            assert not sliced
+            st = hip.bn_train_affine(out, gamma, beta, mm, mv, 0.99, 1e-3, True, True, groups)
+        return out, st, sink
+
+    sliced = False
+    ref, ref_st, ref_sink = run()
+    assert (choice == "pconv") == (not ref_sink)            # on load only in the patch-resident kernel
+    monkeypatch.setattr(hip, "ELEM_LIMIT", 11 * 14 * 14 * 32)          # 11 images per launch -> 8-image slices
+    assert hip._batch_ranges(B, 14 * 14 * 32, B // groups) == [(0, 8), (8, 16), (16, 24), (24, 32), (32, 40), (40, 48)]
+    monkeypatch.setattr(hip, "ELEM_LIMIT", 13 * 14 * 14 * 32)          # 8-image slices, 24-image groups: (16, 24) ...
+    assert (16, 24) in hip._batch_ranges(B, 14 * 14 * 32, B // groups)
+    monkeypatch.setattr(hip, "ELEM_LIMIT", 21 * 14 * 14 * 32)          # 16-image slices: (0,16) (16,24) | (24,40) (40,48)
+    assert hip._batch_ranges(B, 14 * 14 * 32, B // groups) == [(0, 16), (16, 24), (24, 40), (40, 48)]
+    sliced = True
+    got, got_st, sink = run()
+    assert torch.equal(got, ref)
+    assert (choice == "pconv") == (not sink)
+    for u, v in zip(got_st, ref_st):
+        assert torch.allclose(u, v, rtol=1e-4, atol=1e-5)
+    # against the plain pass over the output
+    gamma, beta = torch.ones(32).cuda(), torch.zeros(32).cuda()
+    plain = hip.bn_train_affine(got, gamma, beta, torch.zeros(32).cuda(), torch.ones(32).cuda(), 0.99, 1e-3, True, True,
+                                groups)
+    for u, v in zip(got_st, plain):
+        assert torch.allclose(u, v, rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.parametrize("groups", [1, 2])
+def test_wide_partials_are_folded_before_the_finalize(hip, groups, monkeypatch):
+    """BatchNorm statistics from very many partial columns (one per image and row band at HBM-sized batches): the
+    64-fold pre-reduction gives the statistics of the direct finalize."""
+    torch.manual_seed(8)
+    Cp, nb, rows = 32, 2 * 9001, 2 * 9001 * 7
+    part = torch.randn(2, Cp, nb, device="cuda")
+    part[1] = part[1].abs() * 7 + 40                 # sums of squares: keep the variances positive
+    outs = []
+    for lim in (1 << 30, 1000):
+        monkeypatch.setattr(hip, "FOLD_PARTIALS_MIN", lim)
+        gamma, beta = torch.rand(Cp).cuda() + 0.5, torch.randn(Cp).cuda()
+        torch.manual_seed(9)
+        mm, mv = torch.zeros(Cp).cuda(), torch.ones(Cp).cuda()
+        st = hip.bn_train_affine_from_part(part.reshape(-1), nb, rows, torch.ones(Cp).cuda(), torch.zeros(Cp).cuda(), mm,
+                                           mv, 0.9, 1e-3, True, True, groups)
+        outs.append([t.clone() for t in st] + [mm, mv])
+    for u, v in zip(*outs):
+        assert torch.allclose(u, v, rtol=1e-5, atol=1e-6)
+
+
 def test_batch_split_launches_for_tensors_beyond_32bit_addressing(hip, monkeypatch):
     """Tensors of >= 2^31 elements are split along the batch into several launches (BASELINE config 4: batch sized to
     HBM).  Exercised here with an artificially small limit: fprop / dgrad / one-channel ops give the same bits as one
