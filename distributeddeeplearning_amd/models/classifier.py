@@ -357,7 +357,7 @@ class ReplicaGroupStep:
         self.members, self.dp, self.mode = members, dp, mode
         self.idx = idx.clone()
         self.on_gpu = idx.is_cuda
-        self.comm = torch.cuda.Stream() if self.on_gpu else None
+        self.comm = torch.cuda.Stream(priority=-1) if self.on_gpu else None
         self.losses = None
         self.graphs = None
         if mode == "eager" or not self.on_gpu:

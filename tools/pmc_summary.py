@@ -76,7 +76,7 @@ def main():
     print("per-dispatch means over the timed steps; `us` is the dispatch time UNDER counter collection "
           "(serialised, slower than in the kernel trace); HBM GB/s = (FETCH_SIZE + WRITE_SIZE) KB / us; "
           "mfma = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE * 256 CUs), MFMA-pipe busy cycles per CU per GPU-active cycle "
-          "(4 SIMDs per CU: 4.0 would be every matrix pipe busy all the time); lds conflict % = SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE; "
+          "(a dense back-to-back MFMA loop reads 0.5 on this scale -- calibrated in round 3 -- so 0.19 is 38 % of the matrix pipes' time); lds conflict % = SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE; "
           "wait % = SQ_WAIT_ANY / SQ_WAVE_CYCLES\n")
     print("| kernel | calls | us | read MB | write MB | HBM GB/s | mfma | lds conflict % | wait % | waves |")
     print("|---|---:|---:|---:|---:|---:|---:|---:|---:|---:|")
