@@ -31,6 +31,7 @@ from ..utils.data import Data, Sample
 from .network import Network
 from .optim import FlatOptimizer
 from .search import CompiledSpec
+from ..utils.streams import comm_stream
 
 
 class RandomModel:
@@ -357,7 +358,7 @@ class ReplicaGroupStep:
         self.members, self.dp, self.mode = members, dp, mode
         self.idx = idx.clone()
         self.on_gpu = idx.is_cuda
-        self.comm = torch.cuda.Stream(priority=-1) if self.on_gpu else None
+        self.comm = comm_stream() if self.on_gpu else None
         self.losses = None
         self.graphs = None
         if mode == "eager" or not self.on_gpu:

@@ -37,6 +37,7 @@ from ..utils import hipgraph
 from . import ir
 from .network import ConvOp, Network
 from .optim import FlatOptimizer, OptimConfig, ShardedFlatOptimizer
+from ..utils.streams import comm_stream
 
 NOISE_DIM = 128
 
@@ -168,7 +169,7 @@ class GANTrainer:
         # of a network are ONE kernel, so the separate optimizer launches disappear from the step
         self.fused = bool(dp is not None and not self.sharded and self.G.on_gpu
                           and getattr(dp, "supports_fused_update", False))
-        self._comm_stream = torch.cuda.Stream(priority=-1) if (dp is not None and self.G.on_gpu) else None
+        self._comm_stream = comm_stream() if (dp is not None and self.G.on_gpu) else None
         # Gradient buckets (Network.grad_buckets): the tail of each flat gradient buffer -- D: conv3 + BN + head, 0.8
         # of its 1.04 MB; G: the transposed convolutions -- is all-reduced on the communication stream as soon as
         # its last layer's backward has been issued, under the rest of the backward pass; only the bucket that
@@ -537,7 +538,7 @@ class GraphedGANStep:
             # A | all-reduce(D grads) on the comm stream || B1 (G forward) | B2 | all-reduce(G grads) | C
             # (segments cannot contain an eager collective, so the bucket hooks are off in this mode)
             t.buckets = False
-            self.comm_stream = torch.cuda.Stream(priority=-1)
+            self.comm_stream = comm_stream()
             fns = [lambda: t.phase_a(self.real), lambda: t.phase_b1(self.B), lambda: t.phase_b2(self.B), t.phase_c]
             if t.merged:            # the G-phase forward is part of phase A's merged generator pass
                 fns.pop(1)

@@ -1262,6 +1262,17 @@ _IGEMM_BM = {1: 256, 2: 64, 3: 256, 4: 128, 5: 256, 6: 128, 8: 64, 33: 128, 34: 
 _IGEMM_NO_STATS = ()
 
 
+def _igemm_ksplit(g, mode, Cs, Nd, maxM, ncls, tile):
+    """Split-K factor of the implicit-GEMM launch: a Dense / 1x1 fprop with few output tiles and a very long reduction
+    (model0's 86528 -> 10 head at batch 512 is TWO 256-row blocks walking 2704 k-steps each) is spread over K."""
+    if mode == "fprop" and ncls == 1 and _is_1x1(g) and (tile or 0) < 32:
+        nsteps = (g.KH * g.KW * Cs + 63) // 64
+        blocks = -(-maxM // 256) * -(-Nd // 128)
+        if blocks < 128 and nsteps >= 32:
+            return max(1, min(nsteps // 8, 512 // blocks))
+    return 1
+
+
 def _igemm_stats_cols(tile, g, mode, B, device):
     """(partial columns, images per column) of the implicit-GEMM kernels' statistics epilogue for this tile, or None
     when the tile has none (heuristic tile, classes of different sizes).  A column is one pixel tile of one class
@@ -1277,6 +1288,8 @@ def _igemm_stats_cols(tile, g, mode, B, device):
     if len(hw) != 1:
         return None
     hw, BM = hw.pop(), _IGEMM_BM[t]
+    if _igemm_ksplit(g, mode, pad8(g.I), pad8(g.O), B * hw, len(cl_), tile) > 1:
+        return None                     # the split-K path finishes in its own kernel: no statistics epilogue
     img = BM // hw if BM % hw == 0 else (1 if hw % BM == 0 else B + 1)
     return -(-(B * hw) // BM) * len(cl_), img
 
@@ -1290,16 +1303,9 @@ def _run_igemm(src, wgt, bias, dst, g, mode, B, Hs, Ws, Cs, Hd, Wd, Nd, Nw, ss, 
     tile = IGEMM_TILE if tile is None else tile
     if tile >= 32 and not (ut_all and Cs % 32 == 0):
         raise ValueError(f"igemm tile {tile} (LDS-DMA staging) needs uniform-tap tables and Cs % 32 == 0: {g} Cs={Cs}")
-    # split-K: a Dense / 1x1 fprop with few output tiles and a very long reduction (model0's 86528 -> 10
-    # head at batch 512 is TWO 256-row blocks walking 2704 k-steps each) is spread over the K axis
-    ksplit, slab = 1, None
-    if mode == "fprop" and ncls == 1 and _is_1x1(g):
-        nsteps = (g.KH * g.KW * Cs + 63) // 64
-        blocks = -(-maxM // 256) * -(-Nd // 128)
-        if blocks < 128 and nsteps >= 32 and tile < 32:
-            ksplit = max(1, min(nsteps // 8, 512 // blocks))
-            if ksplit > 1:
-                slab = torch.empty(ksplit * maxM * Nd, dtype=torch.float32, device=src.device)
+    ksplit, slab = _igemm_ksplit(g, mode, Cs, Nd, maxM, ncls, tile), None
+    if ksplit > 1:
+        slab = torch.empty(ksplit * maxM * Nd, dtype=torch.float32, device=src.device)
     _ms = _mul_slope(mul, dst) if ACT_CODE[act] in (0, 1, 6) else None
     if stats is not None:
         if mul is not None or slab is not None:

@@ -20,6 +20,7 @@ from typing import List, Optional
 import torch
 
 from ..ops import functional as F
+from ..utils.streams import comm_stream
 
 
 class PeriodicAverager:
@@ -37,7 +38,7 @@ class PeriodicAverager:
     def attach(self, net):
         self.nets.append(net)
         if net.on_gpu and self._side is None:
-            self._side = torch.cuda.Stream(device=net.device, priority=-1)
+            self._side = comm_stream(net.device)
         # snapshot / sum / statistics buffers are allocated ONCE per network: an average allocates nothing, so the
         # side-stream work is a fixed sequence of copies + collectives on fixed addresses (capturable, no allocator
         # traffic between streams)

@@ -5,9 +5,9 @@ mkdir -p gpurun_out
 filt="$1"; shift
 if [ "$filt" != "skip" ]; then
   if [ -n "$filt" ] && [ "$filt" != "all" ]; then
-    timeout -k 10 900 python -u -m pytest tests -m gpu -q -x --timeout 300 --timeout-method thread -k "$filt" > gpurun_out/gpu_tests.log 2>&1; rc=$?
+    timeout -k 10 900 python -u -m pytest tests -m gpu -v -x --timeout 150 --timeout-method thread -k "$filt" > gpurun_out/gpu_tests.log 2>&1; rc=$?
   else
-    timeout -k 10 900 python -u -m pytest tests -m gpu -q -x --timeout 300 --timeout-method thread > gpurun_out/gpu_tests.log 2>&1; rc=$?
+    timeout -k 10 900 python -u -m pytest tests -m gpu -v -x --timeout 150 --timeout-method thread > gpurun_out/gpu_tests.log 2>&1; rc=$?
   fi
   echo "tests_rc=$rc"; tail -15 gpurun_out/gpu_tests.log; [ $rc -eq 0 ] || exit 1
 fi
