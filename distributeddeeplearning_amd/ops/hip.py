@@ -1543,6 +1543,34 @@ def _batch_ranges(B: int, per_image: int, align: int = 0):
     return out
 
 
+GROUP_SPLIT = os.environ.get("DDL_CONV_GROUP_SPLIT", "1") == "1"
+
+
+def _group_split(kind, x, w, bias, y, g, act, alpha, mul, stats_out, groups):
+    """Ranges that run ONE launch per batch group -- when the BatchNorm behind the layer keeps statistics per group and
+    the kernel chosen for the whole batch is an implicit-GEMM tile whose pixel tiles straddle images (its partial
+    columns then cannot be split by group, and the consumer would fall back to a pass over the output).  None: the
+    single launch is fine."""
+    if not (GROUP_SPLIT and CONV_IMPL == "pconv" and PCONV_STATS and stats_out is not None and mul is None
+            and groups > 1 and x.shape[0] % groups == 0):
+        return None
+    B, Ip, Op = x.shape[0], pad8(g.I), pad8(g.O)
+    if kind == "fprop":
+        ga = (x, w, bias, y, g, "fprop", B, g.H, g.W, Ip, g.OH, g.OW, Op, min(w.shape[0], g.O), (g.sh, g.sw), (1, 1),
+              act, alpha)
+    else:
+        ga = (x, w, bias, y, g, "dgrad", B, g.OH, g.OW, Op, g.H, g.W, Ip, min(w.shape[0], g.I), (1, 1), (g.sh, g.sw),
+              act, alpha)
+    ch = _conv_choice(*ga, mul=None, want_stats=True)
+    if ch[0] != "igemm":
+        return None
+    cols = _igemm_stats_cols(ch[1], g, ga[5], B, x.device)
+    if cols is None or B % (cols[1] * groups) == 0:
+        return None
+    step = B // groups
+    return [(b, b + step) for b in range(0, B, step)]
+
+
 def _conv_slices(kind, x, w, bias, y, g, act, alpha, mul, stats_out, ranges, groups, in_affine=None, aff_sink=None):
     """A convolution whose operands exceed the 32-bit element offsets of one launch, as batch slices -- with the
     fusions of the unsliced path kept: every slice's kernel is chosen first (tuning it if this is its first call), then
@@ -1641,6 +1669,12 @@ def conv_fprop(x, wA, bias, g: ConvGeom, act=None, alpha=0.3, mul=None, stats_ou
             raise ValueError(f"conv_fprop: weight {tuple(wA.shape)} vs geometry {g}")
         _chk_w(wA, wA.shape, "kernel")
         return _conv_slices("fprop", x, wA, bias, y, g, act, alpha, mul, stats_out, ranges, sgroups)
+    if not (g.depthwise or (_is_1x1(g) and GEMM_SK)) and wA.dim() == 4 and wA.shape[1:] == (g.KH, g.KW, Ip) \
+            and wA.shape[0] <= Op and in_affine is None and bn_infer is None:
+        gr = _group_split("fprop", x, wA, bias, y, g, act, alpha, mul, stats_out, sgroups)
+        if gr is not None:
+            _chk_w(wA, wA.shape, "kernel")
+            return _conv_slices("fprop", x, wA, bias, y, g, act, alpha, mul, stats_out, gr, sgroups)
     if g.depthwise:
         _chk_w(wA, (g.KH, g.KW, Ip), "depthwise kernel")
         isc = ish = None
@@ -1724,6 +1758,13 @@ def conv_dgrad(dy, wB, g: ConvGeom, bias=None, act=None, alpha=0.3, mul=None, st
             raise ValueError(f"conv_dgrad: weight {tuple(wB.shape)} vs geometry {g}")
         _chk_w(wB, wB.shape, "kernel")
         return _conv_slices("dgrad", dy, wB, bias, dx, g, act, alpha, mul, stats_out, ranges, ngr, in_affine, aff_sink)
+    if not plain and wB.dim() == 4 and wB.shape[1:] == (g.KH, g.KW, Op) and wB.shape[0] <= Ip and bn_infer is None \
+            and ngr == sgroups:
+        gr = _group_split("dgrad", dy, wB, bias, dx, g, act, alpha, mul, stats_out, sgroups)
+        if gr is not None:
+            _chk_w(wB, wB.shape, "kernel")
+            aff0 = None if in_affine is None else (in_affine[0], in_affine[1], B // in_affine[2][0], in_affine[3])
+            return _conv_slices("dgrad", dy, wB, bias, dx, g, act, alpha, mul, stats_out, gr, ngr, aff0, aff_sink)
     if g.depthwise:
         _chk_w(wB, (g.KH, g.KW, Ip), "depthwise kernel")
         if bias is not None or act not in (None, "linear"):
