@@ -798,19 +798,31 @@ void igemm_conv_kernel_dma(const ConvArgs a, const int n_ntiles, const int n_mti
     const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc(
         (void*)a.wgt, 0, (int)((unsigned)a.Nw * a.Ttot * Cs * 2u), 0x00020000);
 
-    // the tap table is read through the constant address space: beside the LDS-DMA (which the compiler treats as a
-    // store to unknown memory) an ordinary load of it is not provably invariant, becomes a VECTOR load and drags a
-    // vmcnt(0) into every K step
-    const_i32x4* gtaps = (const_i32x4*)(unsigned long)(a.taps + cd.tap_off);
+    // The class's tap table sits in LDS behind the stage buffers and the current entry is kept in SGPRs.  It is
+    // re-read (one broadcast ds_read + readfirstlane, once per tap) at the END of a K step: a scalar load anywhere
+    // in the loop would be outstanding on the LGKM counter while the fragment reads are issued, and with scalar
+    // memory's out-of-order return the compiler then waits lgkmcnt(0) before the first MFMA instead of only for the
+    // fragments that MFMA consumes.  (An ordinary global load of the table is worse still: beside the LDS-DMA, which
+    // the compiler treats as a store to unknown memory, it is not provably invariant, becomes a VECTOR load and
+    // drags a vmcnt(0) into every K step.)
+    const int4* sT = (const int4*)(smem + STAGES * (BM + BNL) * PITCH1);
+    for (int i = tid; i <= cd.ntaps; i += 256) ((int4*)sT)[i] = a.taps[cd.tap_off + i];   // + the spare entry
+    __syncthreads();
     const int last_tap = max(cd.ntaps - 1, 0);
     const int nsteps = cd.ntaps * (Cs >> 5);
     int ut_tap = 0, ut_c = 0;
-    i32x4 te = gtaps[0];             // uniform address: scalar loads (the table ends with a spare entry)
+    int te_x, te_y, te_z, te_w;
+    auto load_te = [&]() {
+        const int4 v = sT[min(ut_tap, last_tap)];
+        te_x = __builtin_amdgcn_readfirstlane(v.x); te_y = __builtin_amdgcn_readfirstlane(v.y);
+        te_z = __builtin_amdgcn_readfirstlane(v.z); te_w = __builtin_amdgcn_readfirstlane(v.w);
+    };
+    load_te();
     auto issue = [&](int buf) {
         const bool tv = ut_tap < cd.ntaps;
-        const unsigned soffA = (unsigned)(((te.x * a.Ws + te.y) * Cs + ut_c) * 2);
-        const unsigned soffW = (unsigned)((te.z * Cs + ut_c) * 2);
-        const unsigned bit = tv ? 1u << te.w : 0u;
+        const unsigned soffA = (unsigned)(((te_x * a.Ws + te_y) * Cs + ut_c) * 2);
+        const unsigned soffW = (unsigned)((te_z * Cs + ut_c) * 2);
+        const unsigned bit = tv ? 1u << te_w : 0u;
 #pragma unroll
         for (int r = 0; r < PA; ++r) {
             const unsigned off = (vmask[r] & bit) ? rowoff[r] + soffA : 0xFFFFFFF0u;
@@ -823,11 +835,13 @@ void igemm_conv_kernel_dma(const ConvArgs a, const int n_ntiles, const int n_mti
             __builtin_amdgcn_raw_ptr_buffer_load_lds(
                 rsW, (lds_void*)(sW + ((buf * BNL + (wave * PW + r) * 16) * PITCH1)), 16, off, 0, 0, 0);
         }
+    };
+    auto next_stage = [&]() {            // K position of the next issue
         ut_c += 32;
         if (ut_c >= Cs) {
             ut_c = 0;
             ++ut_tap;
-            te = gtaps[min(ut_tap, last_tap)];
+            load_te();
         }
     };
 
@@ -839,7 +853,7 @@ void igemm_conv_kernel_dma(const ConvArgs a, const int n_ntiles, const int n_mti
 
     // prologue: STAGES - 1 stages in flight (stages beyond the reduction fetch zeros: the counts below stay uniform)
 #pragma unroll
-    for (int d = 0; d < STAGES - 1; ++d) issue(d);
+    for (int d = 0; d < STAGES - 1; ++d) { issue(d); next_stage(); }
 
     const int fr = lane & 15, fq = lane >> 4;
     const int fqsw = (fq ^ ((-(fr >> 2)) & 3)) * 16;
@@ -863,11 +877,14 @@ void igemm_conv_kernel_dma(const ConvArgs a, const int n_ntiles, const int n_mti
         // all fragment reads in flight before the first MFMA (left alone the scheduler reuses one weight register
         // quad and serialises a read's latency with every group of MT MFMAs)
         __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(1);          // the MFMA cluster keeps the pipe over the other block's issue work
 #pragma unroll
         for (int j = 0; j < MT; ++j)
 #pragma unroll
             for (int i = 0; i < NT; ++i)
                 acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], xf[j], acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+        next_stage();
         if (++cur == STAGES) cur = 0;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // trailing zero-fill stages: nothing may land after exit
@@ -927,7 +944,7 @@ static int launch_igemm_dma(const ConvArgs& a, int n_classes, int max_M, hipStre
     // whole 32-channel K stages and no split-K
     if (a.ksplit > 1 || (a.Cs & 31)) return -6;
     constexpr int BNL = BN < 64 ? 64 : BN;
-    const size_t smem = (size_t)STAGES * (BM + BNL) * PITCH1;
+    const size_t smem = (size_t)STAGES * (BM + BNL) * PITCH1 + ((size_t)a.max_taps + 1) * sizeof(int4);
     auto kern = igemm_conv_kernel_dma<BM, BN, WAVES_M, STAGES>;
     if (smem > 64 * 1024) {
         static bool done = false;

@@ -33,6 +33,11 @@ struct Wg2Args {
     int tiles_c, ngroups;
     int scx8, sny8;                    // 16-byte channel units staged per pixel: min(Cx, TC) / 8, min(Ny, TN) / 8
     float inv_xper_img, inv_cx8, inv_PW, inv_yrow, inv_OW, inv_rows;
+    // LDS-DMA staging (DMA instantiations): two (X patch, dY tile) buffers of buf_bytes each, filled 16-byte chunk by
+    // chunk INCLUDING the pitch padding (chunk u of the padded image -> LDS byte 16 u: one wave-instruction is one
+    // contiguous KiB); rx / ry = chunks per thread of the X / dY section, xcpp / ycpp = chunks per pixel
+    int buf_bytes, rx, ry, xcpp, ycpp;
+    float inv_xcpp, inv_ycpp, inv_phpw;
 };
 
 __device__ __forceinline__ int fdiv2(int x, float inv) { return __float2int_rz(((float)x + 0.5f) * inv); }
@@ -43,12 +48,33 @@ __device__ __forceinline__ s16x4 tr_read2(const char* p) {
 
 // NW = waves per block.  NW = 8 (one 512-thread block per CU, two waves per SIMD) shares one staged unit among
 // twice the waves: twice the loads in flight while staging and half the taps per wave in the MFMA phase.
-template <int TN, int TC, int TPW, int NW>
+// DMA: the unit's X patch and dY tile are staged by `buffer_load_dwordx4 ... lds` into one of TWO LDS buffers while
+// the MFMA phase of the previous unit runs out of the other.  Measured on the register-staged form (ablation, B = 65536
+// 16x16x64 -> 8x8x128): staging alone 1.43 ms, MFMA phase alone 1.40 ms, together 2.49 ms -- the two phases barely
+// overlapped, and the staging pushed every byte through VGPRs and a ds_write_b128.  The padded pixel pitches the
+// transposing LDS reads want are kept: the DMA walks the PADDED image chunk by chunk and the padding chunks (like halo
+// pixels, missing images and rows) fetch an out-of-range offset, which writes zeros and moves no data.
+// The DMA is issued through inline asm: behind the builtin the compiler waits vmcnt(0) in front of the transposing LDS
+// reads of the MFMA phase (it cannot tell them from readers of the buffer in flight) and the overlap is gone.  Hidden
+// in asm the loads are ours to wait for -- one vmcnt(0) in front of the barrier that publishes a buffer.  The
+// compiler's own vmcnt waits stay safe: loads complete in order, ours only make it wait longer, never shorter.
+typedef unsigned int w2_u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ w2_u32x4 w2_rsrc_words(const void* p, unsigned bytes) {
+    const unsigned long a = (unsigned long)p;
+    return (w2_u32x4){(unsigned)a, (unsigned)(a >> 32) & 0xffffu, bytes, 0x00020000u};
+}
+__device__ __forceinline__ void w2_dma16(w2_u32x4 rs, unsigned voff, unsigned lds_base) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(rs), "s"(lds_base) : "memory");
+}
+
+template <int TN, int TC, int TPW, int NW, bool DMA = false>
 __global__ __launch_bounds__(64 * NW, (NW == 8 || TPW * (TN / 16) * (TC / 16) * 4 > 160 ? 1 : 2)) void wgrad2_kernel(const Wg2Args a) {
     constexpr int SN = TN / 16, SC = TC / 16, NT = 64 * NW;
     // the one-block-per-CU variants (512-register budget) whose fragment sets leave room: they stage with deeper
     // rounds and keep the next unit's first round in flight during the MFMA phase
-    constexpr bool PIPE = NW == 4 && TPW * SN * SC * 4 > 160 && (SN + TPW * SC) * 8 <= 160;
+    constexpr bool PIPE = !DMA && NW == 4 && TPW * SN * SC * 4 > 160 && (SN + TPW * SC) * 8 <= 160;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* sX = smem;
     char* sY = smem + a.y_off;
@@ -166,7 +192,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 || TPW * (TN / 16) * (TC / 16) * 
     };
     // ---- every wave walks all 32-pixel slices; its taps' accumulators stay in registers.  All of a
     // slice's fragments are fetched first (one burst of transposing LDS reads), then the MFMAs run.
-    auto load = [&](int m0, bf16x8_t (&fy)[SN], bf16x8_t (&fx)[TPW][SC]) {
+    auto load = [&](int m0, bf16x8_t (&fy)[SN], bf16x8_t (&fx)[TPW][SC], const char* sX, const char* sY) {
         const int plo = m0 + 4 * g + tq, phi = plo + 16;
         const int xlo = sTbl[plo < a.Mmax ? plo : 0], xhi = sTbl[phi < a.Mmax ? phi : 0];
 #pragma unroll
@@ -199,12 +225,65 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 || TPW * (TN / 16) * (TC / 16) * 
                     acc[q][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fy[i], fx[q][j], acc[q][i][j], 0, 0, 0);
     };
 
+    if constexpr (DMA) {
+        const int wv = __builtin_amdgcn_readfirstlane(wave);
+        const int phpw = a.PH * a.PW;
+        const w2_u32x4 dX = w2_rsrc_words(a.x, (unsigned)a.B * a.H * a.W * a.Cx * 2u);
+        const w2_u32x4 dY = w2_rsrc_words(a.dy, (unsigned)a.B * a.OH * a.OW * a.Ny * 2u);
+        const unsigned lds0 = (unsigned)(unsigned long)(__attribute__((address_space(3))) char*)smem;
+        auto dma_issue = [&](int unit, int buf) {
+            const int grp = unit / a.bands, band = unit - grp * a.bands;
+            const int b0 = grp * a.IMG, i0 = band * a.BR;
+            const int row0 = i0 * a.sh - a.pt, col0 = -a.pl;
+            const unsigned xb = lds0 + buf * a.buf_bytes;
+            for (int r = 0; r < a.rx; ++r) {
+                const int u = r * NT + tid;                              // chunk of the padded patch image
+                const int pixl = fdiv2(u, a.inv_xcpp), c16 = u - pixl * a.xcpp;
+                const int img = fdiv2(pixl, a.inv_phpw), pix = pixl - img * phpw;
+                const int pr = fdiv2(pix, a.inv_PW), pc = pix - pr * a.PW;
+                const int sr = row0 + pr, sc = col0 + pc, bb = b0 + img;
+                const bool ok = (c16 < cx8) & (img < a.IMG) & (bb < a.B) & ((unsigned)sr < (unsigned)a.H) &
+                                ((unsigned)sc < (unsigned)a.W) & (c0 + c16 * 8 < a.Cx);
+                const unsigned off = ok ? (unsigned)(((bb * a.H + sr) * a.W + sc) * a.Cx + c0 + c16 * 8) * 2u : OOB_OFF;
+                w2_dma16(dX, off, xb + (r * NT + wv * 64) * 16);
+            }
+            const unsigned yb = xb + a.y_off;
+            const int nrow = min(a.BR, a.OH - i0);
+            for (int r = 0; r < a.ry; ++r) {
+                const int u = r * NT + tid;
+                const int m = fdiv2(u, a.inv_ycpp), c16 = u - m * a.ycpp;
+                const int img = fdiv2(m, a.inv_rows), rem = m - img * (a.BR * a.OW);
+                const int il = fdiv2(rem, a.inv_OW), jl = rem - il * a.OW;
+                const int bb = b0 + img;
+                const bool ok = (c16 < ny8) & (m < a.Mmax) & (bb < a.B) & (il < nrow) & (n0 + c16 * 8 < a.Ny);
+                const unsigned off = ok ? (unsigned)(((bb * a.OH + i0 + il) * a.OW + jl) * a.Ny + n0 + c16 * 8) * 2u : OOB_OFF;
+                w2_dma16(dY, off, yb + (r * NT + wv * 64) * 16);
+            }
+        };
+        int cur = 0;
+        if ((int)blockIdx.x < a.n_units) dma_issue(blockIdx.x, 0);
+        for (int unit = blockIdx.x; unit < a.n_units; unit += gridDim.x) {
+            // this unit's DMA has landed (every wave waits for its own, the barrier publishes them) and every wave is
+            // done with the MFMA phase that read the other buffer
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            const int next = unit + gridDim.x;
+            if (next < a.n_units) dma_issue(next, cur ^ 1);             // lands during this unit's MFMA phase
+            const char* xb = smem + cur * a.buf_bytes;
+            for (int m0 = 0; m0 < a.Mmax; m0 += 32) {
+                bf16x8_t fy[SN], fx[TPW][SC];
+                load(m0, fy, fx, xb, xb + a.y_off);
+                mma(fy, fx);
+            }
+            cur ^= 1;
+        }
+    }
     u32x4_t vP[PIPE ? NLD : 1];                    // PIPE: round 0 of the unit about to be staged
     int dP[PIPE ? NLD : 1];
     if constexpr (PIPE) {
         if (blockIdx.x < a.n_units) issue(blockIdx.x, 0, vP, dP);
     }
-    for (int unit = blockIdx.x; unit < a.n_units; unit += gridDim.x) {
+    for (int unit = blockIdx.x; !DMA && unit < a.n_units; unit += gridDim.x) {
         __syncthreads();                          // previous unit fully consumed (also orders the tables)
         {
             u32x4_t vA[NLD], vB[NLD];
@@ -239,7 +318,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 || TPW * (TN / 16) * (TC / 16) * 
         }
         for (int m0 = 0; m0 < a.Mmax; m0 += 32) {
             bf16x8_t fy[SN], fx[TPW][SC];
-            load(m0, fy, fx);
+            load(m0, fy, fx, sX, sY);
             mma(fy, fx);
         }
     }
@@ -364,18 +443,29 @@ DDL_API int ddl_slab_reduce_frag(const float* slab, float* out, int nsplit, int 
     return 0;
 }
 
-template <int TN, int TC, int TPW, int NW>
+template <int TN, int TC, int TPW, int NW, bool DMA = false>
 static int launch_wg2(const Wg2Args& a, int nsplit, int tiles, size_t smem, hipStream_t s) {
     if (smem > 64 * 1024) {
         static bool done = false;
         if (!done) {
-            hipFuncSetAttribute((const void*)wgrad2_kernel<TN, TC, TPW, NW>, hipFuncAttributeMaxDynamicSharedMemorySize,
+            hipFuncSetAttribute((const void*)wgrad2_kernel<TN, TC, TPW, NW, DMA>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 160 * 1024);
             done = true;
         }
     }
-    wgrad2_kernel<TN, TC, TPW, NW><<<dim3(nsplit, a.ngroups, tiles), 64 * NW, smem, s>>>(a);
+    wgrad2_kernel<TN, TC, TPW, NW, DMA><<<dim3(nsplit, a.ngroups, tiles), 64 * NW, smem, s>>>(a);
     return 0;
+}
+
+// LDS bytes of the DMA form: two buffers whose X and dY sections are whole rounds of one 16-byte chunk per thread
+static long wg2_dma_section(long chunks, int NT) { return (chunks + NT - 1) / NT * NT * 16; }
+
+DDL_API int ddl_wgrad2_lds_dma(int IMG, int BR, int OW, int PH, int PW, int xpitch, int ypitch, int taps, int NW) {
+    const int NT = 64 * NW;
+    long mpad = ((long)IMG * BR * OW + 31) / 32 * 32;
+    long buf = wg2_dma_section((long)IMG * PH * PW * (xpitch / 16), NT) + wg2_dma_section(mpad * (ypitch / 16), NT);
+    long tot = 2 * buf + ((long)IMG * BR * OW * 4 + 15) / 16 * 16 + ((long)taps * 4 + 15) / 16 * 16;
+    return tot > (1L << 30) ? -1 : (int)tot;
 }
 
 DDL_API int ddl_wgrad2_lds(int IMG, int BR, int OW, int Ny, int PH, int PW, int xpitch, int ypitch, int taps) {
@@ -393,6 +483,8 @@ DDL_API int ddl_conv_wgrad2(const void* dy, const void* x, float* slab, long num
                             int xpitch, int ypitch, int TN, int TC, int TPW, int NW, int ngroups, int frag, hipStream_t s) {
     if (Ny % 8 || Cx % 8 || nsplit < 1 || IMG < 1 || BR < 1 || ngroups < 1) return -1;
     if ((long)B * OH * OW * Ny >= (1L << 31) || (long)B * H * W * Cx >= (1L << 31)) return -3;
+    const bool dma = (frag >> 1) & 1;          // bit 1 of `frag`: LDS-DMA staging, double-buffered
+    frag &= 1;
     Wg2Args a;
     a.dy = (const bf16_t*)dy; a.x = (const bf16_t*)x; a.slab = slab;
     a.B = B; a.OH = OH; a.OW = OW; a.Ny = Ny; a.H = H; a.W = W; a.Cx = Cx;
@@ -412,6 +504,19 @@ DDL_API int ddl_conv_wgrad2(const void* dy, const void* x, float* slab, long num
     a.y_off = (int)xbytes;
     a.t_off = (int)(xbytes + mpad * ypitch);
     a.k_off = a.t_off + ((a.Mmax * 4 + 15) / 16 * 16);
+    a.buf_bytes = 0; a.rx = a.ry = 0; a.xcpp = xpitch / 16; a.ycpp = ypitch / 16;
+    a.inv_xcpp = 1.0f / (float)a.xcpp; a.inv_ycpp = 1.0f / (float)a.ycpp; a.inv_phpw = 1.0f / (float)(a.PH * a.PW);
+    if (dma) {
+        const int NT = 64 * NW;
+        const long nxc = (long)IMG * a.PH * a.PW * a.xcpp, nyc = mpad * a.ycpp;
+        const long xsec = wg2_dma_section(nxc, NT), ysec = wg2_dma_section(nyc, NT);
+        if (nxc >= (1L << 22) || nyc >= (1L << 22)) return -2;
+        a.rx = (int)(xsec / (NT * 16)); a.ry = (int)(ysec / (NT * 16));
+        a.y_off = (int)xsec;
+        a.buf_bytes = (int)(xsec + ysec);
+        a.t_off = 2 * a.buf_bytes;
+        a.k_off = a.t_off + ((a.Mmax * 4 + 15) / 16 * 16);
+    }
     size_t smem = (size_t)a.k_off + (size_t)(KH * KW * 4 + 15) / 16 * 16;
     if (smem > 160 * 1024) return -2;
     int tiles_n = (n_lim + TN - 1) / TN;
@@ -425,6 +530,13 @@ DDL_API int ddl_conv_wgrad2(const void* dy, const void* x, float* slab, long num
     a.inv_OW = 1.0f / (float)OW;
     a.inv_rows = 1.0f / (float)(BR * OW);
     int tiles = tiles_n * a.tiles_c;
+    if (dma) {
+#define W2_DMA(TN_, TC_, TPW_, NW_) if (NW == NW_ && TN == TN_ && TC == TC_ && TPW == TPW_) return launch_wg2<TN_, TC_, TPW_, NW_, true>(a, nsplit, tiles, smem, s);
+        W2_DMA(64, 64, 2, 8) W2_DMA(64, 32, 4, 8) W2_DMA(32, 64, 4, 8) W2_DMA(32, 32, 4, 8)
+        W2_DMA(64, 32, 7, 4) W2_DMA(64, 32, 4, 4) W2_DMA(32, 32, 7, 4) W2_DMA(32, 32, 4, 4)
+#undef W2_DMA
+        return -4;
+    }
 #define W2_CASE8(TN_, TC_, TPW_) if (NW == 8 && TN == TN_ && TC == TC_ && TPW == TPW_) return launch_wg2<TN_, TC_, TPW_, 8>(a, nsplit, tiles, smem, s);
     W2_CASE8(64, 64, 2) W2_CASE8(64, 32, 4) W2_CASE8(32, 64, 4) W2_CASE8(32, 32, 4)
 #undef W2_CASE8

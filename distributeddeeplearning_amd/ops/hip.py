@@ -96,6 +96,7 @@ _wgrad2 = _sig("ddl_conv_wgrad2", ci, vp, vp, vp, cl, ci, ci, ci, ci, ci, ci, ci
 _wgrad2_frag_elems = _sig("ddl_wgrad2_frag_elems", cl, ci, ci, ci, ci, ci, ci, ci)
 _slab_reduce_frag = _sig("ddl_slab_reduce_frag", ci, vp, vp, ci, ci, ci, ci, ci, ci, ci, ci, ci, cl, cl, cl, vp)
 _wgrad2_lds = _sig("ddl_wgrad2_lds", ci, ci, ci, ci, ci, ci, ci, ci, ci, ci)
+_wgrad2_lds_dma = _sig("ddl_wgrad2_lds_dma", ci, ci, ci, ci, ci, ci, ci, ci, ci, ci)
 _slab_reduce = _sig("ddl_slab_reduce", None, vp, vp, cl, cl, ci, vp)
 _dw_blocks = _sig("ddl_dw_wgrad_blocks", ci, cl, ci)
 _dw_dgrad_bn = _sig("ddl_dw_dgrad_bn", ci, ci, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci,
@@ -1799,6 +1800,8 @@ _W2_COMBOS = {(64, 64): (2, 3), (64, 32): (4, 7), (32, 64): (4, 7), (32, 32): (4
 # eight-wave blocks (one 512-thread block per CU sharing a staged unit): tile -> taps per wave
 _W2_COMBOS8 = {(64, 64): 2, (64, 32): 4, (32, 64): 4, (32, 32): 4}
 W2_NW8 = os.environ.get("DDL_W2_NW8", "1") == "1"
+W2_DMA = os.environ.get("DDL_W2_DMA", "1") == "1"
+_W2_DMA4 = {(64, 32): (7, 4), (32, 32): (7, 4)}           # four-wave DMA instantiations: tile -> taps per wave
 _W2_PLANS: Dict[Tuple, Optional[dict]] = {}
 
 
@@ -1824,9 +1827,10 @@ def _tr_pitch_x(nbytes: int, sw: int) -> int:
     return _tr_pitch(nbytes)
 
 
-def _wgrad2_one_plan(g, B, Cx, Ny, n_lim, c_lim, tn, tc, TPW, budget_kb=None, NW=4):
+def _wgrad2_one_plan(g, B, Cx, Ny, n_lim, c_lim, tn, tc, TPW, budget_kb=None, NW=4, dma=False):
     """One wgrad2 launch plan for an output tile (tn x tc), TPW taps per wave and an LDS budget (which
-    sets how many images / rows a unit holds and with it how many blocks share a CU)."""
+    sets how many images / rows a unit holds and with it how many blocks share a CU).  `dma`: LDS-DMA staging into two
+    buffers (the budget covers both), the next unit's transfer under the current unit's MFMA phase."""
     T = g.KH * g.KW
     ngroups = -(-T // (NW * TPW))
     tiles = -(-n_lim // tn) * -(-c_lim // tc)
@@ -1837,7 +1841,10 @@ def _wgrad2_one_plan(g, B, Cx, Ny, n_lim, c_lim, tn, tc, TPW, budget_kb=None, NW
     # only the output tile's channels are staged: pitches follow the tile, not the tensor
     xp, yp = _tr_pitch_x(min(Cx, tc) * 2, g.sw), _tr_pitch(min(Ny, tn) * 2)
     PW = (g.OW - 1) * g.sw + (g.KW - 1) * g.dw + 1
-    lds = lambda img, br: _wgrad2_lds(img, br, g.OW, Ny, (br - 1) * g.sh + (g.KH - 1) * g.dh + 1, PW, xp, yp, T)
+    if dma:
+        lds = lambda img, br: _wgrad2_lds_dma(img, br, g.OW, (br - 1) * g.sh + (g.KH - 1) * g.dh + 1, PW, xp, yp, T, NW)
+    else:
+        lds = lambda img, br: _wgrad2_lds(img, br, g.OW, Ny, (br - 1) * g.sh + (g.KH - 1) * g.dh + 1, PW, xp, yp, T)
     IMG, BR = 0, g.OH
     if lds(1, g.OH) <= budget:
         IMG = 1
@@ -1855,8 +1862,11 @@ def _wgrad2_one_plan(g, B, Cx, Ny, n_lim, c_lim, tn, tc, TPW, budget_kb=None, NW
     per_cu = 1 if one_block else max(1, min(2, (160 * 1024) // max(lds(IMG, BR), 1)))
     target = 256 * per_cu
     nsplit = max(1, min(n_units, target // (ngroups * tiles)))
-    return dict(IMG=IMG, BR=BR, xp=xp, yp=yp, TN=tn, TC=tc, TPW=TPW, NW=NW, ngroups=ngroups, nsplit=nsplit,
-                budget=budget_kb)
+    pl = dict(IMG=IMG, BR=BR, xp=xp, yp=yp, TN=tn, TC=tc, TPW=TPW, NW=NW, ngroups=ngroups, nsplit=nsplit,
+              budget=budget_kb)
+    if dma:
+        pl["DMA"] = 1
+    return pl
 
 
 def _wgrad2_plans(g: ConvGeom, B: int, Cx: int, Ny: int, n_lim: int, c_lim: int):
@@ -1907,6 +1917,22 @@ def _wgrad2_plans(g: ConvGeom, B: int, Cx: int, Ny: int, n_lim: int, c_lim: int)
                     if sig not in seen:
                         seen.add(sig)
                         plans.append(pl)
+        # LDS-DMA staged, double-buffered forms (appended: the indices of the plans above are what recorded choices
+        # name).  Two unit sizes each: the buffers halve what a unit can hold, and the transfer only hides behind the
+        # MFMA phase when a block walks several units
+        if W2_DMA:
+            for (a_, b_) in sorted(tiles):
+                forms = [(8, _W2_COMBOS8[(a_, b_)])] if (a_, b_) in _W2_COMBOS8 else []
+                forms += [(4, t) for t in _W2_DMA4.get((a_, b_), ())]
+                for nw, tpw in forms:
+                    for kb in (150, 76):
+                        pl = _wgrad2_one_plan(g, B, Cx, Ny, n_lim, c_lim, a_, b_, tpw, kb, NW=nw, dma=True)
+                        if pl is None:
+                            continue
+                        sig = tuple(sorted((k, v) for k, v in pl.items() if k != "budget"))
+                        if sig not in seen:
+                            seen.add(sig)
+                            plans.append(pl)
     _W2_PLANS[key] = plans
     return plans
 
@@ -2033,7 +2059,7 @@ def conv_wgrad(x, dy, g: ConvGeom, layout="A", out=None, box=None, x_affine=None
         rc = _wgrad2(dy.data_ptr(), x.data_ptr(), slab.data_ptr(), numel, ns, B, g.OH, g.OW, Op, g.H, g.W, Ip,
                      g.KH, g.KW, g.sh, g.sw, g.dh, g.dw, g.pt, g.pl, n_lim, c_lim, sn, st, sc, pl["IMG"], pl["BR"],
                      pl["xp"], pl["yp"], pl["TN"], pl["TC"], pl["TPW"], pl["NW"], pl["ngroups"],
-                     1 if W2_FRAG_SLAB else 0,
+                     (1 if W2_FRAG_SLAB else 0) | (2 if pl.get("DMA") else 0),
                      _stream())
         if rc:
             raise ValueError(f"conv_wgrad2 rejected its plan (rc={rc}): {g} {pl}")
@@ -2073,7 +2099,8 @@ def conv_wgrad(x, dy, g: ConvGeom, layout="A", out=None, box=None, x_affine=None
                 _record_choice(kstr, ["wgrad", choice])
                 if os.environ.get("DDL_AUTOTUNE_VERBOSE"):
                     desc = [(round(t, 1), "wgrad" if i < 0 else
-                             tuple(plans[i][k] for k in ("TN", "TC", "TPW", "NW", "IMG", "BR", "ngroups", "nsplit")))
+                             tuple(plans[i][k] for k in ("TN", "TC", "TPW", "NW", "IMG", "BR", "ngroups", "nsplit")) +
+                             (("dma",) if plans[i].get("DMA") else ()))
                             for t, i in timed[:6]]
                     print(f"[autotune] wgrad B={B} {g.H}x{g.W}x{g.I}->{g.OH}x{g.OW}x{g.O}: {desc}", flush=True)
             else:

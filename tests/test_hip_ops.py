@@ -360,11 +360,13 @@ def test_wgrad2_slab_orders_agree(hip, case, layout, monkeypatch):
         close(a[..., :I], ref, rtol=1e-2)
 
 
-@pytest.mark.parametrize("case", [(14, 14, 64, 128, 5, 2, 37), (7, 7, 64, 128, 5, 2, 50), (9, 11, 24, 40, 3, 1, 20)])
+@pytest.mark.parametrize("case", [(14, 14, 64, 128, 5, 2, 37), (7, 7, 64, 128, 5, 2, 50), (9, 11, 24, 40, 3, 1, 20),
+                                  (14, 14, 64, 128, 5, 2, 700)])
 @pytest.mark.parametrize("frag", [True, False])
 def test_wgrad2_every_candidate_plan(hip, case, frag, monkeypatch):
-    """Every launch plan the autotuner may pick (tile, taps per wave, four- and eight-wave blocks, LDS budget) gives
-    the oracle's gradient, in both slab orders."""
+    """Every launch plan the autotuner may pick (tile, taps per wave, four- and eight-wave blocks, LDS budget, register
+    or LDS-DMA staging -- the latter double-buffered: at B = 700 a block walks several units) gives the oracle's
+    gradient, in both slab orders."""
     H, W, I, O, k, s, B = case
     g = G.conv2d_geom(H, W, I, O, (k, k), (s, s), (1, 1), "same")
     torch.manual_seed(12)
@@ -377,6 +379,7 @@ def test_wgrad2_every_candidate_plan(hip, case, frag, monkeypatch):
     Ip, Op, T = hip.pad8(I), hip.pad8(O), k * k
     plans = hip._wgrad2_plans(g, B, Ip, Op, O, Ip)
     assert any(pl["NW"] == 8 for pl in plans) and any(pl["NW"] == 4 for pl in plans)
+    assert any(pl.get("DMA") for pl in plans) and not plans[0].get("DMA")
     key = ("wgrad", g, B, Ip, Op, O, Ip, T * Ip, Ip, 1)
     for i, pl in enumerate(plans):
         monkeypatch.setitem(hip._CONV_CHOICE, key, i)
