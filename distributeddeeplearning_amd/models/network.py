@@ -33,6 +33,7 @@ from .ir import LayerSpec, ModelSpec
 ONECH = os.environ.get("DDL_ONECH", "1") == "1"      # single-channel conv fast path (device)
 BN_BWD_FUSE = os.environ.get("DDL_BN_BWD_FUSE", "1") == "1"       # BN backward column sums from the kernel that makes dy
 BIAS_IN_WGRAD = os.environ.get("DDL_BIAS_IN_WGRAD", "1") == "1"   # one-channel input conv: bias gradient out of the weight-gradient launch
+BN_ON_LOAD_PCONV = os.environ.get("DDL_BN_ON_LOAD_PCONV", "1") == "1"   # ... in front of a multi-channel transposed conv
 BN_ON_LOAD = os.environ.get("DDL_BN_ON_LOAD", "1") == "1"         # BN in front of a 1-channel ConvT applied on load
 FUSE_ACT_BWD = os.environ.get("DDL_FUSE_ACT_BWD", "1") == "1"   # act'(y) of the layer below in the dgrad epilogue
 DW_BN_FUSE = os.environ.get("DDL_DW_BN_FUSE", "1") == "1"     # depthwise dgrad + backward of the BatchNorm in front of it
@@ -670,7 +671,8 @@ class Network:
                 continue
             # ... or in front of any other transposed conv: the patch-resident kernel applies it while staging
             # ... or in front of a depthwise layer: the stencil kernels (forward, weight gradient) apply it per loaded pixel
-            if (b_.onech == "out" or (b_.onech is None and b_.kind == "conv2d_transpose" and not b_.g.depthwise)
+            if (b_.onech == "out" or (BN_ON_LOAD_PCONV and b_.onech is None and b_.kind == "conv2d_transpose"
+                                      and not b_.g.depthwise)
                     or (b_.onech is None and b_.g.depthwise and b_.kind != "conv2d_transpose")):
                 a_.defer_to = b_
                 b_.in_bn = a_
