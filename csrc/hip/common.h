@@ -42,19 +42,29 @@ __device__ __forceinline__ uint4 pack8(const float* f) {
     return v;
 }
 
+// Activation transcendentals straight on the hardware units: v_exp_f32 (2^x), v_log_f32 (log2 x), v_rcp_f32, one
+// instruction each.  `__expf` / `__logf` wrap them in denormal-range scaling (compare, select, ldexp: ~7 more
+// instructions per call) and `__frcp_rn` is a correctly rounded division (div_scale / div_fmas / div_fixup: ~10);
+// an 8-channel softplus epilogue was 14 VALU instructions per element beside its two transcendentals and the
+// streaming kernels that carry one were instruction-bound.  Every result here is rounded to bf16 (8 mantissa bits),
+// the units are good to 1 ulp of fp32, and the arguments never need the denormal path: exp underflows to the 0 it
+// should round to, and the logarithm only ever sees 1 + e^x >= 1.
+__device__ __forceinline__ float fast_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504f); }
+__device__ __forceinline__ float fast_log(float x) { return __builtin_amdgcn_logf(x) * 0.69314718f; }
+__device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+
 // tanh(x) = 1 - 2 / (1 + e^{2x}); saturates cleanly for |x| large (e^{2x} -> 0 or inf)
-__device__ __forceinline__ float fast_tanh(float x) { return 1.f - 2.f * __frcp_rn(1.f + __expf(2.f * x)); }
+__device__ __forceinline__ float fast_tanh(float x) { return 1.f - 2.f * fast_rcp(1.f + fast_exp(2.f * x)); }
 
 __device__ __forceinline__ float act_apply(float x, int kind, float alpha) {
     switch (kind) {
         case ACT_RELU: return fmaxf(x, 0.f);
-        // transcendental ones on the fast hardware exp/log/rcp (results are rounded to bf16 anyway)
-        case ACT_SIGMOID: return __frcp_rn(1.f + __expf(-x));
-        case ACT_SOFTPLUS: return x > 15.f ? x : __logf(1.f + __expf(x));
+        case ACT_SIGMOID: return fast_rcp(1.f + fast_exp(-x));
+        case ACT_SOFTPLUS: return x > 15.f ? x : fast_log(1.f + fast_exp(x));
         case ACT_TANH: return fast_tanh(x);
-        case ACT_SOFTSIGN: return x * __frcp_rn(1.f + fabsf(x));
+        case ACT_SOFTSIGN: return x * fast_rcp(1.f + fabsf(x));
         case ACT_LEAKY: return x > 0.f ? x : alpha * x;
-        case ACT_TANH01: return __frcp_rn(1.f + __expf(-2.f * x));        // (tanh(x) + 1) / 2 == sigmoid(2x)
+        case ACT_TANH01: return fast_rcp(1.f + fast_exp(-2.f * x));       // (tanh(x) + 1) / 2 == sigmoid(2x)
         default: return x;
     }
 }
@@ -64,7 +74,7 @@ __device__ __forceinline__ float act_grad_y(float y, int kind, float alpha) {
     switch (kind) {
         case ACT_RELU: return y > 0.f ? 1.f : 0.f;
         case ACT_SIGMOID: return y * (1.f - y);
-        case ACT_SOFTPLUS: return 1.f - __expf(-y);
+        case ACT_SOFTPLUS: return 1.f - fast_exp(-y);
         case ACT_TANH: return 1.f - y * y;
         case ACT_SOFTSIGN: { float t = 1.f - fabsf(y); return t * t; }
         case ACT_LEAKY: return y > 0.f ? 1.f : alpha;

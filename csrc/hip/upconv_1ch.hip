@@ -1,0 +1,410 @@
+// Transposed convolution FROM a single-channel image (a Conv2DTranspose as the first layer of a random_layer
+// classifier, /root/reference/DDL_Normal4.py:39-43; model0 of the shipped replicas: 28x28x1 -> 57x57x64, k3 s2):
+//
+//   y[b][h][w][n] = act(bias[n] + sum_{kh,kw} [sh | h+pt-kh*dh][sw | w+pl-kw*dw] x[b][(h+pt-kh*dh)/sh][(w+pl-kw*dw)/sw] * wgt[n][kh][kw])
+//
+// and its weight gradient dW[n][kh][kw] = sum_{b,h,w} dY[b][h][w][n] * x[...same pixel...].
+//
+// With one input channel the layer has K = taps <= 9 multiply-adds per output value: there is nothing for the matrix
+// cores to do (the implicit-GEMM kernels pad K to 32 and ran this layer at 1.4 TB/s of stores, the streaming weight
+// gradient needed an im2col tensor and read 388 MB for a 213 MB dY).  Both passes are pure streaming problems, so
+// they are written as such: a lane owns 8 output channels of one pixel (one 16-byte store / load, the 8 lanes of a
+// pixel cover a whole 128-byte line at N = 64), the image sits in LDS as a zero-haloed fp32 plane, the lane's
+// 8 x taps weights (forward) or 8 x taps accumulators (gradient) live in registers.  A block owns ONE stride class
+// (h+pt mod sh, w+pl mod sw) of one image, so which taps are live is block-uniform: dead taps are skipped by scalar
+// branches (a stride-2 3x3 layer has 2.25 live taps per pixel on average, not 9) and tap offsets into the plane are
+// scalars.  The forward pass also leaves the BatchNorm statistics' partial sums of its (bf16-rounded) output, one
+// column per block, laid out like pconv's STATS epilogue (part[2][Np][columns]).
+#include "common.h"
+#include <cstdlib>
+
+struct UpArgs {
+    const bf16_t* x;          // [B][IH][IW][Cs], channel 0 real
+    const bf16_t* w;          // [N][KH*KW][Cw], channel 0 real (canonical [layer_out][KH][KW][pad(layer_in)])
+    const float* bias;        // [N] or null
+    bf16_t* y;                // forward: output [B][H][W][Np]; gradient: dY (read only)
+    float* part;              // forward: statistics partials (or null); gradient: slab [blocks][T * Np]
+    int stats_stride, stats_off;
+    int B, IH, IW, Cs, Cw, H, W, Np, N, KH, KW, sh, sw, dh, dw, pt, pl, act;
+    float alpha;
+    int PH, PW, halo_h, halo_w;   // plane[(ih + halo_h) * PW + iw + halo_w]
+    int bands, rpb;               // bands per class, class rows per band
+    int ipb;                      // images per block (weight gradient: fewer, fatter slabs)
+    int lps;                      // log2(Np / 8): lanes per pixel
+};
+
+__device__ __forceinline__ int up_fdiv(int x, float inv) { return __float2int_rz(((float)x + 0.5f) * inv); }
+__device__ __forceinline__ int up_mod(int a, int m) { int r = a % m; return r < 0 ? r + m : r; }
+
+// Block-uniform description of the class / band this block owns.
+struct UpBlock {
+    int h_first, w_first, ncols, i0, i1, m_first, n_first;
+    int toff[9];
+    unsigned live;            // bit t: tap t contributes to this class
+};
+
+template <int K>
+__device__ __forceinline__ UpBlock up_block(const UpArgs& a) {
+    UpBlock u;
+    const int cls = blockIdx.y / a.bands, band = blockIdx.y - cls * a.bands;
+    const int ph = cls / a.sw, pw = cls - ph * a.sw;
+    u.h_first = up_mod(ph - a.pt, a.sh);
+    u.w_first = up_mod(pw - a.pl, a.sw);
+    const int nrows = u.h_first < a.H ? (a.H - u.h_first + a.sh - 1) / a.sh : 0;
+    u.ncols = u.w_first < a.W ? (a.W - u.w_first + a.sw - 1) / a.sw : 0;
+    u.i0 = min(nrows, band * a.rpb);
+    u.i1 = min(nrows, u.i0 + a.rpb);
+    u.m_first = (u.h_first + a.pt - ph) / a.sh;
+    u.n_first = (u.w_first + a.pl - pw) / a.sw;
+    u.live = 0;
+#pragma unroll
+    for (int kh = 0; kh < K; ++kh)
+#pragma unroll
+        for (int kw = 0; kw < K; ++kw) {
+            const int rh = ph - kh * a.dh, rw = pw - kw * a.dw;
+            const bool ok = (rh % a.sh == 0) && (rw % a.sw == 0);
+            u.toff[kh * K + kw] = ok ? (rh / a.sh) * a.PW + (rw / a.sw) : 0;
+            if (ok) u.live |= 1u << (kh * K + kw);
+        }
+    return u;
+}
+
+// zero-haloed fp32 plane of image b
+__device__ __forceinline__ void up_stage(const UpArgs& a, float* plane, int b) {
+    const int tid = threadIdx.x;
+    for (int i = tid; i < a.PH * a.PW; i += 256) plane[i] = 0.f;
+    __syncthreads();
+    const bf16_t* src = a.x + (size_t)b * a.IH * a.IW * a.Cs;
+    const float invW = 1.0f / (float)a.IW;
+    const int n = a.IH * a.IW;
+    for (int i0 = tid; i0 < n; i0 += 1024) {
+        bf16_t v[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int i = min(i0 + k * 256, n - 1);
+            v[k] = src[(size_t)i * a.Cs];
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int i = i0 + k * 256;
+            if (i < n) {
+                const int r = up_fdiv(i, invW), c = i - r * a.IW;
+                plane[(r + a.halo_h) * a.PW + c + a.halo_w] = bf2f(v[k]);
+            }
+        }
+    }
+    __syncthreads();
+}
+
+template <int K>
+__global__ __launch_bounds__(256) void upconv_1ch_fwd_kernel(const UpArgs a) {
+    constexpr int T = K * K;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* plane = (float*)smem;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.x;
+    const UpBlock u = up_block<K>(a);
+    const int LP = 1 << a.lps;
+    const int cg = tid & (LP - 1);
+    // this lane's 8 channels: bias in registers, the weights of every tap in LDS as fp32 [T][Np] (72 registers of
+    // weights left the kernel at two waves per SIMD; a live tap now costs two 16-byte LDS reads per lane)
+    float* wsm = plane + ((a.PH * a.PW + 3) & ~3);
+    float bv[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int n = cg * 8 + j;
+        bv[j] = (n < a.N && a.bias) ? a.bias[n] : 0.f;
+    }
+    for (int i = tid; i < T * a.Np; i += 256) {
+        const int t = i / a.Np, n = i - t * a.Np;
+        wsm[i] = n < a.N ? bf2f(a.w[((size_t)n * T + t) * a.Cw]) : 0.f;
+    }
+    up_stage(a, plane, b);
+
+    float st_s[8], st_q[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) st_s[j] = st_q[j] = 0.f;
+    const int total = ((u.i1 - u.i0) * u.ncols) << a.lps;
+    const float invC = 1.0f / (float)max(u.ncols, 1);
+    const int act = a.act;
+    const float alpha = a.alpha;
+    bf16_t* yb = a.y + (size_t)b * a.H * a.W * a.Np;         // (an image is far below 2^31 elements: up_fill)
+    const bool padded = a.N < a.Np;
+    auto body = [&](auto KA) {
+        for (int idx = tid; idx < total; idx += 256) {
+            const int q = idx >> a.lps;
+            const int il = up_fdiv(q, invC), j = q - il * u.ncols;
+            const int i = u.i0 + il;
+            const int h = u.h_first + a.sh * i, w = u.w_first + a.sw * j;
+            const int pb = (u.m_first + i + a.halo_h) * a.PW + u.n_first + j + a.halo_w;
+            float acc[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[e] = bv[e];
+#pragma unroll
+            for (int t = 0; t < T; ++t)
+                if (u.live & (1u << t)) {
+                    const float xv = plane[pb + u.toff[t]];
+                    const float4 w0 = *(const float4*)(wsm + t * a.Np + cg * 8);
+                    const float4 w1 = *(const float4*)(wsm + t * a.Np + cg * 8 + 4);
+                    acc[0] = fmaf(xv, w0.x, acc[0]); acc[1] = fmaf(xv, w0.y, acc[1]);
+                    acc[2] = fmaf(xv, w0.z, acc[2]); acc[3] = fmaf(xv, w0.w, acc[3]);
+                    acc[4] = fmaf(xv, w1.x, acc[4]); acc[5] = fmaf(xv, w1.y, acc[5]);
+                    acc[6] = fmaf(xv, w1.z, acc[6]); acc[7] = fmaf(xv, w1.w, acc[7]);
+                }
+            float v[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float z = act_apply_k<decltype(KA)::value>(acc[e], act, alpha);
+                v[e] = (!padded || cg * 8 + e < a.N) ? z : 0.f;
+            }
+            const uint4 o = pack8(v);
+            *(uint4*)(yb + (unsigned)((h * a.W + w) * a.Np + cg * 8)) = o;
+            if (a.part) {
+                float r[8];
+                unpack8(o, r);               // what the stored tensor holds
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    st_s[e] += r[e];
+                    st_q[e] = fmaf(r[e], r[e], st_q[e]);
+                }
+            }
+        }
+    };
+    act_switch(act, body);
+
+    if (a.part) {
+        // lanes with the same channel group hold different pixels: fold them, then the four waves
+        for (int o = LP; o < 64; o <<= 1)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                st_s[e] += __shfl_xor(st_s[e], o, 64);
+                st_q[e] += __shfl_xor(st_q[e], o, 64);
+            }
+        __syncthreads();                     // the plane is no longer read
+        float* red = (float*)smem;           // [4 waves][2][Np]
+        if (lane < LP) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                red[(wave * 2 + 0) * a.Np + cg * 8 + e] = st_s[e];
+                red[(wave * 2 + 1) * a.Np + cg * 8 + e] = st_q[e];
+            }
+        }
+        __syncthreads();
+        const size_t col = (size_t)a.stats_off + (size_t)blockIdx.x * gridDim.y + blockIdx.y;
+        for (int i = tid; i < 2 * a.Np; i += 256) {
+            const int k = i / a.Np, c = i - k * a.Np;
+            const float s = ((red[(0 * 2 + k) * a.Np + c] + red[(1 * 2 + k) * a.Np + c]) + red[(2 * 2 + k) * a.Np + c]) +
+                            red[(3 * 2 + k) * a.Np + c];
+            a.part[((size_t)k * a.Np + c) * a.stats_stride + col] = s;
+        }
+    }
+}
+
+// dW partials: slab[block][t * Np + n] = sum over the block's pixels of dY[.][n] * x[tap t of the pixel]
+template <int K>
+__global__ __launch_bounds__(256) void upconv_1ch_wgrad_kernel(const UpArgs a) {
+    constexpr int T = K * K, U = 4;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* plane = (float*)smem;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const UpBlock u = up_block<K>(a);
+    const int LP = 1 << a.lps;
+    const int cg = tid & (LP - 1);
+
+    float acc[T][8];
+#pragma unroll
+    for (int t = 0; t < T; ++t)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[t][e] = 0.f;
+    const int total = ((u.i1 - u.i0) * u.ncols) << a.lps;
+    const float invC = 1.0f / (float)max(u.ncols, 1);
+    for (int b = blockIdx.x * a.ipb; b < min(a.B, (int)(blockIdx.x + 1) * a.ipb); ++b) {
+    __syncthreads();                         // every lane is done with the previous image's plane
+    up_stage(a, plane, b);
+    const bf16_t* yb = a.y + (size_t)b * a.H * a.W * a.Np;
+    for (int base = tid; base < total; base += 256 * U) {
+        uint4 v[U];
+        int pb[U];
+        bool ok[U];
+#pragma unroll
+        for (int k = 0; k < U; ++k) {
+            const int idx = base + k * 256;
+            ok[k] = idx < total;
+            const int q = min(idx, total - 1) >> a.lps;
+            const int il = up_fdiv(q, invC), j = q - il * u.ncols;
+            const int i = u.i0 + il;
+            const int h = u.h_first + a.sh * i, w = u.w_first + a.sw * j;
+            pb[k] = (u.m_first + i + a.halo_h) * a.PW + u.n_first + j + a.halo_w;
+            v[k] = *(const uint4*)(yb + (unsigned)((h * a.W + w) * a.Np + cg * 8));
+        }
+#pragma unroll
+        for (int k = 0; k < U; ++k) {
+            float d[8];
+            unpack8(v[k], d);
+#pragma unroll
+            for (int t = 0; t < T; ++t)
+                if (u.live & (1u << t)) {
+                    const float xv = ok[k] ? plane[pb[k] + u.toff[t]] : 0.f;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) acc[t][e] = fmaf(xv, d[e], acc[t][e]);
+                }
+        }
+    }
+    }
+    for (int o = LP; o < 64; o <<= 1)
+#pragma unroll
+        for (int t = 0; t < T; ++t)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[t][e] += __shfl_xor(acc[t][e], o, 64);
+    __syncthreads();                         // the plane is no longer read
+    float* red = (float*)smem;               // [4 waves][T][Np]
+    if (lane < LP) {
+#pragma unroll
+        for (int t = 0; t < T; ++t)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) red[(wave * T + t) * a.Np + cg * 8 + e] = acc[t][e];
+    }
+    __syncthreads();
+    const int E = T * a.Np;
+    float* dst = a.part + ((size_t)blockIdx.x * gridDim.y + blockIdx.y) * E;
+    for (int i = tid; i < E; i += 256) dst[i] = ((red[i] + red[E + i]) + red[2 * E + i]) + red[3 * E + i];
+}
+
+// out[(n * T + t) * Cw + 0] = sum_k slab[k][t * Np + n] (fixed order: deterministic), channels 1 .. Cw-1 = 0.
+// A block owns 32 slab columns, 8 lanes split the slabs of a column and combine through LDS.
+__global__ __launch_bounds__(256) void upconv_1ch_wgrad_finish_kernel(const float* __restrict__ slab,
+                                                                      float* __restrict__ out, int E, int Np, int N,
+                                                                      int T, int Cw, int nslab) {
+    __shared__ float red[8][33];
+    const int col = threadIdx.x & 31, kl = threadIdx.x >> 5;
+    const int e = blockIdx.x * 32 + col;
+    float s = 0.f;
+    if (e < E) {
+        int k = kl;
+        for (; k + 56 < nslab; k += 64) {           // eight independent loads per trip, summed in a fixed order
+            float v[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) v[q] = slab[(size_t)(k + 8 * q) * E + e];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) s += v[q];
+        }
+        for (; k < nslab; k += 8) s += slab[(size_t)k * E + e];
+    }
+    red[kl][col] = s;
+    __syncthreads();
+    if (kl == 0 && e < E) {
+#pragma unroll
+        for (int q = 1; q < 8; ++q) s += red[q][col];
+        const int t = e / Np, n = e - t * Np;
+        if (n < N) {
+            float* o = out + ((size_t)n * T + t) * Cw;
+            o[0] = s;
+            for (int c = 1; c < Cw; ++c) o[c] = 0.f;
+        }
+    }
+}
+
+static long up_env(const char* name, long dflt) {
+    const char* v = getenv(name);
+    return v ? atol(v) : dflt;
+}
+
+// `target`: blocks to aim for (bands split a class's rows until there are that many; the weight gradient also folds
+// images into one block while there would be twice as many).  Measured on model0's layer (B = 512, 4 classes): forward
+// 2048 / 4096 / 8192 / 16384 blocks -> 99 / 104 / 121 / 156 us (every block stages its image and its weights);
+// weight gradient 512 / 1024 / 2048 blocks -> 63 / 53 / 68 us (1024 = one round at its register count, half the slabs).
+static int up_fill(UpArgs& a, const void* x, const void* w, const float* bias, void* y, float* part, int B, int IH,
+                   int IW, int Cs, int Cw, int H, int W, int Np, int N, int KH, int KW, int sh, int sw, int dh, int dw,
+                   int pt, int pl, int act, float alpha, long target) {
+    if (B <= 0 || IH <= 0 || IW <= 0 || H <= 0 || W <= 0 || Cs <= 0 || Cw <= 0 || N <= 0 || N > Np || Np % 8) return -1;
+    if (sh <= 0 || sw <= 0 || dh <= 0 || dw <= 0 || pt < 0 || pl < 0) return -1;
+    if (KH != KW || KH < 1 || KH > 3) return 1;
+    const int LP = Np / 8;
+    if (LP > 16 || (LP & (LP - 1))) return 1;
+    if ((long)B * H * W * Np >= (1L << 31) || (long)B * IH * IW * Cs >= (1L << 31)) return 1;
+    a.x = (const bf16_t*)x; a.w = (const bf16_t*)w; a.bias = bias; a.y = (bf16_t*)y; a.part = part;
+    a.stats_stride = 0; a.stats_off = 0;
+    a.B = B; a.IH = IH; a.IW = IW; a.Cs = Cs; a.Cw = Cw; a.H = H; a.W = W; a.Np = Np; a.N = N; a.KH = KH; a.KW = KW;
+    a.sh = sh; a.sw = sw; a.dh = dh; a.dw = dw; a.pt = pt; a.pl = pl; a.act = act; a.alpha = alpha;
+    a.halo_h = ((KH - 1) * dh + sh - 1) / sh;
+    a.halo_w = ((KW - 1) * dw + sw - 1) / sw;
+    const int top_h = (H - 1 + pt) / sh + 1, top_w = (W - 1 + pl) / sw + 1;
+    a.PH = a.halo_h + (IH > top_h ? IH : top_h);
+    a.PW = a.halo_w + (IW > top_w ? IW : top_w);
+    int lps = 0;
+    while ((1 << lps) < LP) ++lps;
+    a.lps = lps;
+    // enough blocks to fill the chip: bands split a class's rows when batch x classes alone would not
+    const int classes = sh * sw, rows = (H + sh - 1) / sh;
+    int bands = 1, ipb = 1;
+    while ((long)B * classes * bands < target && bands * 2 <= rows) bands *= 2;
+    while (bands == 1 && (long)((B + 2 * ipb - 1) / (2 * ipb)) * classes >= target) ipb *= 2;
+    a.bands = bands;
+    a.rpb = (rows + bands - 1) / bands;
+    a.ipb = ipb;
+    if ((long)rows * ((W + sw - 1) / sw) * LP >= (1L << 21)) return 1;     // up_fdiv's exact range
+    return 0;
+}
+
+static long up_target(int wgrad) {
+    static const long tf = up_env("DDL_UP_FWD_BLOCKS", 2048), tw = up_env("DDL_UP_WG_BLOCKS", 1024);
+    return wgrad ? tw : tf;
+}
+
+// Statistics columns (forward, wgrad = 0) / slabs (weight gradient, wgrad = 1) of a launch.  0: outside the kernels' range.
+DDL_API int ddl_upconv_1ch_blocks(int wgrad, int B, int H, int W, int Np, int KH, int KW, int sh, int sw) {
+    UpArgs a;
+    if (up_fill(a, nullptr, nullptr, nullptr, nullptr, nullptr, B, 1, 1, 8, 8, H, W, Np, Np, KH, KW, sh, sw, 1, 1, 0, 0, 0,
+                0.f, up_target(wgrad)))
+        return 0;
+    return ((B + a.ipb - 1) / a.ipb) * sh * sw * a.bands;
+}
+
+// Returns 0 on success, 1 if the shape is outside this kernel's range (nothing launched), < 0 on bad arguments.
+DDL_API int ddl_upconv_1ch(const void* x, const void* w, const float* bias, void* y, float* stats, int stats_stride,
+                           int stats_off, int B, int IH, int IW, int Cs, int Cw, int H, int W, int Np, int N, int KH,
+                           int KW, int sh, int sw, int dh, int dw, int pt, int pl, int act, float alpha, hipStream_t s) {
+    UpArgs a;
+    const int rc = up_fill(a, x, w, bias, y, stats, B, IH, IW, Cs, Cw, H, W, Np, N, KH, KW, sh, sw, dh, dw, pt, pl, act,
+                           alpha, up_target(0));
+    if (rc) return rc;
+    a.ipb = 1;
+    const int gy = sh * sw * a.bands;
+    a.stats_stride = stats_stride > 0 ? stats_stride : B * gy;
+    a.stats_off = stats_stride > 0 ? stats_off : 0;
+    if (stats && (a.stats_off < 0 || a.stats_off + B * gy > a.stats_stride)) return -1;
+    size_t smem = (size_t)((a.PH * a.PW + 3) & ~3) * 4 + (size_t)KH * KW * Np * 4;      // plane + weights
+    const size_t red = (size_t)4 * 2 * Np * 4;
+    if (red > smem) smem = red;
+    if (smem > 64 * 1024) return 1;
+    const dim3 grid(B, gy);
+    if (KH == 1) upconv_1ch_fwd_kernel<1><<<grid, 256, smem, s>>>(a);
+    else if (KH == 2) upconv_1ch_fwd_kernel<2><<<grid, 256, smem, s>>>(a);
+    else upconv_1ch_fwd_kernel<3><<<grid, 256, smem, s>>>(a);
+    return 0;
+}
+
+// dW into the canonical fp32 gradient [N][KH*KW][Cw] (channel 0; the padding channels are written as zeros).
+// `slab`: ddl_upconv_1ch_blocks(1, ...) * KH*KW*Np floats of scratch.
+DDL_API int ddl_upconv_1ch_wgrad(const void* x, const void* dy, float* slab, float* out, int B, int IH, int IW, int Cs,
+                                 int Cw, int H, int W, int Np, int N, int KH, int KW, int sh, int sw, int dh, int dw,
+                                 int pt, int pl, hipStream_t s) {
+    UpArgs a;
+    const int rc = up_fill(a, x, nullptr, nullptr, const_cast<void*>(dy), slab, B, IH, IW, Cs, Cw, H, W, Np, N, KH, KW,
+                           sh, sw, dh, dw, pt, pl, 0, 0.f, up_target(1));
+    if (rc) return rc;
+    if (!slab || !out) return -1;
+    const int gy = sh * sw * a.bands, T = KH * KW;
+    size_t smem = (size_t)a.PH * a.PW * 4;
+    const size_t red = (size_t)4 * T * Np * 4;
+    if (red > smem) smem = red;
+    if (smem > 64 * 1024) return 1;
+    const int gx = (B + a.ipb - 1) / a.ipb;
+    const dim3 grid(gx, gy);
+    if (KH == 1) upconv_1ch_wgrad_kernel<1><<<grid, 256, smem, s>>>(a);
+    else if (KH == 2) upconv_1ch_wgrad_kernel<2><<<grid, 256, smem, s>>>(a);
+    else upconv_1ch_wgrad_kernel<3><<<grid, 256, smem, s>>>(a);
+    const int E = T * Np;
+    upconv_1ch_wgrad_finish_kernel<<<(E + 31) / 32, 256, 0, s>>>(slab, out, E, Np, N, T, Cw, gx * gy);
+    return 0;
+}

@@ -149,7 +149,7 @@ class ConvOp(Op):
         self.w_main = self.w_alt = None           # compute-dtype views
         self.x = self.y = self.x_img = None
         # single-channel fast path (device only): see ops/hip.py im2col_1ch / col2im_1ch
-        self.onech = None               # None | "in" (Conv2D 1->N) | "out" (Conv2DTranspose C->1)
+        self.onech = None               # None | "in" (Conv2D 1->N) | "out" (Conv2DTranspose C->1) | "up" (ConvT 1->N)
         self.g1 = None                  # the equivalent 1x1 geometry on the taps-as-channels tensor
         self.w_tap = self.w_tapT = None
         self.dy_premul = False          # the incoming dY already carries act'(y) (fused by the layer above)
@@ -344,9 +344,30 @@ class ConvOp(Op):
                 _BR.run(wg, dy)
         return dx
 
+    def _fwd_up(self, x, training):
+        """Conv2DTranspose from a one-channel image (the first layer of a `random_layer` model,
+        /root/reference/DDL_Normal4.py:39-43): the streaming kernel of csrc/hip/upconv_1ch.hip, which also leaves the
+        statistics partials of a batch-statistics BatchNorm behind it.  None: outside its range (generic path)."""
+        bn = self.next_bn
+        if self.in_affine is not None or (not training and bn is not None):
+            return None                 # (inference folds the BatchNorm into the generic kernels' epilogue)
+        so = {"groups": bn.groups} if (training and bn is not None and bn.mode == "batch") else None
+        y = F.hip_backend().upconv_1ch(x, self.w_main, self.g, self.bias, self.act, self.alpha, stats_out=so)
+        if y is None:
+            return None
+        if so and "part" in so and (bn.groups == 1 or x.shape[0] % (so["img"] * bn.groups) == 0):
+            bn.pre_stats = (so["part"], so["nb"])
+        if training:
+            self.x, self.y, self.x_affine = x, y, None
+        return y
+
     def fwd(self, x, training):
         g = self.g
-        if self.onech:
+        if self.onech == "up":
+            y = self._fwd_up(x, training)
+            if y is not None:
+                return y
+        elif self.onech:
             return self._fwd_onech(x, training)
         # a batch-statistics BN right behind this layer: let the conv kernel emit the statistics' partial sums
         bn = self.next_bn
@@ -391,7 +412,18 @@ class ConvOp(Op):
                 dy = F.act_bwd(dy, self.y, self.act, self.alpha)
         x = self.x
         dx = None
-        if self.onech:
+        if self.onech == "up":
+            if need_dw and not need_dx and self.x_affine is None:
+                done = [False]
+
+                def wg_up():
+                    done[0] = F.hip_backend().upconv_1ch_wgrad(x, dy, self.w_main, g, self.gkernel)
+                    if done[0]:
+                        self._bias_grad(dy)
+                _BR.run(wg_up, dy)
+                if done[0]:
+                    return None
+        elif self.onech:
             return self._bwd_onech(dy, need_dx, need_dw, mul)
         if self.kind == "dense":
             B = x.shape[0]
@@ -808,6 +840,9 @@ class Network:
         g_off = 0
         if self.on_gpu and ONECH:
             for op in self.ops:
+                if isinstance(op, ConvOp) and op.kind == "conv2d_transpose" and op.g.O == 1 and op.g.I != 1:
+                    op.onech = "up"             # Conv2DTranspose 1 -> N: streaming kernels on the canonical weights
+                    continue
                 if not isinstance(op, ConvOp) or op.g.depthwise or op.g.I != 1:
                     continue
                 if op.kind not in ("conv2d", "conv2d_transpose"):

@@ -79,6 +79,11 @@ _tapfold = _sig("ddl_tapfold_1ch", ci, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, c
                 cf, vp, vp, ci, ci, ci, vp)
 _tapconv = _sig("ddl_tapconv_1ch", ci, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci,
                 cf, vp, vp, vp, vp, ci, ci, cf, vp)
+_upconv_blocks = _sig("ddl_upconv_1ch_blocks", ci, ci, ci, ci, ci, ci, ci, ci, ci, ci)
+_upconv = _sig("ddl_upconv_1ch", ci, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci,
+               ci, ci, ci, cf, vp)
+_upconv_wgrad = _sig("ddl_upconv_1ch_wgrad", ci, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci,
+                     ci, ci, ci, vp)
 _gather = _sig("ddl_relayout_gather", None, vp, vp, vp, ci, cl, vp)
 _relayout_both = _sig("ddl_relayout_both", None, vp, vp, vp, ci, vp, vp, ci, cl, vp)
 _gemm_sk = _sig("ddl_gemm_sk", ci, vp, vp, vp, vp, cl, ci, ci, ci, ci, cf, vp)
@@ -659,6 +664,82 @@ def tapconv_1ch(img, w, g: ConvGeom, bias=None, act=None, alpha=0.3, out=None, b
         return None
     _done()
     return y
+
+
+UPCONV = os.environ.get("DDL_UPCONV", "1") == "1"
+
+
+def _upconv_shape(x, w, g: ConvGeom, name, wgrad=0):
+    """Operands of a transposed convolution from a one-channel image against its core geometry `g` (the forward conv
+    whose input gradient it is: g.O = 1 layer input channel, g.I layer output channels, g.OH x g.OW the layer's input,
+    g.H x g.W its output).  Returns (B, Cs, Cw, Np, blocks of the launch) or None when outside the kernels' range."""
+    _chk_act(x, "x")
+    B, Cs = x.shape[0], x.shape[-1]
+    if g.O != 1 or g.depthwise or tuple(x.shape[1:3]) != (g.OH, g.OW):
+        raise ValueError(f"{name}: x {tuple(x.shape)} vs geometry {g}")
+    if not (w.is_cuda and w.dtype == torch.bfloat16 and w.is_contiguous()) or w.dim() != 4 \
+            or tuple(w.shape[:3]) != (g.I, g.KH, g.KW):
+        raise ValueError(f"{name}: weights must be contiguous bf16 [N][KH][KW][Cw], got {tuple(w.shape)} for {g}")
+    Np = pad8(g.I)
+    nby = _upconv_blocks(wgrad, B, g.H, g.W, Np, g.KH, g.KW, g.sh, g.sw)
+    if nby <= 0 or _batch_ranges(B, max(g.H * g.W * Np, g.OH * g.OW * Cs)) is not None:
+        return None
+    return B, Cs, w.shape[-1], Np, nby
+
+
+def upconv_1ch(x, w, g: ConvGeom, bias=None, act=None, alpha=0.3, stats_out=None):
+    """Transposed convolution from a single-channel image (csrc/hip/upconv_1ch.hip): x [B][g.OH][g.OW][Cs] (channel 0
+    real), w canonical [N][KH][KW][Cw] bf16 (channel 0 real) -> [B][g.H][g.W][pad8(N)] = act(bias + taps).  A streaming
+    kernel: one 16-byte store per lane, only the taps live for the block's stride class are computed.
+    `stats_out` (dict): receives the BatchNorm partials of the output ("part", "nb", "img") like the conv kernels'
+    statistics epilogue.  Returns None when the shape is outside the kernel's range (nothing launched)."""
+    if not UPCONV:
+        return None
+    shp = _upconv_shape(x, w, g, "upconv_1ch")
+    if shp is None:
+        return None
+    B, Cs, Cw, Np, nby = shp
+    if bias is not None:
+        _chk_f32(bias, g.I, "bias")
+    y = torch.empty(B, g.H, g.W, Np, dtype=torch.bfloat16, device=x.device)
+    part = None
+    if stats_out is not None:
+        part = torch.empty(2 * Np * nby, dtype=torch.float32, device=x.device)
+    rc = _upconv(x.data_ptr(), w.data_ptr(), _p(bias), y.data_ptr(), _p(part), 0, 0, B, g.OH, g.OW, Cs, Cw, g.H, g.W,
+                 Np, g.I, g.KH, g.KW, g.sh, g.sw, g.dh, g.dw, g.pt, g.pl, ACT_CODE[act], alpha, _stream())
+    if rc < 0:
+        raise ValueError(f"upconv_1ch rejected its arguments (rc={rc})")
+    if rc > 0:
+        return None
+    if part is not None:
+        stats_out["part"], stats_out["nb"], stats_out["img"] = part, nby, 1
+    _done()
+    return y
+
+
+def upconv_1ch_wgrad(x, dy, w_like, g: ConvGeom, out):
+    """Weight gradient of `upconv_1ch`: out (fp32, canonical [N][KH][KW][Cw] like `w_like`) = sum over pixels of
+    dY[b][h][w][n] * x[tap]; the padding channels of `out` are written as zeros.  Deterministic (per-block slabs summed
+    in a fixed order).  Returns False when the shape is outside the kernel's range (nothing launched)."""
+    if not UPCONV:
+        return False
+    shp = _upconv_shape(x, w_like, g, "upconv_1ch_wgrad", 1)
+    if shp is None:
+        return False
+    B, Cs, Cw, Np, nby = shp
+    _chk_act(dy, "dy")
+    if tuple(dy.shape) != (B, g.H, g.W, Np):
+        raise ValueError(f"upconv_1ch_wgrad: dy {tuple(dy.shape)} != {(B, g.H, g.W, Np)}")
+    _chk_f32(out, g.I * g.KH * g.KW * Cw, "out")
+    if tuple(out.shape) != tuple(w_like.shape):
+        raise ValueError(f"upconv_1ch_wgrad: out {tuple(out.shape)} != weights {tuple(w_like.shape)}")
+    slab = torch.empty(nby * g.KH * g.KW * Np, dtype=torch.float32, device=x.device)
+    rc = _upconv_wgrad(x.data_ptr(), dy.data_ptr(), slab.data_ptr(), out.data_ptr(), B, g.OH, g.OW, Cs, Cw, g.H, g.W, Np,
+                       g.I, g.KH, g.KW, g.sh, g.sw, g.dh, g.dw, g.pt, g.pl, _stream())
+    if rc < 0:
+        raise ValueError(f"upconv_1ch_wgrad rejected its arguments (rc={rc})")
+    _done()
+    return rc == 0
 
 
 def pad_channels(x, c_phys, index=None, scale=1.0, c_true=None):

@@ -1137,3 +1137,75 @@ def test_depthwise_dgrad_fused_with_batchnorm_backward(hip, case):
     close(a[1], (gref * xhat).reshape(-1, Cc).sum(0), rtol=1e-2)
     close(a[2], gref.reshape(-1, Cc).sum(0), rtol=1e-2, atol=1e-2 * float(gref.reshape(-1, Cc).sum(0).abs().max()) + 1e-3)
     close(a[3], dxr.reshape(-1, Cc).sum(0), rtol=2e-2, atol=2e-3 * float(dxr.abs().reshape(-1, Cc).sum(0).max()))
+
+
+UPCONV_CASES = [
+    # H, W, filters, k, s, d, padding, act
+    (28, 28, 64, 3, 2, 1, "valid", "softplus"),     # model0 conv2d_transpose_1 (57 x 57 x 64)
+    (28, 28, 16, 2, 2, 3, "valid", "relu"),         # k_eff 4 > s
+    (11, 9, 128, 3, 1, 2, "valid", "tanh"),         # stride 1: one class
+    (8, 8, 8, 1, 2, 2, "valid", "sigmoid"),         # k 1 s 2: three of four classes are bias only
+    (7, 7, 32, 3, 3, 1, "valid", "softsign"),       # nine classes, one tap each
+    (14, 14, 64, 3, 2, 1, "same", "leaky"),
+]
+
+
+@pytest.mark.parametrize("case", UPCONV_CASES)
+@pytest.mark.parametrize("B", [3, 40])
+def test_upconv_1ch_forward_statistics_and_weight_gradient(hip, case, B):
+    """Streaming kernels for a Conv2DTranspose fed by a one-channel image (csrc/hip/upconv_1ch.hip) against the fp32
+    oracle of the same op; the statistics partials against a column reduction of the stored output."""
+    H, W, Fo, k, s, d, pad, act = case
+    g = G.conv2d_transpose_geom(H, W, 1, Fo, (k, k), (s, s), (d, d), pad)
+    torch.manual_seed(31)
+    x = r16(torch.randn(B, H, W, 1))
+    w = r16(torch.randn(Fo, k, k, 1) / k)                       # canonical [filters][KH][KW][in]
+    b = torch.randn(Fo)
+    wA = w.permute(3, 1, 2, 0).contiguous()
+    y_ref = cpu_ref.conv_dgrad(x, wA, g, b, act)
+    so = {}
+    xd, wd = dev(hip, x), padw(hip, w)
+    y = hip.upconv_1ch(xd, wd, g, b.cuda(), act, 0.3, stats_out=so)
+    assert y is not None and tuple(y.shape) == (B, g.H, g.W, hip.pad8(Fo))
+    close(host(hip, y, Fo), y_ref)
+    y2 = hip.conv_dgrad(xd, wd, g, b.cuda(), act)               # the generic kernels agree to rounding
+    assert torch.allclose(y.float(), y2.float(), rtol=2e-2, atol=2e-2)
+    Np, nb = hip.pad8(Fo), so["nb"]
+    sums = so["part"].view(2, Np, nb).double().sum(-1).cpu()
+    yf = y.float().reshape(-1, Np).double().cpu()
+    assert torch.allclose(sums[0], yf.sum(0), rtol=1e-4, atol=1e-2)
+    assert torch.allclose(sums[1], (yf * yf).sum(0), rtol=1e-4, atol=1e-2)
+    dout = r16(torch.randn(B, g.H, g.W, Fo))
+    dw_ref = cpu_ref.conv_wgrad(dout, x, g).permute(3, 1, 2, 0)                  # -> canonical
+    out = torch.full(tuple(wd.shape), float("nan"), device="cuda")
+    assert hip.upconv_1ch_wgrad(xd, dev(hip, dout), wd, g, out)
+    close(out[..., :1].cpu(), dw_ref, rtol=1e-2)
+    assert float(out[..., 1:].abs().max()) == 0.0
+    out2 = torch.empty_like(out)
+    assert hip.upconv_1ch_wgrad(xd, dev(hip, dout), wd, g, out2) and torch.equal(out, out2)      # deterministic
+
+
+def test_network_with_a_transposed_first_layer_uses_the_streaming_kernels(hip, monkeypatch):
+    """model0 (ConvT 1 -> 64 first): one training step with the streaming path equals the generic path to rounding."""
+    from pathlib import Path
+    from distributeddeeplearning_amd.models import network
+    from distributeddeeplearning_amd.models.ir import ModelSpec
+    from distributeddeeplearning_amd.ops import hip as H_
+    arch = Path(__file__).parent / "fixtures" / "reference_models" / "model0" / "architecture.json"
+    spec = ModelSpec.from_keras_json(arch.read_text())
+    res = {}
+    for flag in (True, False):
+        monkeypatch.setattr(H_, "UPCONV", flag)
+        net = network.Network(spec, "cuda", 5)
+        torch.manual_seed(9)
+        x = torch.rand(16, 28, 28, 1) * 255
+        xd = net.prepare_input(x.cuda())
+        y = net.forward(xd, training=True)
+        dy = torch.ones_like(y) / y.numel()
+        net.backward(dy)
+        first = net.first_param_op()
+        assert first.onech == "up"
+        res[flag] = (y.float().cpu(), first.gkernel.clone().cpu(), net.G.clone().cpu())
+    assert torch.allclose(res[True][0], res[False][0], rtol=2e-2, atol=2e-3)
+    gk_a, gk_b = res[True][1], res[False][1]
+    assert torch.allclose(gk_a, gk_b, rtol=5e-2, atol=2e-2 * float(gk_b.abs().max()) + 1e-12)
