@@ -450,9 +450,18 @@ class ConvOp(Op):
             if need_dw:
                 def wg():
                     xx = x
-                    if self.x_affine is not None:       # the BatchNorm output was never written: rebuild it for
-                        sc, sh, groups, ctrue = self.x_affine       # the weight gradient (on the wgrad branch)
-                        xx = F.hip_backend().bn_apply(x, sc, sh, None, 0.3, ctrue, groups)
+                    if self.x_affine is not None:       # the BatchNorm output was never written
+                        sc, sh, groups, ctrue = self.x_affine
+                        hip = F.hip_backend()
+                        if groups == 1 and hip._is_1x1(g):
+                            # a 1x1 layer is the same GEMM seen from either side: the streaming weight-gradient kernel
+                            # takes OUR input as its X operand and applies the BatchNorm as it stages it
+                            gs = ConvGeom(g.OH, g.OW, g.O, g.H, g.W, g.I, 1, 1).check()
+                            hip.conv_wgrad(x, dy, gs, "A", out=self.gkernel,
+                                           x_affine=(sc.reshape(-1), sh.reshape(-1), ctrue))
+                            self._bias_grad(dy)
+                            return
+                        xx = hip.bn_apply(x, sc, sh, None, 0.3, ctrue, groups)      # rebuild it (on the wgrad branch)
                     F.conv_wgrad(dy, xx, g, "B", out=self.gkernel)
                     self._bias_grad(dy)
                 _BR.run(wg, dy)

@@ -86,7 +86,8 @@ _upconv_wgrad = _sig("ddl_upconv_1ch_wgrad", ci, vp, vp, vp, vp, ci, ci, ci, ci,
                      ci, ci, ci, vp)
 _gather = _sig("ddl_relayout_gather", None, vp, vp, vp, ci, cl, vp)
 _relayout_both = _sig("ddl_relayout_both", None, vp, vp, vp, ci, vp, vp, ci, cl, vp)
-_gemm_sk = _sig("ddl_gemm_sk", ci, vp, vp, vp, vp, cl, ci, ci, ci, ci, cf, vp)
+_gemm_sk = _sig("ddl_gemm_sk", ci, vp, vp, vp, vp, cl, ci, ci, ci, ci, cf, vp, vp, ci, vp, ci, ci, vp)
+_gemm_sk_cols = _sig("ddl_gemm_sk_stats_cols", ci, cl, ci, ci)
 _philox = _sig("ddl_philox_uniform", None, vp, cl, vp, cf, cf, vp)
 _igemm = _sig("ddl_igemm_conv", ci, vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci,
               ci, ci, ci, ci, cf, ci, ci, vp, vp, cf, vp, ci, ci, vp)
@@ -1593,6 +1594,37 @@ def _chk_w(w, shape, name):
 GEMM_SK = os.environ.get("DDL_GEMM_SK", "1") == "1"
 
 
+SK_AFFINE = os.environ.get("DDL_SK_AFFINE", "1") == "1"     # BatchNorm in front of a 1x1 layer applied on load by gemm_sk
+# BatchNorm statistics from gemm_sk's store loop for problems with at least this many rows (below, the separate
+# column reduction over a cache-sized output is as cheap as the epilogue; model0's 57x57x128 layer at batch 512 is
+# 1.66 M rows and 426 MB: the reduction pass alone was 104 us)
+SK_STATS_MIN_ROWS = int(os.environ.get("DDL_SK_STATS_MIN_ROWS", "262144"))
+
+
+def _gemm_sk_call(x, w, bias, y, M, K, Nd, Nw, act, alpha, in_affine=None, stats_out=None):
+    """One launch of the skinny-K GEMM (csrc/hip/gemm_sk.hip).  `in_affine` = (scale, shift, c_true): fp32 rows applied
+    to x as it is loaded; `stats_out`: receives the BatchNorm partials of y ("part", "nb", "img" = 2^30: pixel tiles
+    straddle images, one statistics group only).  Returns False when the problem is outside the kernel's range
+    (nothing launched)."""
+    isc = ish = part = None
+    ict = cols = 0
+    if in_affine is not None:
+        _chk_f32(in_affine[0], K, "in_affine scale")
+        _chk_f32(in_affine[1], K, "in_affine shift")
+        isc, ish, ict = in_affine[0].data_ptr(), in_affine[1].data_ptr(), int(in_affine[2])
+    if stats_out is not None and PCONV_STATS and M >= SK_STATS_MIN_ROWS and int(stats_out.get("groups", 1)) == 1:
+        cols = _gemm_sk_cols(M, K, Nd)
+        if cols > 0:
+            part = torch.empty(2 * Nd * cols, dtype=torch.float32, device=x.device)
+    rc = _gemm_sk(x.data_ptr(), w.data_ptr(), _p(bias), y.data_ptr(), M, K, Nd, Nw, ACT_CODE[act], alpha, isc, ish, ict,
+                  _p(part), cols, 0, _stream())
+    if rc < 0:
+        raise ValueError(f"gemm_sk rejected the problem (rc={rc}): M={M} K={K} N={Nd}")
+    if rc == 0 and part is not None:
+        stats_out["part"], stats_out["nb"], stats_out["img"] = part, cols, 1 << 30
+    return rc == 0
+
+
 def _is_1x1(g: ConvGeom) -> bool:
     """A 1x1 / stride-1 / unpadded correlation: a row-major GEMM over pixels (also Dense)."""
     return (g.KH == g.KW == 1 and g.sh == g.sw == 1 and g.pt == g.pl == 0 and g.OH == g.H and g.OW == g.W
@@ -1784,11 +1816,8 @@ def conv_fprop(x, wA, bias, g: ConvGeom, act=None, alpha=0.3, mul=None, stats_ou
         raise ValueError(f"conv_fprop: weight {tuple(wA.shape)} vs geometry {g}")
     _chk_w(wA, wA.shape, "kernel")
     if _is_1x1(g) and GEMM_SK:
-        rc = _gemm_sk(x.data_ptr(), wA.data_ptr(), _p(bias), y.data_ptr(), B * g.H * g.W, Ip, Op,
-                      min(wA.shape[0], g.O), ACT_CODE[act], alpha, _stream())
-        if rc < 0:
-            raise ValueError(f"gemm_sk rejected the problem (rc={rc}): {g}")
-        if rc == 0:
+        if _gemm_sk_call(x, wA, bias, y, B * g.H * g.W, Ip, Op, min(wA.shape[0], g.O), act, alpha,
+                         stats_out=stats_out if (mul is None and bn_infer is None) else None):
             _mul_inplace(y, mul)
             _done()
             return y
@@ -1822,9 +1851,13 @@ def conv_dgrad(dy, wB, g: ConvGeom, bias=None, act=None, alpha=0.3, mul=None, st
     ngr = max(sgroups, agroups) if (B % sgroups == 0 and max(sgroups, agroups) % min(sgroups, agroups) == 0) else agroups
     ranges = _batch_ranges(B, max(g.H * g.W * Ip, g.OH * g.OW * Op), B // ngr if ngr > 1 else 0)
     plain = g.depthwise or (_is_1x1(g) and GEMM_SK)
+    sk_aff = None
     if in_affine is not None:
         sc_t, sh_t, groups, ictrue = in_affine
-        if plain:
+        if (plain and not g.depthwise and SK_AFFINE and groups == 1 and ranges is None and wB.dim() == 4
+                and _gemm_sk_cols(B * g.H * g.W, Op, Ip) > 0):
+            sk_aff, in_affine = (sc_t.reshape(-1), sh_t.reshape(-1), ictrue), None      # gemm_sk applies it on load
+        elif plain:
             dy = bn_apply(dy, sc_t, sh_t, None, 0.3, ictrue, groups)        # no on-load path there
             in_affine = None
             if aff_sink is not None:    # `aff_sink["x"]`: the materialised operand, kept by the caller
@@ -1862,14 +1895,15 @@ def conv_dgrad(dy, wB, g: ConvGeom, bias=None, act=None, alpha=0.3, mul=None, st
         raise ValueError(f"conv_dgrad: weight {tuple(wB.shape)} vs geometry {g}")
     _chk_w(wB, wB.shape, "kernel")
     if _is_1x1(g) and GEMM_SK:
-        rc = _gemm_sk(dy.data_ptr(), wB.data_ptr(), _p(bias), dx.data_ptr(), B * g.H * g.W, Op, Ip,
-                      min(wB.shape[0], g.I), ACT_CODE[act], alpha, _stream())
-        if rc < 0:
-            raise ValueError(f"gemm_sk rejected the problem (rc={rc}): {g}")
-        if rc == 0:
+        if _gemm_sk_call(dy, wB, bias, dx, B * g.H * g.W, Op, Ip, min(wB.shape[0], g.I), act, alpha, in_affine=sk_aff,
+                         stats_out=stats_out if (mul is None and bn_infer is None) else None):
             _mul_inplace(dx, mul)
             _done()
             return dx
+        if sk_aff is not None:          # (not reached: the range was checked above) materialise for the generic kernels
+            dy = bn_apply(dy, sk_aff[0], sk_aff[1], None, 0.3, sk_aff[2], 1)
+            if aff_sink is not None:
+                aff_sink["x"] = dy
     _igemm_call(dy, wB, bias, dx, g, "dgrad", B, g.OH, g.OW, Op, g.H, g.W, Ip, min(wB.shape[0], g.I),
                 (1, 1), (g.sh, g.sw), act, alpha, mul, stats_out, bn_infer, in_affine, aff_sink)
     return dx
@@ -2106,7 +2140,8 @@ def conv_wgrad(x, dy, g: ConvGeom, layout="A", out=None, box=None, x_affine=None
     if out.numel() != numel:
         raise ValueError(f"conv_wgrad: out has {out.numel()} elements, expected {numel} for layout {layout}")
     _chk_f32(out, numel, "dW")
-    plans = _wgrad2_plans(g, B, Ip, Op, n_lim, c_lim) if (WGRAD_IMPL == "wgrad2" and bias_tail is None) else []
+    plans = _wgrad2_plans(g, B, Ip, Op, n_lim, c_lim) \
+        if (WGRAD_IMPL == "wgrad2" and bias_tail is None and x_affine is None) else []
     if bias_tail is not None and box is None:
         raise ValueError("conv_wgrad: bias_tail needs a custom box")
     bcol, boff, brow = -1, 0, -1

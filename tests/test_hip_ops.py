@@ -1209,3 +1209,36 @@ def test_network_with_a_transposed_first_layer_uses_the_streaming_kernels(hip, m
     assert torch.allclose(res[True][0], res[False][0], rtol=2e-2, atol=2e-3)
     gk_a, gk_b = res[True][1], res[False][1]
     assert torch.allclose(gk_a, gk_b, rtol=5e-2, atol=2e-2 * float(gk_b.abs().max()) + 1e-12)
+
+
+@pytest.mark.parametrize("case", [(40, 21, 21, 64, 128, "softplus"), (3, 9, 11, 24, 40, "relu"), (70, 16, 16, 128, 16, "linear"),
+                                  (5, 7, 7, 8, 64, "tanh")])
+def test_gemm_sk_applies_batchnorm_on_load_and_emits_statistics(hip, case, monkeypatch):
+    """A 1x1 transposed conv behind a BatchNorm (model0's second layer): the skinny-K GEMM reads x through the affine
+    (bit-identical to the materialised BatchNorm output) and its store loop leaves the statistics of the next one."""
+    B, H, W, Cin, Fo, act = case
+    monkeypatch.setattr(hip, "SK_STATS_MIN_ROWS", 0)
+    g = G.conv2d_transpose_geom(H, W, Cin, Fo, (1, 1), (1, 1), (1, 1), "valid")
+    torch.manual_seed(41)
+    x = dev(hip, r16(torch.randn(B, H, W, Cin)))
+    w = padw(hip, r16(torch.randn(Fo, 1, 1, Cin) / math.sqrt(Cin)))
+    b = torch.randn(Fo).cuda()
+    Cp, Np = hip.pad8(Cin), hip.pad8(Fo)
+    sc, sh = (torch.rand(1, Cp) + 0.5).cuda(), torch.randn(1, Cp).cuda()
+    xm = hip.bn_apply(x, sc, sh, None, 0.3, Cin, 1)
+    y_ref = hip.conv_dgrad(xm, w, g, b, act)
+    so = {"groups": 1}
+    y = hip.conv_dgrad(x, w, g, b, act, in_affine=(sc, sh, 1, Cin), stats_out=so)
+    assert torch.equal(y, y_ref)
+    assert "part" in so
+    nb = so["nb"]
+    sums = so["part"].view(2, Np, nb).double().sum(-1).cpu()
+    yf = y.float().reshape(-1, Np).double().cpu()
+    assert torch.allclose(sums[0], yf.sum(0), rtol=1e-4, atol=1e-2)
+    assert torch.allclose(sums[1], (yf * yf).sum(0), rtol=1e-4, atol=1e-2)
+    # the weight gradient of the same layer through the streaming kernel with the affine on its X operand
+    dout = dev(hip, r16(torch.randn(B, g.H, g.W, Fo)))
+    dw_ref = hip.conv_wgrad(dout, xm, g, "B")
+    gs = G.ConvGeom(g.OH, g.OW, g.O, g.H, g.W, g.I, 1, 1).check()
+    dw = hip.conv_wgrad(x, dout, gs, "A", x_affine=(sc.reshape(-1), sh.reshape(-1), Cin))
+    close(dw.cpu(), dw_ref.cpu(), rtol=1e-2)
