@@ -1174,6 +1174,10 @@ static void dw_fast_launch(int mode, const void* a_, const void* w, const float*
     }
 }
 
+extern "C" int ddl_dw_fprop_ring(const void* x, const void* w, const float* bias, void* y, int B, int H, int W, int C,
+                                 int OH, int OW, int K, int sh, int sw, int c_true, int act, float alpha,
+                                 const float* in_scale, const float* in_shift, int in_ctrue, hipStream_t s);
+
 DDL_API int ddl_depthwise(int mode, const void* a, const void* w, const float* bias, void* out, float* part,
                           int B, int H, int W, int C, int OH, int OW, int KH, int KW, int sh, int sw, int dh,
                           int dw, int pt, int pl, int c_true, int act, float alpha, const float* in_scale,
@@ -1182,6 +1186,11 @@ DDL_API int ddl_depthwise(int mode, const void* a, const void* w, const float* b
     if (in_scale && mode == 1) return -1;
     const int cg = C / 8;
     const long in_elems = (long)B * H * W * C, out_elems = (long)B * OH * OW * C;
+    // forward of an unpadded, undilated layer: the LDS-ring kernel (dw_ring.hip) reads every input byte once
+    if (mode == 0 && KH == KW && dh == 1 && dw == 1 && pt == 0 && pl == 0 &&
+        ddl_dw_fprop_ring(a, w, bias, out, B, H, W, C, OH, OW, KH, sh, sw, c_true, act, alpha, in_scale, in_shift,
+                          in_ctrue, s) == 0)
+        return 0;
     if (KH == KW && KH <= 3 && in_elems < (1L << 31) && out_elems < (1L << 31) && sh <= 3 && sw <= 3) {
         DwArgs d;
         d.B = B; d.H = H; d.W = W; d.C = C; d.OH = OH; d.OW = OW; d.sh = sh; d.sw = sw; d.dh = dh; d.dw = dw;
