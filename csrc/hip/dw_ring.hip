@@ -7,7 +7,9 @@
 // 2.1 TB/s of its compulsory traffic.  Here a block owns (image, channel chunk) and walks the image top to bottom:
 // the input rows live in an LDS ring of K + stride rows, every input byte is loaded from global memory exactly once
 // (coalesced 16-byte units, requested one output row ahead into registers, written to the ring after the row's
-// arithmetic), the stencil reads come from LDS, and the weights sit in LDS as fp32.  One barrier per output row.
+// arithmetic), the stencil reads come from LDS, and the weights sit in LDS as fp32.  One barrier per step of R output
+// rows (R > 1 where the ring has room: a 28-pixel-wide stride-1 layer has 208 items and one new input row per output
+// row, and one row per barrier left it bound by the latency of that row's load: 97 us for 191 MB).
 //
 // Optional BatchNorm on load (in_scale / in_shift: a BatchNorm in front of the layer that is never materialised):
 // with every tap inside the image the affine goes on the tap SUM, s * sum_t w_t x_t + h * sum_t w_t, in fp32 -- the
@@ -20,7 +22,7 @@ struct DwRingArgs {
     const float* in_scale; const float* in_shift; int in_ctrue;
     int B, H, W, C, OH, OW, sh, sw, c_true, act;
     float alpha;
-    int Cc, RR;               // channels per block (multiple of 8), ring rows (K + sh)
+    int Cc, RR, R;            // channels per block (multiple of 8), ring rows, output rows per step (barrier)
 };
 
 __device__ __forceinline__ int dwr_fdiv(int x, float inv) { return __float2int_rz(((float)x + 0.5f) * inv); }
@@ -88,29 +90,38 @@ __global__ __launch_bounds__(256) void dw_fprop_ring_kernel(const DwRingArgs a) 
     const float inv_cgc = 1.0f / (float)cgc;
     const DwStage sg{a.x + (size_t)b * a.H * a.W * a.C + c0, ring, upr, cgc, a.W, a.C, a.Cc, a.RR, rowb,
                      1.0f / (float)upr, inv_cgc};
-    // prologue: the first K rows (K <= 3 <= RR - 1 rows, possibly more than one pass of U units)
-    for (int r = 0; r < K; r += a.sh) {
+    // prologue: the window of the first step, in passes of at most R * sh rows (what the staging registers hold)
+    const int R = a.R, step_rows = R * a.sh;
+    const int win0 = min(a.H, (min(R, a.OH) - 1) * a.sh + K);
+    for (int r = 0; r < win0; r += step_rows) {
         dwr_u32x4 v[U];
-        const int nr = min(a.sh, K - r);
+        const int nr = min(step_rows, win0 - r);
         dwr_stage_load<U>(sg, r, nr, v);
         dwr_stage_store<U>(sg, r, nr, v);
     }
     __syncthreads();
 
-    const int items = a.OW * cgc;
+    const int rowitems = a.OW * cgc;
+    const float inv_rowitems = 1.0f / (float)rowitems;
     const int act = a.act;
     const float alpha = a.alpha;
     bf16_t* yb = a.y + (size_t)b * a.OH * a.OW * a.C + c0;
-    for (int oh = 0; oh < a.OH; ++oh) {
-        // the rows the NEXT output row adds to the window, requested now, written to the ring after this row's math
-        // (after the last row: an unconditional load of row 0 that is never stored -- a conditional one put the
-        // staging registers into scratch memory)
-        const bool more = oh + 1 < a.OH;
-        const int nr0 = more ? oh * a.sh + K : 0, nrn = more ? min(a.sh, a.H - nr0) : 1;
+    for (int oh0 = 0; oh0 < a.OH; oh0 += R) {
+        // the rows the NEXT step adds to the window, requested now, written to the ring after this step's math
+        // (after the last step: an unconditional load of row 0 that is never stored -- a conditional one, or HIP's
+        // uint4 struct instead of a vector type, put the staging registers into scratch memory)
+        const int ohn = oh0 + R;                                // first output row of the next step
+        const bool more = ohn < a.OH;
+        const int have = (ohn - 1) * a.sh + K;                  // input rows [0, have) are in the ring
+        const int need = more ? (min(ohn + R, a.OH) - 1) * a.sh + K : 0;
+        const int nr0 = more ? have : 0, nrn = more ? need - have : 1;
         dwr_u32x4 nv[U];
         dwr_stage_load<U>(sg, nr0, nrn, nv);
+        const int items = min(R, a.OH - oh0) * rowitems;
         for (int it = tid; it < items; it += 256) {
-            const int ow = dwr_fdiv(it, inv_cgc), g8 = it - ow * cgc;
+            const int rl = dwr_fdiv(it, inv_rowitems), q = it - rl * rowitems;
+            const int ow = dwr_fdiv(q, inv_cgc), g8 = q - ow * cgc;
+            const int oh = oh0 + rl;
             float acc[8];
 #pragma unroll
             for (int j = 0; j < 8; ++j) acc[j] = 0.f;
@@ -155,25 +166,32 @@ extern "C" int ddl_dw_fprop_ring(const void* x, const void* w, const float* bias
     if (!on || K < 1 || K > 3 || sh < 1 || sh > 3 || sw < 1 || sw > 3 || C % 8) return 1;
     if ((OH - 1) * sh + K > H || (OW - 1) * sw + K > W || OH < 1 || OW < 1) return 1;      // every tap inside the image
     if ((long)H * W * C >= (1L << 24)) return 1;                    // per-image index math in 32 bits / dwr_fdiv's range
-    const int RR = K + sh;
     static const long budget = getenv("DDL_DW_RING_LDS_KB") ? atol(getenv("DDL_DW_RING_LDS_KB")) * 1024 : 36 * 1024;
-    // channel chunk: the whole layer if its ring fits the budget, else the largest multiple of 8 that does
+    static const int rmax = getenv("DDL_DW_RING_ROWS") ? atoi(getenv("DDL_DW_RING_ROWS")) : 4;
+    // channel chunk: the whole layer if a one-row-per-step ring fits the budget, else the largest multiple of 8 that does
     int Cc = C;
-    while (Cc > 8 && (long)RR * W * Cc * 2 > budget) Cc = ((Cc / 2) + 7) / 8 * 8;
+    while (Cc > 8 && (long)(K + sh) * W * Cc * 2 > budget) Cc = ((Cc / 2) + 7) / 8 * 8;
     // ... and enough blocks for four per CU while a pixel's chunk stays at least 64 bytes
     while (Cc > 32 && (long)B * ((C + Cc - 1) / Cc) < 1024) Cc = ((Cc / 2) + 7) / 8 * 8;
+    // output rows per step: as many as the ring has room for (window (R-1) sh + K rows + R sh incoming rows) and the
+    // staging registers hold (R sh W Cc / 8 units over 256 threads, at most 8 each)
+    int R = 1;
+    while (R < rmax && R < OH && (long)((2 * (R + 1) - 1) * sh + K) * W * Cc * 2 <= budget &&
+           (long)(R + 1) * sh * W * (Cc / 8) <= 256 * 8)
+        ++R;
+    const int RR = (2 * R - 1) * sh + K;
     const size_t smem = (size_t)RR * W * Cc * 2 + (size_t)(K * K + 2) * Cc * 4;
     if (smem > 64 * 1024) return 1;
-    const int units = sh * W * (Cc / 8);                            // staged per output row
+    const int units = R * sh * W * (Cc / 8);                        // staged per step
     const int U = (units + 255) / 256;
     if (U > 8) return 1;
     DwRingArgs a{(const bf16_t*)x, (const bf16_t*)w, bias, (bf16_t*)y, in_scale, in_shift, in_ctrue,
-                 B, H, W, C, OH, OW, sh, sw, c_true, act, alpha, Cc, RR};
+                 B, H, W, C, OH, OW, sh, sw, c_true, act, alpha, Cc, RR, R};
     const dim3 grid(B, (C + Cc - 1) / Cc);
 #define DWR_CASE(K_, U_) if (K == K_ && U <= U_) { dw_fprop_ring_kernel<K_, U_><<<grid, 256, smem, s>>>(a); return 0; }
-    DWR_CASE(1, 2) DWR_CASE(1, 4) DWR_CASE(1, 8)
-    DWR_CASE(2, 2) DWR_CASE(2, 4) DWR_CASE(2, 8)
-    DWR_CASE(3, 2) DWR_CASE(3, 4) DWR_CASE(3, 8)
+    DWR_CASE(1, 1) DWR_CASE(1, 2) DWR_CASE(1, 4) DWR_CASE(1, 8)
+    DWR_CASE(2, 1) DWR_CASE(2, 2) DWR_CASE(2, 4) DWR_CASE(2, 8)
+    DWR_CASE(3, 1) DWR_CASE(3, 2) DWR_CASE(3, 4) DWR_CASE(3, 8)
 #undef DWR_CASE
     return 1;
 }
