@@ -12,53 +12,103 @@
 // Row losses go to rowloss[B]; dlogits (bf16, [B][Cs], pad = 0) already carry the 1/B mean factor.
 // `index` (optional): row r's target is target[index[r]] -- the label gather of a minibatch drawn by index from the
 // HBM-resident dataset happens here, not in a gather pass of its own.
+__global__ void mean_kernel(const float* __restrict__ v, long n, float scale, float* __restrict__ out);
+
+// NV: compile-time bound on N (16 / 64): the row lives in registers (a run-time-indexed v[64] went to scratch memory:
+// 272 bytes per lane and 12 us for 512 rows of 10 classes).  MEAN: the launch is ONE block covering every row, and it
+// also leaves mean(rowloss) in loss_out (same double-precision tree as mean_kernel) -- one dispatch per loss instead
+// of two.
+template <int NV, bool MEAN>
 __global__ void softmax_loss_kernel(const bf16_t* __restrict__ logits, const float* __restrict__ target,
                                     const long* __restrict__ index, float* __restrict__ probs,
-                                    bf16_t* __restrict__ dlogits, float* __restrict__ rowloss, int B, int Cs, int N,
-                                    int mode, int want_grad) {
-    int r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= B) return;
-    const bf16_t* l = logits + (size_t)r * Cs;
-    float v[64];
-    float mx = -3.0e38f;
-    for (int j = 0; j < N; ++j) { v[j] = bf2f(l[j]); mx = fmaxf(mx, v[j]); }
-    float sum = 0.f;
-    for (int j = 0; j < N; ++j) { v[j] = __expf(v[j] - mx); sum += v[j]; }
-    float inv = 1.f / sum;
-    for (int j = 0; j < N; ++j) v[j] *= inv;
-    if (probs) for (int j = 0; j < N; ++j) probs[(size_t)r * N + j] = v[j];
-    if (mode == 0) return;
-    const float* t = target + (size_t)(index ? index[r] : r) * N;
+                                    bf16_t* __restrict__ dlogits, float* __restrict__ rowloss,
+                                    float* __restrict__ loss_out, int B, int Cs, int N, int mode, int want_grad) {
+    __shared__ double red[MEAN ? 1024 : 1];
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
     float loss = 0.f;
-    if (mode == 1) {
-        float tsum = 0.f;
-        for (int j = 0; j < N; ++j) {
-            float pc = fminf(fmaxf(v[j], 1e-7f), 1.f - 1e-7f);
-            loss -= t[j] * __logf(pc);
-            tsum += t[j];
+    if (r < B) {
+        const bf16_t* l = logits + (size_t)r * Cs;
+        float v[NV];
+        if (NV == 16 && Cs == 16) {                 // the common head: 10 classes padded to 16 = two 16-byte loads
+            unpack8(*(const uint4*)l, v);
+            unpack8(*(const uint4*)(l + 8), v + 8);
+        } else {
+#pragma unroll
+            for (int j = 0; j < NV; ++j) v[j] = j < N ? bf2f(l[j]) : 0.f;
         }
-        if (want_grad) {
-            bf16_t* d = dlogits + (size_t)r * Cs;
-            float ib = 1.f / (float)B;
-            for (int j = 0; j < N; ++j) d[j] = f2bf((v[j] * tsum - t[j]) * ib);
-            for (int j = N; j < Cs; ++j) d[j] = 0;
+        float mx = -3.0e38f;
+#pragma unroll
+        for (int j = 0; j < NV; ++j) mx = j < N ? fmaxf(mx, v[j]) : mx;
+        float sum = 0.f;
+#pragma unroll
+        for (int j = 0; j < NV; ++j) { v[j] = j < N ? __expf(v[j] - mx) : 0.f; sum += v[j]; }
+        const float inv = 1.f / sum;
+#pragma unroll
+        for (int j = 0; j < NV; ++j) v[j] *= inv;
+        if (probs) {
+#pragma unroll
+            for (int j = 0; j < NV; ++j)
+                if (j < N) probs[(size_t)r * N + j] = v[j];
         }
-    } else {
-        float dot = 0.f;
-        float k = 2.f / ((float)B * (float)N);
-        for (int j = 0; j < N; ++j) {
-            float df = v[j] - t[j];
-            loss += df * df;
-            dot += k * df * v[j];
-        }
-        loss /= (float)N;
-        if (want_grad) {
-            bf16_t* d = dlogits + (size_t)r * Cs;
-            for (int j = 0; j < N; ++j) d[j] = f2bf(v[j] * (k * (v[j] - t[j]) - dot));
-            for (int j = N; j < Cs; ++j) d[j] = 0;
+        if (mode != 0) {
+            const float* tp = target + (size_t)(index ? index[r] : r) * N;
+            float t[NV];
+#pragma unroll
+            for (int j = 0; j < NV; ++j) t[j] = j < N ? tp[j] : 0.f;
+            float d[NV];
+            if (mode == 1) {
+                float tsum = 0.f;
+#pragma unroll
+                for (int j = 0; j < NV; ++j) {
+                    if (j < N) {
+                        const float pc = fminf(fmaxf(v[j], 1e-7f), 1.f - 1e-7f);
+                        loss -= t[j] * __logf(pc);
+                        tsum += t[j];
+                    }
+                }
+                const float ib = 1.f / (float)B;
+#pragma unroll
+                for (int j = 0; j < NV; ++j) d[j] = j < N ? (v[j] * tsum - t[j]) * ib : 0.f;
+            } else {
+                float dot = 0.f;
+                const float k = 2.f / ((float)B * (float)N);
+#pragma unroll
+                for (int j = 0; j < NV; ++j) {
+                    if (j < N) {
+                        const float df = v[j] - t[j];
+                        loss += df * df;
+                        dot += k * df * v[j];
+                    }
+                }
+                loss /= (float)N;
+#pragma unroll
+                for (int j = 0; j < NV; ++j) d[j] = j < N ? v[j] * (k * (v[j] - t[j]) - dot) : 0.f;
+            }
+            if (want_grad) {
+                bf16_t* dp = dlogits + (size_t)r * Cs;
+                if (NV == 16 && Cs == 16) {
+                    *(uint4*)dp = pack8(d);
+                    *(uint4*)(dp + 8) = pack8(d + 8);
+                } else {
+#pragma unroll
+                    for (int j = 0; j < NV; ++j)
+                        if (j < Cs) dp[j] = f2bf(d[j]);
+                    for (int j = NV; j < Cs; ++j) dp[j] = 0;
+                }
+            }
+            rowloss[r] = loss;
         }
     }
-    rowloss[r] = loss;
+    if (MEAN && mode != 0) {
+        // blockDim.x is a power of two >= B: the tree pairs rows exactly as mean_kernel's strided walk + tree does
+        red[threadIdx.x] = r < B ? (double)loss : 0.0;
+        __syncthreads();
+        for (int o = blockDim.x / 2; o > 0; o >>= 1) {
+            if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) loss_out[0] = (float)(red[0] * (1.0 / (double)B));
+    }
 }
 
 // mean of n floats -> out[0] (single block, deterministic order)
@@ -78,9 +128,23 @@ __global__ void mean_kernel(const float* __restrict__ v, long n, float scale, fl
 DDL_API void ddl_softmax_loss(const void* logits, const float* target, const long* index, float* probs,
                               void* dlogits, float* rowloss, float* loss_out, int B, int Cs, int N, int mode,
                               int want_grad, hipStream_t s) {
-    softmax_loss_kernel<<<(B + 127) / 128, 128, 0, s>>>((const bf16_t*)logits, target, index, probs,
-                                                        (bf16_t*)dlogits, rowloss, B, Cs, N, mode, want_grad);
-    if (mode != 0) mean_kernel<<<1, LB, 0, s>>>(rowloss, B, 1.0 / (double)B, loss_out);
+    const bf16_t* lg = (const bf16_t*)logits;
+    bf16_t* dl = (bf16_t*)dlogits;
+    const bool small = N <= 16;
+    if (B <= 1024 && mode != 0 && loss_out) {       // one block: losses, gradients and the mean loss in one launch
+        int threads = 64;
+        while (threads < B) threads *= 2;
+        if (small) softmax_loss_kernel<16, true><<<1, threads, 0, s>>>(lg, target, index, probs, dl, rowloss, loss_out,
+                                                                        B, Cs, N, mode, want_grad);
+        else softmax_loss_kernel<64, true><<<1, threads, 0, s>>>(lg, target, index, probs, dl, rowloss, loss_out, B, Cs,
+                                                                  N, mode, want_grad);
+        return;
+    }
+    if (small) softmax_loss_kernel<16, false><<<(B + 127) / 128, 128, 0, s>>>(lg, target, index, probs, dl, rowloss,
+                                                                               loss_out, B, Cs, N, mode, want_grad);
+    else softmax_loss_kernel<64, false><<<(B + 127) / 128, 128, 0, s>>>(lg, target, index, probs, dl, rowloss, loss_out,
+                                                                         B, Cs, N, mode, want_grad);
+    if (mode != 0 && loss_out) mean_kernel<<<1, LB, 0, s>>>(rowloss, B, 1.0 / (double)B, loss_out);
 }
 
 // ------------------------------------------------------------------------------ sigmoid BCE
