@@ -23,6 +23,7 @@ struct DwRingArgs {
     int B, H, W, C, OH, OW, sh, sw, c_true, act;
     float alpha;
     int Cc, RR, R;            // channels per block (multiple of 8), ring rows, output rows per step (barrier)
+    float* stats;             // BatchNorm partials of the stored output, part[2][C][B] (column = image), or null
 };
 
 __device__ __forceinline__ int dwr_fdiv(int x, float inv) { return __float2int_rz(((float)x + 0.5f) * inv); }
@@ -103,6 +104,9 @@ __global__ __launch_bounds__(256) void dw_fprop_ring_kernel(const DwRingArgs a) 
 
     const int rowitems = a.OW * cgc;
     const float inv_rowitems = 1.0f / (float)rowitems;
+    float st_s[8], st_q[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) st_s[j] = st_q[j] = 0.f;
     const int act = a.act;
     const float alpha = a.alpha;
     bf16_t* yb = a.y + (size_t)b * a.OH * a.OW * a.C + c0;
@@ -151,17 +155,51 @@ __global__ __launch_bounds__(256) void dw_fprop_ring_kernel(const DwRingArgs a) 
                 for (int j = 0; j < 8; ++j)
                     acc[j] = c0 + g8 * 8 + j < a.c_true ? act_apply_k<decltype(KA)::value>(acc[j], act, alpha) : 0.f;
             });
-            *(uint4*)(yb + ((size_t)oh * a.OW + ow) * a.C + g8 * 8) = pack8(acc);
+            const uint4 o = pack8(acc);
+            *(uint4*)(yb + ((size_t)oh * a.OW + ow) * a.C + g8 * 8) = o;
+            if (a.stats) {                  // (host-checked: 256 % cgc == 0, a thread's channel group never changes)
+                float r[8];
+                unpack8(o, r);              // what the stored tensor holds
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    st_s[j] += r[j];
+                    st_q[j] = fmaf(r[j], r[j], st_q[j]);
+                }
+            }
         }
         if (more) dwr_stage_store<U>(sg, nr0, nrn, nv);
         __syncthreads();
+    }
+    if (a.stats) {
+        // lanes l, l + cgc, ... of a wave hold different pixels of one channel group: fold them, then the four waves
+        const int lane = tid & 63, wave = tid >> 6;
+        for (int off = cgc; off < 64; off <<= 1)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                st_s[j] += __shfl_xor(st_s[j], off, 64);
+                st_q[j] += __shfl_xor(st_q[j], off, 64);
+            }
+        float* red = (float*)smem;          // [4 waves][2][a.Cc]  (the ring is no longer read: barrier above)
+        if (lane < cgc) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                red[(wave * 2 + 0) * a.Cc + lane * 8 + j] = st_s[j];
+                red[(wave * 2 + 1) * a.Cc + lane * 8 + j] = st_q[j];
+            }
+        }
+        __syncthreads();
+        for (int i = tid; i < 2 * Cc; i += 256) {
+            const int k = i / Cc, c = i - k * Cc;
+            const float v = ((red[k * a.Cc + c] + red[(2 + k) * a.Cc + c]) + red[(4 + k) * a.Cc + c]) + red[(6 + k) * a.Cc + c];
+            a.stats[((size_t)k * a.C + c0 + c) * a.B + b] = v;
+        }
     }
 }
 
 // Returns 0 on success, 1 if the layer is outside this kernel's range (nothing launched).
 extern "C" int ddl_dw_fprop_ring(const void* x, const void* w, const float* bias, void* y, int B, int H, int W, int C,
                                  int OH, int OW, int K, int sh, int sw, int c_true, int act, float alpha,
-                                 const float* in_scale, const float* in_shift, int in_ctrue, hipStream_t s) {
+                                 const float* in_scale, const float* in_shift, int in_ctrue, float* stats, hipStream_t s) {
     static const int on = getenv("DDL_DW_RING") ? atoi(getenv("DDL_DW_RING")) : 1;
     if (!on || K < 1 || K > 3 || sh < 1 || sh > 3 || sw < 1 || sw > 3 || C % 8) return 1;
     if ((OH - 1) * sh + K > H || (OW - 1) * sw + K > W || OH < 1 || OW < 1) return 1;      // every tap inside the image
@@ -180,13 +218,15 @@ extern "C" int ddl_dw_fprop_ring(const void* x, const void* w, const float* bias
            (long)(R + 1) * sh * W * (Cc / 8) <= 256 * 8)
         ++R;
     const int RR = (2 * R - 1) * sh + K;
-    const size_t smem = (size_t)RR * W * Cc * 2 + (size_t)(K * K + 2) * Cc * 4;
+    size_t smem = (size_t)RR * W * Cc * 2 + (size_t)(K * K + 2) * Cc * 4;
+    if (smem < (size_t)32 * Cc) smem = (size_t)32 * Cc;             // the statistics epilogue's [4 waves][2][Cc] scratch
     if (smem > 64 * 1024) return 1;
     const int units = R * sh * W * (Cc / 8);                        // staged per step
     const int U = (units + 255) / 256;
     if (U > 8) return 1;
     DwRingArgs a{(const bf16_t*)x, (const bf16_t*)w, bias, (bf16_t*)y, in_scale, in_shift, in_ctrue,
-                 B, H, W, C, OH, OW, sh, sw, c_true, act, alpha, Cc, RR, R};
+                 B, H, W, C, OH, OW, sh, sw, c_true, act, alpha, Cc, RR, R, stats};
+    if (stats && (256 % (Cc / 8) || C % Cc)) return 1;      // a thread keeps one channel group; full chunks only
     const dim3 grid(B, (C + Cc - 1) / Cc);
 #define DWR_CASE(K_, U_) if (K == K_ && U <= U_) { dw_fprop_ring_kernel<K_, U_><<<grid, 256, smem, s>>>(a); return 0; }
     DWR_CASE(1, 1) DWR_CASE(1, 2) DWR_CASE(1, 4) DWR_CASE(1, 8)

@@ -1176,7 +1176,18 @@ static void dw_fast_launch(int mode, const void* a_, const void* w, const float*
 
 extern "C" int ddl_dw_fprop_ring(const void* x, const void* w, const float* bias, void* y, int B, int H, int W, int C,
                                  int OH, int OW, int K, int sh, int sw, int c_true, int act, float alpha,
-                                 const float* in_scale, const float* in_shift, int in_ctrue, hipStream_t s);
+                                 const float* in_scale, const float* in_shift, int in_ctrue, float* stats, hipStream_t s);
+
+// Forward with the BatchNorm statistics partials of the output (part[2][C][B], one column per image): only the ring
+// kernel has that epilogue.  Returns 0 on success, 1 when the layer is outside its range (nothing launched: the caller
+// runs the plain forward and a reduction pass).
+DDL_API int ddl_depthwise_fwd_stats(const void* x, const void* w, const float* bias, void* y, float* stats, int B, int H,
+                                    int W, int C, int OH, int OW, int K, int sh, int sw, int c_true, int act, float alpha,
+                                    const float* in_scale, const float* in_shift, int in_ctrue, hipStream_t s) {
+    if (!stats) return 1;
+    return ddl_dw_fprop_ring(x, w, bias, y, B, H, W, C, OH, OW, K, sh, sw, c_true, act, alpha, in_scale, in_shift,
+                             in_ctrue, stats, s);
+}
 
 DDL_API int ddl_depthwise(int mode, const void* a, const void* w, const float* bias, void* out, float* part,
                           int B, int H, int W, int C, int OH, int OW, int KH, int KW, int sh, int sw, int dh,
@@ -1189,7 +1200,7 @@ DDL_API int ddl_depthwise(int mode, const void* a, const void* w, const float* b
     // forward of an unpadded, undilated layer: the LDS-ring kernel (dw_ring.hip) reads every input byte once
     if (mode == 0 && KH == KW && dh == 1 && dw == 1 && pt == 0 && pl == 0 &&
         ddl_dw_fprop_ring(a, w, bias, out, B, H, W, C, OH, OW, KH, sh, sw, c_true, act, alpha, in_scale, in_shift,
-                          in_ctrue, s) == 0)
+                          in_ctrue, nullptr, s) == 0)
         return 0;
     if (KH == KW && KH <= 3 && in_elems < (1L << 31) && out_elems < (1L << 31) && sh <= 3 && sw <= 3) {
         DwArgs d;

@@ -107,6 +107,8 @@ _slab_reduce = _sig("ddl_slab_reduce", None, vp, vp, cl, cl, ci, vp)
 _dw_blocks = _sig("ddl_dw_wgrad_blocks", ci, cl, ci)
 _dw_dgrad_bn = _sig("ddl_dw_dgrad_bn", ci, ci, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci,
                     vp, vp, vp, vp, vp, ci, cf, ci, vp)
+_dw_fwd_stats = _sig("ddl_depthwise_fwd_stats", ci, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, cf,
+                     vp, vp, ci, vp)
 _depthwise = _sig("ddl_depthwise", ci, ci, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci,
                   ci, ci, ci, ci, cf, vp, vp, ci, vp)
 
@@ -668,6 +670,7 @@ def tapconv_1ch(img, w, g: ConvGeom, bias=None, act=None, alpha=0.3, out=None, b
 
 
 UPCONV = os.environ.get("DDL_UPCONV", "1") == "1"
+DW_STATS = os.environ.get("DDL_DW_STATS", "1") == "1"       # BatchNorm statistics out of the depthwise ring forward
 
 
 def _upconv_shape(x, w, g: ConvGeom, name, wgrad=0):
@@ -1797,6 +1800,15 @@ def conv_fprop(x, wA, bias, g: ConvGeom, act=None, alpha=0.3, mul=None, stats_ou
             _chk_f32(in_affine[0], Ip, "in_affine scale")
             _chk_f32(in_affine[1], Ip, "in_affine shift")
             isc, ish, ict = in_affine[0].data_ptr(), in_affine[1].data_ptr(), int(in_affine[3])
+        if (stats_out is not None and PCONV_STATS and DW_STATS and mul is None and bn_infer is None and sgroups == 1
+                and g.KH == g.KW and g.dh == g.dw == 1 and g.pt == g.pl == 0):
+            # the row-ring kernel also leaves the statistics of the BatchNorm behind the layer (one column per image)
+            part = torch.empty(2 * Ip * B, dtype=torch.float32, device=x.device)
+            if _dw_fwd_stats(x.data_ptr(), wA.data_ptr(), _p(bias), y.data_ptr(), part.data_ptr(), B, g.H, g.W, Ip,
+                             g.OH, g.OW, g.KH, g.sh, g.sw, g.O, ACT_CODE[act], alpha, isc, ish, ict, _stream()) == 0:
+                stats_out["part"], stats_out["nb"], stats_out["img"] = part, B, 1
+                _done()
+                return y
         rc = _depthwise(0, x.data_ptr(), wA.data_ptr(), _p(bias), y.data_ptr(), None, B, g.H, g.W, Ip, g.OH, g.OW,
                         g.KH, g.KW, g.sh, g.sw, g.dh, g.dw, g.pt, g.pl, g.O, ACT_CODE[act], alpha, isc, ish, ict,
                         _stream())

@@ -1246,3 +1246,29 @@ def test_gemm_sk_applies_batchnorm_on_load_and_emits_statistics(hip, case, monke
     gs = G.ConvGeom(g.OH, g.OW, g.O, g.H, g.W, g.I, 1, 1).check()
     dw = hip.conv_wgrad(x, dout, gs, "A", x_affine=(sc.reshape(-1), sh.reshape(-1), Cin))
     close(dw.cpu(), dw_ref.cpu(), rtol=1e-2)
+
+
+@pytest.mark.parametrize("case", [(57, 57, 128, 3, 2, "relu"), (28, 28, 128, 3, 1, "tanh"), (10, 10, 128, 2, 3, "sigmoid"),
+                                  (18, 18, 16, 3, 1, "softsign"), (5, 4, 24, 3, 1, "linear")])
+def test_depthwise_ring_forward_emits_batchnorm_statistics(hip, case):
+    """The row-ring depthwise forward leaves the partial sums of its stored output (one column per image): equal to a
+    column reduction of the tensor, and the output equal to the plain launch."""
+    H, W, Cc, k, s, act = case
+    g = G.depthwise_geom(H, W, Cc, (k, k), (s, s), (1, 1), "valid")
+    B = 6
+    torch.manual_seed(61)
+    x = dev(hip, r16(torch.randn(B, H, W, Cc)))
+    w = padw(hip, r16(torch.randn(k, k, Cc) / k))
+    b = torch.randn(Cc).cuda()
+    y0 = hip.conv_fprop(x, w, b, g, act)
+    so = {"groups": 1}
+    y = hip.conv_fprop(x, w, b, g, act, stats_out=so)
+    assert torch.equal(y, y0)
+    if "part" not in so:            # channel chunking outside the epilogue's range (e.g. 24 channels): plain path
+        assert Cc % 16
+        return
+    Cp, nb = hip.pad8(Cc), so["nb"]
+    sums = so["part"].view(2, Cp, nb).double().sum(-1).cpu()
+    yf = y.float().reshape(-1, Cp).double().cpu()
+    assert torch.allclose(sums[0], yf.sum(0), rtol=1e-4, atol=1e-2)
+    assert torch.allclose(sums[1], (yf * yf).sum(0), rtol=1e-4, atol=1e-2)
