@@ -31,6 +31,12 @@ struct UpArgs {
     int bands, rpb;               // bands per class, class rows per band
     int ipb;                      // images per block (weight gradient: fewer, fatter slabs)
     int lps;                      // log2(Np / 8): lanes per pixel
+    // weight gradient only (BNB instantiation): the layer is followed by a batch-statistics BatchNorm and `y` is the
+    // gradient at that BatchNorm's OUTPUT; the gradient at its input -- dx = act'(bx) * (k0 g + k1 bx + k2), what
+    // bn_bwd_apply would write -- is formed on load from g and the BatchNorm's input bx (= this layer's own output)
+    // and never stored: the first layer is its only consumer.
+    const bf16_t* bx; const float *bmean, *binvstd, *bgamma, *bc1, *bc2;
+    int bact; float balpha;
 };
 
 __device__ __forceinline__ int up_fdiv(int x, float inv) { return __float2int_rz(((float)x + 0.5f) * inv); }
@@ -201,15 +207,28 @@ __global__ __launch_bounds__(256) void upconv_1ch_fwd_kernel(const UpArgs a) {
 }
 
 // dW partials: slab[block][t * Np + n] = sum over the block's pixels of dY[.][n] * x[tap t of the pixel]
-template <int K>
+template <int K, bool BNB>
 __global__ __launch_bounds__(256) void upconv_1ch_wgrad_kernel(const UpArgs a) {
-    constexpr int T = K * K, U = 4;
+    constexpr int T = K * K, U = BNB ? 2 : 4;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* plane = (float*)smem;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const UpBlock u = up_block<K>(a);
     const int LP = 1 << a.lps;
     const int cg = tid & (LP - 1);
+    // BNB: k0 = gamma * is, k1 = -gamma * is * is * c2, k2 = -gamma * is * (c1 - mean * is * c2) per channel, in LDS
+    // behind the plane (24 registers of coefficients would cost a wave of occupancy)
+    float* kco = plane + ((a.PH * a.PW + 3) & ~3);          // [3][Np]
+    if (BNB) {
+        for (int c = tid; c < a.Np; c += 256) {
+            const bool real = c < a.N;
+            const float is = real ? a.binvstd[c] : 0.f, gi = real ? a.bgamma[c] * is : 0.f;
+            const float c2 = real ? a.bc2[c] : 0.f, c1 = real ? a.bc1[c] : 0.f, mu = real ? a.bmean[c] : 0.f;
+            kco[c] = gi;
+            kco[a.Np + c] = -gi * is * c2;
+            kco[2 * a.Np + c] = -gi * (c1 - mu * is * c2);
+        }
+    }
 
     float acc[T][8];
 #pragma unroll
@@ -222,8 +241,9 @@ __global__ __launch_bounds__(256) void upconv_1ch_wgrad_kernel(const UpArgs a) {
     __syncthreads();                         // every lane is done with the previous image's plane
     up_stage(a, plane, b);
     const bf16_t* yb = a.y + (size_t)b * a.H * a.W * a.Np;
+    const bf16_t* xbb = BNB ? a.bx + (size_t)b * a.H * a.W * a.Np : nullptr;
     for (int base = tid; base < total; base += 256 * U) {
-        uint4 v[U];
+        uint4 v[U], vx[BNB ? U : 1];
         int pb[U];
         bool ok[U];
 #pragma unroll
@@ -236,11 +256,31 @@ __global__ __launch_bounds__(256) void upconv_1ch_wgrad_kernel(const UpArgs a) {
             const int h = u.h_first + a.sh * i, w = u.w_first + a.sw * j;
             pb[k] = (u.m_first + i + a.halo_h) * a.PW + u.n_first + j + a.halo_w;
             v[k] = *(const uint4*)(yb + (unsigned)((h * a.W + w) * a.Np + cg * 8));
+            if (BNB) vx[k] = *(const uint4*)(xbb + (unsigned)((h * a.W + w) * a.Np + cg * 8));
         }
 #pragma unroll
         for (int k = 0; k < U; ++k) {
             float d[8];
             unpack8(v[k], d);
+            if (BNB) {
+                float xf[8], k0[8], k1[8], k2[8];
+                unpack8(vx[k], xf);
+                *(float4*)k0 = *(const float4*)(kco + cg * 8);  *(float4*)(k0 + 4) = *(const float4*)(kco + cg * 8 + 4);
+                *(float4*)k1 = *(const float4*)(kco + a.Np + cg * 8);
+                *(float4*)(k1 + 4) = *(const float4*)(kco + a.Np + cg * 8 + 4);
+                *(float4*)k2 = *(const float4*)(kco + 2 * a.Np + cg * 8);
+                *(float4*)(k2 + 4) = *(const float4*)(kco + 2 * a.Np + cg * 8 + 4);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) d[e] = fmaf(k0[e], d[e], fmaf(k1[e], xf[e], k2[e]));
+                act_switch(a.bact, [&](auto KA) {
+                    if (decltype(KA)::value != ACT_LINEAR) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) d[e] *= act_grad_y_k<decltype(KA)::value>(xf[e], a.bact, a.balpha);
+                    }
+                });
+#pragma unroll
+                for (int e = 0; e < 8; ++e) d[e] = bf2f(f2bf(d[e]));        // the rounding of the tensor it replaces
+            }
 #pragma unroll
             for (int t = 0; t < T; ++t)
                 if (u.live & (1u << t)) {
@@ -338,7 +378,7 @@ static int up_fill(UpArgs& a, const void* x, const void* w, const float* bias, v
     const int classes = sh * sw, rows = (H + sh - 1) / sh;
     int bands = 1, ipb = 1;
     while ((long)B * classes * bands < target && bands * 2 <= rows) bands *= 2;
-    while (bands == 1 && (long)((B + 2 * ipb - 1) / (2 * ipb)) * classes >= target) ipb *= 2;
+    if (bands == 1 && (long)B * classes > target) ipb = (int)(((long)B * classes + target - 1) / target);
     a.bands = bands;
     a.rpb = (rows + bands - 1) / bands;
     a.ipb = ipb;
@@ -346,9 +386,10 @@ static int up_fill(UpArgs& a, const void* x, const void* w, const float* bias, v
     return 0;
 }
 
-static long up_target(int wgrad) {
-    static const long tf = up_env("DDL_UP_FWD_BLOCKS", 2048), tw = up_env("DDL_UP_WG_BLOCKS", 1024);
-    return wgrad ? tw : tf;
+static long up_target(int wgrad) {     // 0: forward, 1: weight gradient, 2: weight gradient with the BatchNorm backward on load
+    static const long tf = up_env("DDL_UP_FWD_BLOCKS", 2048), tw = up_env("DDL_UP_WG_BLOCKS", 1024),
+                      tb = up_env("DDL_UP_WGBN_BLOCKS", 768);      // (149 registers: three blocks per CU, one round)
+    return wgrad == 2 ? tb : (wgrad ? tw : tf);
 }
 
 // Statistics columns (forward, wgrad = 0) / slabs (weight gradient, wgrad = 1) of a launch.  0: outside the kernels' range.
@@ -386,24 +427,38 @@ DDL_API int ddl_upconv_1ch(const void* x, const void* w, const float* bias, void
 
 // dW into the canonical fp32 gradient [N][KH*KW][Cw] (channel 0; the padding channels are written as zeros).
 // `slab`: ddl_upconv_1ch_blocks(1, ...) * KH*KW*Np floats of scratch.
+// bn_x (optional, with bn_mean .. bn_c2 fp32 [>= N]): dy is the gradient at the OUTPUT of the batch-statistics BatchNorm
+// behind the layer, bn_x that BatchNorm's input; its backward apply step (coefficients c1, c2 from ddl_bn_bwd's finalize,
+// bn_act = the layer's own activation, whose derivative is taken through bn_x) is performed on load.
 DDL_API int ddl_upconv_1ch_wgrad(const void* x, const void* dy, float* slab, float* out, int B, int IH, int IW, int Cs,
                                  int Cw, int H, int W, int Np, int N, int KH, int KW, int sh, int sw, int dh, int dw,
-                                 int pt, int pl, hipStream_t s) {
+                                 int pt, int pl, const void* bn_x, const float* bn_mean, const float* bn_invstd,
+                                 const float* bn_gamma, const float* bn_c1, const float* bn_c2, int bn_act,
+                                 float bn_alpha, hipStream_t s) {
     UpArgs a;
     const int rc = up_fill(a, x, nullptr, nullptr, const_cast<void*>(dy), slab, B, IH, IW, Cs, Cw, H, W, Np, N, KH, KW,
-                           sh, sw, dh, dw, pt, pl, 0, 0.f, up_target(1));
+                           sh, sw, dh, dw, pt, pl, 0, 0.f, up_target(bn_x ? 2 : 1));
     if (rc) return rc;
     if (!slab || !out) return -1;
+    if (bn_x && !(bn_mean && bn_invstd && bn_gamma && bn_c1 && bn_c2)) return -1;
+    a.bx = (const bf16_t*)bn_x; a.bmean = bn_mean; a.binvstd = bn_invstd; a.bgamma = bn_gamma; a.bc1 = bn_c1; a.bc2 = bn_c2;
+    a.bact = bn_act; a.balpha = bn_alpha;
     const int gy = sh * sw * a.bands, T = KH * KW;
-    size_t smem = (size_t)a.PH * a.PW * 4;
+    size_t smem = (size_t)((a.PH * a.PW + 3) & ~3) * 4 + (bn_x ? (size_t)3 * Np * 4 : 0);
     const size_t red = (size_t)4 * T * Np * 4;
     if (red > smem) smem = red;
     if (smem > 64 * 1024) return 1;
     const int gx = (B + a.ipb - 1) / a.ipb;
     const dim3 grid(gx, gy);
-    if (KH == 1) upconv_1ch_wgrad_kernel<1><<<grid, 256, smem, s>>>(a);
-    else if (KH == 2) upconv_1ch_wgrad_kernel<2><<<grid, 256, smem, s>>>(a);
-    else upconv_1ch_wgrad_kernel<3><<<grid, 256, smem, s>>>(a);
+    if (bn_x) {
+        if (KH == 1) upconv_1ch_wgrad_kernel<1, true><<<grid, 256, smem, s>>>(a);
+        else if (KH == 2) upconv_1ch_wgrad_kernel<2, true><<<grid, 256, smem, s>>>(a);
+        else upconv_1ch_wgrad_kernel<3, true><<<grid, 256, smem, s>>>(a);
+    } else {
+        if (KH == 1) upconv_1ch_wgrad_kernel<1, false><<<grid, 256, smem, s>>>(a);
+        else if (KH == 2) upconv_1ch_wgrad_kernel<2, false><<<grid, 256, smem, s>>>(a);
+        else upconv_1ch_wgrad_kernel<3, false><<<grid, 256, smem, s>>>(a);
+    }
     const int E = T * Np;
     upconv_1ch_wgrad_finish_kernel<<<(E + 31) / 32, 256, 0, s>>>(slab, out, E, Np, N, T, Cw, gx * gy);
     return 0;

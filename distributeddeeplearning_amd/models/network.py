@@ -36,6 +36,7 @@ BIAS_IN_WGRAD = os.environ.get("DDL_BIAS_IN_WGRAD", "1") == "1"   # one-channel 
 BN_ON_LOAD_PCONV = os.environ.get("DDL_BN_ON_LOAD_PCONV", "1") == "1"   # ... in front of a multi-channel transposed conv
 BN_ON_LOAD = os.environ.get("DDL_BN_ON_LOAD", "1") == "1"         # BN in front of a 1-channel ConvT applied on load
 FUSE_ACT_BWD = os.environ.get("DDL_FUSE_ACT_BWD", "1") == "1"   # act'(y) of the layer below in the dgrad epilogue
+BN_BWD_ON_LOAD = os.environ.get("DDL_BN_BWD_ON_LOAD", "1") == "1"   # first layer's wgrad applies the BatchNorm backward on load
 DW_BN_FUSE = os.environ.get("DDL_DW_BN_FUSE", "1") == "1"     # depthwise dgrad + backward of the BatchNorm in front of it
 BRANCH = os.environ.get("DDL_BRANCH", "1") == "1"    # weight-gradient branch on a side stream (captured steps)
 ALIGN = 8      # every tensor starts at a multiple of 8 elements (16 B in bf16, 32 B in fp32)
@@ -161,6 +162,7 @@ class ConvOp(Op):
         self.in_bn = None               # the BatchNorm whose apply this layer performs on load (BNOp.defer_to is us)
         self.in_affine = None           # set by BNOp.fwd for the next forward only
         self.x_affine = None            # what the last training forward used (for backward)
+        self.bn_deferred = None         # "up" path: the BatchNorm behind us left its backward apply step to our wgrad
 
     def _p(self, c):
         return _round_up(c, self.cpad)
@@ -413,16 +415,20 @@ class ConvOp(Op):
         x = self.x
         dx = None
         if self.onech == "up":
+            bnd, self.bn_deferred = self.bn_deferred, None
             if need_dw and not need_dx and self.x_affine is None:
                 done = [False]
 
                 def wg_up():
-                    done[0] = F.hip_backend().upconv_1ch_wgrad(x, dy, self.w_main, g, self.gkernel)
+                    done[0] = F.hip_backend().upconv_1ch_wgrad(x, dy, self.w_main, g, self.gkernel, bn=bnd)
                     if done[0]:
                         self._bias_grad(dy)
                 _BR.run(wg_up, dy)
                 if done[0]:
                     return None
+            if bnd is not None:         # (not reached with the shipped shapes) the generic kernels want the real dx
+                dy, _, _ = F.hip_backend().bn_bwd(dy, bnd["x"], None, bnd["mean"], bnd["invstd"], bnd["gamma"], None, 0.3,
+                                                  True, bnd["act"], bnd["alpha"])
         elif self.onech:
             return self._bwd_onech(dy, need_dx, need_dw, mul)
         if self.kind == "dense":
@@ -540,6 +546,8 @@ class BNOp(Op):
         self.fp32_handoff = False      # ... and does so in fp32 (depthwise tap sums): no bf16 rounding of our output
         self.pre_bwd = None            # (partials, blocks, sums) of our backward reduction, left by the kernel that made dy
         self.bwd_done = False          # the layer above already ran our backward (ConvOp._dw_bn_bwd): dy IS our dx
+        self.defer_apply_to = None     # first-layer ConvOp ("up") whose weight gradient applies our backward on load
+        self.below_needs_dx = False    # set per backward pass: somebody below that layer wants an input gradient
 
     def fwd(self, x, training):
         use_batch = training and self.mode == "batch"
@@ -608,6 +616,18 @@ class BNOp(Op):
             return dy
         conv = self.bias_grad_for
         pre, self.pre_bwd = self.pre_bwd, None
+        tgt = self.defer_apply_to
+        if (tgt is not None and BN_BWD_ON_LOAD and need_dw and not self.below_needs_dx and pre is None and dy.is_cuda
+                and self.used_batch_stats and self.groups_used == 1 and self.post_act in (None, "linear")):
+            # The layer below is the network's first (a Conv2DTranspose from the one-channel image): our dx has exactly
+            # one consumer, that layer's weight gradient, which forms it on load from (dy, x) -- the apply pass and the
+            # dx tensor (213 MB for model0 at batch 512) are not needed.  Reduction + finalize only here.
+            c1, c2 = F.hip_backend().bn_bwd_sums(dy, self.x, self.mean.reshape(-1), self.invstd.reshape(-1), self.gamma,
+                                                 self.prev_act, self.prev_alpha, self.ggamma, self.gbeta,
+                                                 conv.gbias if conv is not None else None)
+            tgt.bn_deferred = dict(x=self.x, mean=self.mean.reshape(-1), invstd=self.invstd.reshape(-1),
+                                   gamma=self.gamma, c1=c1, c2=c2, act=self.prev_act, alpha=self.prev_alpha)
+            return dy
         if pre is not None and pre[2] == (5 if (need_dw and conv is not None) else 2):
             dx, _, _ = F.hip_backend().bn_bwd(
                 dy, self.x, None, self.mean, self.invstd, self.gamma, None, 0.3, self.used_batch_stats, self.prev_act,
@@ -854,6 +874,10 @@ class Network:
             for op in self.ops:
                 if isinstance(op, ConvOp) and op.kind == "conv2d_transpose" and op.g.O == 1 and op.g.I != 1:
                     op.onech = "up"             # Conv2DTranspose 1 -> N: streaming kernels on the canonical weights
+                    # the network's first layer with a BatchNorm right behind it: that BatchNorm's backward apply step
+                    # moves into this layer's weight gradient (BNOp.bwd)
+                    if op is self.first_param_op() and op.next_bn is not None and op.next_bn.rank4:
+                        op.next_bn.defer_apply_to = op
                     continue
                 if not isinstance(op, ConvOp) or op.g.depthwise or op.g.I != 1:
                     continue
@@ -1055,6 +1079,8 @@ class Network:
         for op in self.ops:
             if isinstance(op, ConvOp):
                 op.dy_premul = False
+            elif isinstance(op, BNOp):
+                op.below_needs_dx = need_input_grad or not need_dw
         if dy_premultiplied and start > 0 and isinstance(self.ops[start - 1], ConvOp):
             self.ops[start - 1].dy_premul = True
         for i in range(start - 1, -1, -1):

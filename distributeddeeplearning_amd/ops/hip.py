@@ -83,7 +83,7 @@ _upconv_blocks = _sig("ddl_upconv_1ch_blocks", ci, ci, ci, ci, ci, ci, ci, ci, c
 _upconv = _sig("ddl_upconv_1ch", ci, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci,
                ci, ci, ci, cf, vp)
 _upconv_wgrad = _sig("ddl_upconv_1ch_wgrad", ci, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci,
-                     ci, ci, ci, vp)
+                     ci, ci, ci, vp, vp, vp, vp, vp, vp, ci, cf, vp)
 _gather = _sig("ddl_relayout_gather", None, vp, vp, vp, ci, cl, vp)
 _relayout_both = _sig("ddl_relayout_both", None, vp, vp, vp, ci, vp, vp, ci, cl, vp)
 _gemm_sk = _sig("ddl_gemm_sk", ci, vp, vp, vp, vp, cl, ci, ci, ci, ci, cf, vp, vp, ci, vp, ci, ci, vp)
@@ -721,13 +721,17 @@ def upconv_1ch(x, w, g: ConvGeom, bias=None, act=None, alpha=0.3, stats_out=None
     return y
 
 
-def upconv_1ch_wgrad(x, dy, w_like, g: ConvGeom, out):
+def upconv_1ch_wgrad(x, dy, w_like, g: ConvGeom, out, bn=None):
     """Weight gradient of `upconv_1ch`: out (fp32, canonical [N][KH][KW][Cw] like `w_like`) = sum over pixels of
     dY[b][h][w][n] * x[tap]; the padding channels of `out` are written as zeros.  Deterministic (per-block slabs summed
-    in a fixed order).  Returns False when the shape is outside the kernel's range (nothing launched)."""
+    in a fixed order).  `bn` = dict(x, mean, invstd, gamma, c1, c2, act, alpha): `dy` is the gradient at the OUTPUT of
+    the batch-statistics BatchNorm behind the layer and bn["x"] that BatchNorm's input (the layer's own output); the
+    BatchNorm's backward apply step -- act'(x) * (k0 dy + k1 x + k2) with the finalized coefficients c1, c2
+    (`bn_bwd_sums`) -- happens on load and the gradient at the BatchNorm's input is never written.
+    Returns False when the shape is outside the kernel's range (nothing launched)."""
     if not UPCONV:
         return False
-    shp = _upconv_shape(x, w_like, g, "upconv_1ch_wgrad", 1)
+    shp = _upconv_shape(x, w_like, g, "upconv_1ch_wgrad", 2 if bn is not None else 1)
     if shp is None:
         return False
     B, Cs, Cw, Np, nby = shp
@@ -737,13 +741,44 @@ def upconv_1ch_wgrad(x, dy, w_like, g: ConvGeom, out):
     _chk_f32(out, g.I * g.KH * g.KW * Cw, "out")
     if tuple(out.shape) != tuple(w_like.shape):
         raise ValueError(f"upconv_1ch_wgrad: out {tuple(out.shape)} != weights {tuple(w_like.shape)}")
+    bargs = (None, None, None, None, None, None, 0, 0.0)
+    if bn is not None:
+        _chk_act(bn["x"], "bn x")
+        if tuple(bn["x"].shape) != tuple(dy.shape):
+            raise ValueError(f"upconv_1ch_wgrad: bn x {tuple(bn['x'].shape)} vs dy {tuple(dy.shape)}")
+        for k_ in ("mean", "invstd", "gamma", "c1", "c2"):
+            _chk_f32(bn[k_], g.I, f"bn {k_}")
+        bargs = (bn["x"].data_ptr(), bn["mean"].data_ptr(), bn["invstd"].data_ptr(), bn["gamma"].data_ptr(),
+                 bn["c1"].data_ptr(), bn["c2"].data_ptr(), ACT_CODE[bn.get("act")], float(bn.get("alpha", 0.3)))
     slab = torch.empty(nby * g.KH * g.KW * Np, dtype=torch.float32, device=x.device)
     rc = _upconv_wgrad(x.data_ptr(), dy.data_ptr(), slab.data_ptr(), out.data_ptr(), B, g.OH, g.OW, Cs, Cw, g.H, g.W, Np,
-                       g.I, g.KH, g.KW, g.sh, g.sw, g.dh, g.dw, g.pt, g.pl, _stream())
+                       g.I, g.KH, g.KW, g.sh, g.sw, g.dh, g.dw, g.pt, g.pl, *bargs, _stream())
     if rc < 0:
         raise ValueError(f"upconv_1ch_wgrad rejected its arguments (rc={rc})")
     _done()
     return rc == 0
+
+
+def bn_bwd_sums(dy, x, mean, invstd, gamma, prev_act, prev_alpha, out_dgamma, out_dbeta, out_dbias=None):
+    """The reduction + finalize half of `bn_bwd` for a BatchNorm without an activation of its own (one statistics
+    group): dgamma, dbeta (and the bias gradient of the conv in front of it) are written, the coefficients (c1, c2) of
+    the apply step are returned for a consumer that applies them on load (`upconv_1ch_wgrad(bn=...)`)."""
+    _chk_act(dy, "dy")
+    _chk_act(x, "x")
+    if dy.shape != x.shape:
+        raise ValueError(f"bn_bwd_sums: dy {tuple(dy.shape)} vs x {tuple(x.shape)}")
+    rows, Cp = _group_rows(x, 1)
+    for t, n in ((mean, "mean"), (invstd, "invstd"), (gamma, "gamma"), (out_dgamma, "dgamma"), (out_dbeta, "dbeta")):
+        _chk_f32(t, Cp, n)
+    dev = x.device
+    part = _part(rows, Cp, dev, 5 if out_dbias is not None else 2, 1)
+    coef = torch.empty(2, Cp, dtype=torch.float32, device=dev)
+    _bn_bwd(dy.data_ptr(), x.data_ptr(), None, None, rows, Cp, mean.data_ptr(), invstd.data_ptr(), gamma.data_ptr(), 0,
+            0.3, 1, ACT_CODE[prev_act], prev_alpha, part.data_ptr(), out_dgamma.data_ptr(), out_dbeta.data_ptr(),
+            coef[0].data_ptr(), coef[1].data_ptr(), _p(out_dbias), 0 if out_dbias is None else out_dbias.numel(), 1, 0,
+            _stream())
+    _done()
+    return coef[0], coef[1]
 
 
 def pad_channels(x, c_phys, index=None, scale=1.0, c_true=None):

@@ -1272,3 +1272,32 @@ def test_depthwise_ring_forward_emits_batchnorm_statistics(hip, case):
     yf = y.float().reshape(-1, Cp).double().cpu()
     assert torch.allclose(sums[0], yf.sum(0), rtol=1e-4, atol=1e-2)
     assert torch.allclose(sums[1], (yf * yf).sum(0), rtol=1e-4, atol=1e-2)
+
+
+@pytest.mark.parametrize("act", ["softplus", "relu", "linear"])
+def test_upconv_wgrad_applies_the_batchnorm_backward_on_load(hip, act):
+    """`upconv_1ch_wgrad(bn=...)`: reduction + finalize (`bn_bwd_sums`), then the weight gradient forms the gradient at
+    the BatchNorm's input on load -- against bn_bwd (which writes that tensor) followed by the plain weight gradient."""
+    H, Fo, k, s, B = 28, 64, 3, 2, 9
+    g = G.conv2d_transpose_geom(H, H, 1, Fo, (k, k), (s, s), (1, 1), "valid")
+    torch.manual_seed(71)
+    x = dev(hip, r16(torch.rand(B, H, H, 1)))
+    w = padw(hip, r16(torch.randn(Fo, k, k, 1) / k))
+    y = hip.upconv_1ch(x, w, g, torch.randn(Fo).cuda(), act, 0.3)              # the BatchNorm's input
+    dy = dev(hip, r16(torch.randn(B, g.H, g.W, Fo)))
+    yf = y.float().reshape(-1, Fo)
+    mean, invstd = yf.mean(0).contiguous(), (1.0 / torch.sqrt(yf.var(0, unbiased=False) + 1e-3)).contiguous()
+    gamma = (torch.rand(Fo) + 0.5).cuda()
+    ref_g = [torch.zeros(Fo, device="cuda") for _ in range(3)]
+    dx, _, _ = hip.bn_bwd(dy, y, None, mean, invstd, gamma, None, 0.3, True, act, 0.3, *ref_g)
+    ref = torch.empty(tuple(w.shape), device="cuda")
+    assert hip.upconv_1ch_wgrad(x, dx, w, g, ref)
+    got_g = [torch.zeros(Fo, device="cuda") for _ in range(3)]
+    c1, c2 = hip.bn_bwd_sums(dy, y, mean, invstd, gamma, act, 0.3, *got_g)
+    got = torch.empty(tuple(w.shape), device="cuda")
+    assert hip.upconv_1ch_wgrad(x, dy, w, g, got, bn=dict(x=y, mean=mean, invstd=invstd, gamma=gamma, c1=c1, c2=c2,
+                                                          act=act, alpha=0.3))
+    for a, b in zip(got_g, ref_g):
+        assert torch.equal(a, b)
+    close(got[..., :1].cpu(), ref[..., :1].cpu(), rtol=1e-3, atol=1e-3 * float(ref.abs().max()))
+    assert float(got[..., 1:].abs().max()) == 0.0

@@ -78,6 +78,11 @@ def _run_local(c, g, x, dy_scale=1.0):
     units = _units(g)
     assert [len(u) for u in units] == [len(u) for u in _units(g)]
     N._BR.enabled = False
+    # units run on the ORACLE's tensors one at a time: a BatchNorm must not leave its backward apply step to the unit
+    # below it (network.BNOp.defer_apply_to; covered end to end by tests/test_hip_ops.py and tests/test_network_gpu.py)
+    for op in g.ops:
+        if isinstance(op, N.BNOp):
+            op.below_needs_dx = True
     # oracle forward, unit by unit
     xs, t = [], x
     for u in units:
