@@ -15,6 +15,10 @@
 // branches (a stride-2 3x3 layer has 2.25 live taps per pixel on average, not 9) and tap offsets into the plane are
 // scalars.  The forward pass also leaves the BatchNorm statistics' partial sums of its (bf16-rounded) output, one
 // column per block, laid out like pconv's STATS epilogue (part[2][Np][columns]).
+//
+// The same two kernels serve the FORWARD direction (`fwdconv`: a Conv2D from the one-channel image with a kernel of at
+// most 3 x 3 -- the first layer of four of the five shipped replicas): one "class" holding every output pixel, every
+// tap live, the plane indexed at (h * sh + kh * dh, w * sw + kw * dw) with the padding as its halo.
 #include "common.h"
 #include <cstdlib>
 
@@ -31,6 +35,7 @@ struct UpArgs {
     int bands, rpb;               // bands per class, class rows per band
     int ipb;                      // images per block (weight gradient: fewer, fatter slabs)
     int lps;                      // log2(Np / 8): lanes per pixel
+    int fwdconv;                  // 0: transposed convolution (stride classes); 1: forward convolution
     // weight gradient only (BNB instantiation): the layer is followed by a batch-statistics BatchNorm and `y` is the
     // gradient at that BatchNorm's OUTPUT; the gradient at its input -- dx = act'(bx) * (k0 g + k1 bx + k2), what
     // bn_bwd_apply would write -- is formed on load from g and the BatchNorm's input bx (= this layer's own output)
@@ -45,6 +50,7 @@ __device__ __forceinline__ int up_mod(int a, int m) { int r = a % m; return r < 
 // Block-uniform description of the class / band this block owns.
 struct UpBlock {
     int h_first, w_first, ncols, i0, i1, m_first, n_first;
+    int oh_step, ow_step, ih_step, iw_step;   // output pixel (h_first + oh_step * i, ..) reads plane row m_first + ih_step * i (+ halo)
     int toff[9];
     unsigned live;            // bit t: tap t contributes to this class
 };
@@ -52,6 +58,24 @@ struct UpBlock {
 template <int K>
 __device__ __forceinline__ UpBlock up_block(const UpArgs& a) {
     UpBlock u;
+    if (a.fwdconv) {
+        const int band = blockIdx.y;
+        u.h_first = u.w_first = 0;
+        u.ncols = a.W;
+        u.i0 = min(a.H, band * a.rpb);
+        u.i1 = min(a.H, u.i0 + a.rpb);
+        u.m_first = -a.halo_h;              // plane row of output row i, tap row 0: i * sh (the halo IS the padding)
+        u.n_first = -a.halo_w;
+        u.oh_step = u.ow_step = 1;
+        u.ih_step = a.sh;
+        u.iw_step = a.sw;
+        u.live = (1u << (K * K)) - 1u;
+#pragma unroll
+        for (int kh = 0; kh < K; ++kh)
+#pragma unroll
+            for (int kw = 0; kw < K; ++kw) u.toff[kh * K + kw] = kh * a.dh * a.PW + kw * a.dw;
+        return u;
+    }
     const int cls = blockIdx.y / a.bands, band = blockIdx.y - cls * a.bands;
     const int ph = cls / a.sw, pw = cls - ph * a.sw;
     u.h_first = up_mod(ph - a.pt, a.sh);
@@ -62,6 +86,9 @@ __device__ __forceinline__ UpBlock up_block(const UpArgs& a) {
     u.i1 = min(nrows, u.i0 + a.rpb);
     u.m_first = (u.h_first + a.pt - ph) / a.sh;
     u.n_first = (u.w_first + a.pl - pw) / a.sw;
+    u.oh_step = a.sh;
+    u.ow_step = a.sw;
+    u.ih_step = u.iw_step = 1;
     u.live = 0;
 #pragma unroll
     for (int kh = 0; kh < K; ++kh)
@@ -141,8 +168,8 @@ __global__ __launch_bounds__(256) void upconv_1ch_fwd_kernel(const UpArgs a) {
             const int q = idx >> a.lps;
             const int il = up_fdiv(q, invC), j = q - il * u.ncols;
             const int i = u.i0 + il;
-            const int h = u.h_first + a.sh * i, w = u.w_first + a.sw * j;
-            const int pb = (u.m_first + i + a.halo_h) * a.PW + u.n_first + j + a.halo_w;
+            const int h = u.h_first + u.oh_step * i, w = u.w_first + u.ow_step * j;
+            const int pb = (u.m_first + u.ih_step * i + a.halo_h) * a.PW + u.n_first + u.iw_step * j + a.halo_w;
             float acc[8];
 #pragma unroll
             for (int e = 0; e < 8; ++e) acc[e] = bv[e];
@@ -253,8 +280,8 @@ __global__ __launch_bounds__(256) void upconv_1ch_wgrad_kernel(const UpArgs a) {
             const int q = min(idx, total - 1) >> a.lps;
             const int il = up_fdiv(q, invC), j = q - il * u.ncols;
             const int i = u.i0 + il;
-            const int h = u.h_first + a.sh * i, w = u.w_first + a.sw * j;
-            pb[k] = (u.m_first + i + a.halo_h) * a.PW + u.n_first + j + a.halo_w;
+            const int h = u.h_first + u.oh_step * i, w = u.w_first + u.ow_step * j;
+            pb[k] = (u.m_first + u.ih_step * i + a.halo_h) * a.PW + u.n_first + u.iw_step * j + a.halo_w;
             v[k] = *(const uint4*)(yb + (unsigned)((h * a.W + w) * a.Np + cg * 8));
             if (BNB) vx[k] = *(const uint4*)(xbb + (unsigned)((h * a.W + w) * a.Np + cg * 8));
         }
@@ -355,7 +382,7 @@ static long up_env(const char* name, long dflt) {
 // weight gradient 512 / 1024 / 2048 blocks -> 63 / 53 / 68 us (1024 = one round at its register count, half the slabs).
 static int up_fill(UpArgs& a, const void* x, const void* w, const float* bias, void* y, float* part, int B, int IH,
                    int IW, int Cs, int Cw, int H, int W, int Np, int N, int KH, int KW, int sh, int sw, int dh, int dw,
-                   int pt, int pl, int act, float alpha, long target) {
+                   int pt, int pl, int act, float alpha, long target, int fwdconv) {
     if (B <= 0 || IH <= 0 || IW <= 0 || H <= 0 || W <= 0 || Cs <= 0 || Cw <= 0 || N <= 0 || N > Np || Np % 8) return -1;
     if (sh <= 0 || sw <= 0 || dh <= 0 || dw <= 0 || pt < 0 || pl < 0) return -1;
     if (KH != KW || KH < 1 || KH > 3) return 1;
@@ -366,23 +393,32 @@ static int up_fill(UpArgs& a, const void* x, const void* w, const float* bias, v
     a.stats_stride = 0; a.stats_off = 0;
     a.B = B; a.IH = IH; a.IW = IW; a.Cs = Cs; a.Cw = Cw; a.H = H; a.W = W; a.Np = Np; a.N = N; a.KH = KH; a.KW = KW;
     a.sh = sh; a.sw = sw; a.dh = dh; a.dw = dw; a.pt = pt; a.pl = pl; a.act = act; a.alpha = alpha;
-    a.halo_h = ((KH - 1) * dh + sh - 1) / sh;
-    a.halo_w = ((KW - 1) * dw + sw - 1) / sw;
-    const int top_h = (H - 1 + pt) / sh + 1, top_w = (W - 1 + pl) / sw + 1;
-    a.PH = a.halo_h + (IH > top_h ? IH : top_h);
-    a.PW = a.halo_w + (IW > top_w ? IW : top_w);
+    a.fwdconv = fwdconv;
+    if (fwdconv) {          // plane rows 0 .. (H-1) sh + (KH-1) dh, the image at row pt
+        a.halo_h = pt;
+        a.halo_w = pl;
+        const int ext_h = (H - 1) * sh + (KH - 1) * dh + 1, ext_w = (W - 1) * sw + (KW - 1) * dw + 1;
+        a.PH = pt + IH > ext_h ? pt + IH : ext_h;
+        a.PW = pl + IW > ext_w ? pl + IW : ext_w;
+    } else {
+        a.halo_h = ((KH - 1) * dh + sh - 1) / sh;
+        a.halo_w = ((KW - 1) * dw + sw - 1) / sw;
+        const int top_h = (H - 1 + pt) / sh + 1, top_w = (W - 1 + pl) / sw + 1;
+        a.PH = a.halo_h + (IH > top_h ? IH : top_h);
+        a.PW = a.halo_w + (IW > top_w ? IW : top_w);
+    }
     int lps = 0;
     while ((1 << lps) < LP) ++lps;
     a.lps = lps;
     // enough blocks to fill the chip: bands split a class's rows when batch x classes alone would not
-    const int classes = sh * sw, rows = (H + sh - 1) / sh;
+    const int classes = fwdconv ? 1 : sh * sw, rows = fwdconv ? H : (H + sh - 1) / sh;
     int bands = 1, ipb = 1;
     while ((long)B * classes * bands < target && bands * 2 <= rows) bands *= 2;
     if (bands == 1 && (long)B * classes > target) ipb = (int)(((long)B * classes + target - 1) / target);
     a.bands = bands;
     a.rpb = (rows + bands - 1) / bands;
     a.ipb = ipb;
-    if ((long)rows * ((W + sw - 1) / sw) * LP >= (1L << 21)) return 1;     // up_fdiv's exact range
+    if ((long)rows * (fwdconv ? W : (W + sw - 1) / sw) * LP >= (1L << 21)) return 1;     // up_fdiv's exact range
     return 0;
 }
 
@@ -393,24 +429,25 @@ static long up_target(int wgrad) {     // 0: forward, 1: weight gradient, 2: wei
 }
 
 // Statistics columns (forward, wgrad = 0) / slabs (weight gradient, wgrad = 1) of a launch.  0: outside the kernels' range.
-DDL_API int ddl_upconv_1ch_blocks(int wgrad, int B, int H, int W, int Np, int KH, int KW, int sh, int sw) {
+DDL_API int ddl_upconv_1ch_blocks(int wgrad, int B, int H, int W, int Np, int KH, int KW, int sh, int sw, int fwdconv) {
     UpArgs a;
     if (up_fill(a, nullptr, nullptr, nullptr, nullptr, nullptr, B, 1, 1, 8, 8, H, W, Np, Np, KH, KW, sh, sw, 1, 1, 0, 0, 0,
-                0.f, up_target(wgrad)))
+                0.f, up_target(wgrad), fwdconv))
         return 0;
-    return ((B + a.ipb - 1) / a.ipb) * sh * sw * a.bands;
+    return ((B + a.ipb - 1) / a.ipb) * (fwdconv ? 1 : sh * sw) * a.bands;
 }
 
 // Returns 0 on success, 1 if the shape is outside this kernel's range (nothing launched), < 0 on bad arguments.
 DDL_API int ddl_upconv_1ch(const void* x, const void* w, const float* bias, void* y, float* stats, int stats_stride,
                            int stats_off, int B, int IH, int IW, int Cs, int Cw, int H, int W, int Np, int N, int KH,
-                           int KW, int sh, int sw, int dh, int dw, int pt, int pl, int act, float alpha, hipStream_t s) {
+                           int KW, int sh, int sw, int dh, int dw, int pt, int pl, int act, float alpha, int fwdconv,
+                           hipStream_t s) {
     UpArgs a;
     const int rc = up_fill(a, x, w, bias, y, stats, B, IH, IW, Cs, Cw, H, W, Np, N, KH, KW, sh, sw, dh, dw, pt, pl, act,
-                           alpha, up_target(0));
+                           alpha, up_target(0), fwdconv);
     if (rc) return rc;
     a.ipb = 1;
-    const int gy = sh * sw * a.bands;
+    const int gy = (fwdconv ? 1 : sh * sw) * a.bands;
     a.stats_stride = stats_stride > 0 ? stats_stride : B * gy;
     a.stats_off = stats_stride > 0 ? stats_off : 0;
     if (stats && (a.stats_off < 0 || a.stats_off + B * gy > a.stats_stride)) return -1;
@@ -434,16 +471,16 @@ DDL_API int ddl_upconv_1ch_wgrad(const void* x, const void* dy, float* slab, flo
                                  int Cw, int H, int W, int Np, int N, int KH, int KW, int sh, int sw, int dh, int dw,
                                  int pt, int pl, const void* bn_x, const float* bn_mean, const float* bn_invstd,
                                  const float* bn_gamma, const float* bn_c1, const float* bn_c2, int bn_act,
-                                 float bn_alpha, hipStream_t s) {
+                                 float bn_alpha, int fwdconv, hipStream_t s) {
     UpArgs a;
     const int rc = up_fill(a, x, nullptr, nullptr, const_cast<void*>(dy), slab, B, IH, IW, Cs, Cw, H, W, Np, N, KH, KW,
-                           sh, sw, dh, dw, pt, pl, 0, 0.f, up_target(bn_x ? 2 : 1));
+                           sh, sw, dh, dw, pt, pl, 0, 0.f, up_target(bn_x ? 2 : 1), fwdconv);
     if (rc) return rc;
     if (!slab || !out) return -1;
     if (bn_x && !(bn_mean && bn_invstd && bn_gamma && bn_c1 && bn_c2)) return -1;
     a.bx = (const bf16_t*)bn_x; a.bmean = bn_mean; a.binvstd = bn_invstd; a.bgamma = bn_gamma; a.bc1 = bn_c1; a.bc2 = bn_c2;
     a.bact = bn_act; a.balpha = bn_alpha;
-    const int gy = sh * sw * a.bands, T = KH * KW;
+    const int gy = (fwdconv ? 1 : sh * sw) * a.bands, T = KH * KW;
     size_t smem = (size_t)((a.PH * a.PW + 3) & ~3) * 4 + (bn_x ? (size_t)3 * Np * 4 : 0);
     const size_t red = (size_t)4 * T * Np * 4;
     if (red > smem) smem = red;

@@ -36,6 +36,8 @@ BIAS_IN_WGRAD = os.environ.get("DDL_BIAS_IN_WGRAD", "1") == "1"   # one-channel 
 BN_ON_LOAD_PCONV = os.environ.get("DDL_BN_ON_LOAD_PCONV", "1") == "1"   # ... in front of a multi-channel transposed conv
 BN_ON_LOAD = os.environ.get("DDL_BN_ON_LOAD", "1") == "1"         # BN in front of a 1-channel ConvT applied on load
 FUSE_ACT_BWD = os.environ.get("DDL_FUSE_ACT_BWD", "1") == "1"   # act'(y) of the layer below in the dgrad epilogue
+STREAM1 = os.environ.get("DDL_STREAM1", "1") == "1"     # Conv2D 1 -> N with k <= 3: streaming kernels (csrc/hip/upconv_1ch.hip)
+STREAM1_MIN_ELEMS = int(os.environ.get("DDL_STREAM1_MIN_ELEMS", str(4 << 20)))
 BN_BWD_ON_LOAD = os.environ.get("DDL_BN_BWD_ON_LOAD", "1") == "1"   # first layer's wgrad applies the BatchNorm backward on load
 DW_BN_FUSE = os.environ.get("DDL_DW_BN_FUSE", "1") == "1"     # depthwise dgrad + backward of the BatchNorm in front of it
 BRANCH = os.environ.get("DDL_BRANCH", "1") == "1"    # weight-gradient branch on a side stream (captured steps)
@@ -163,6 +165,8 @@ class ConvOp(Op):
         self.in_affine = None           # set by BNOp.fwd for the next forward only
         self.x_affine = None            # what the last training forward used (for backward)
         self.bn_deferred = None         # "up" path: the BatchNorm behind us left its backward apply step to our wgrad
+        self.stream1 = False            # "in" path, kernel <= 3 x 3: the streaming kernels of the "up" path, forward direction
+        self.stream_used = False        # ... and the last training forward took them
 
     def _p(self, c):
         return _round_up(c, self.cpad)
@@ -351,25 +355,34 @@ class ConvOp(Op):
         /root/reference/DDL_Normal4.py:39-43): the streaming kernel of csrc/hip/upconv_1ch.hip, which also leaves the
         statistics partials of a batch-statistics BatchNorm behind it.  None: outside its range (generic path)."""
         bn = self.next_bn
+        self.stream_used = False
         if self.in_affine is not None or (not training and bn is not None):
             return None                 # (inference folds the BatchNorm into the generic kernels' epilogue)
+        # forward direction: from ~4 M output elements up (batch-32 ensemble members keep the taps kernels: at 0.8 M
+        # elements the streaming pair was 2 % slower per 32-step graph, at 12.8 M -- batch 512 -- it wins)
+        if self.onech == "in" and x.shape[0] * self.g.OH * self.g.OW * _round_up(self.g.O, 8) < STREAM1_MIN_ELEMS:
+            return None
         so = {"groups": bn.groups} if (training and bn is not None and bn.mode == "batch") else None
-        y = F.hip_backend().upconv_1ch(x, self.w_main, self.g, self.bias, self.act, self.alpha, stats_out=so)
+        y = F.hip_backend().upconv_1ch(x, self.w_main, self.g, self.bias, self.act, self.alpha, stats_out=so,
+                                       fwdconv=self.onech == "in")
         if y is None:
             return None
         if so and "part" in so and (bn.groups == 1 or x.shape[0] % (so["img"] * bn.groups) == 0):
             bn.pre_stats = (so["part"], so["nb"])
+        self.stream_used = True
         if training:
-            self.x, self.y, self.x_affine = x, y, None
+            self.x, self.y, self.x_affine, self.x_img = x, y, None, x
+            if self.onech == "in":
+                self.x = None           # (the "in" path's taps tensor: built by its weight gradient if that runs)
         return y
 
     def fwd(self, x, training):
         g = self.g
-        if self.onech == "up":
+        if self.onech == "up" or self.stream1:
             y = self._fwd_up(x, training)
             if y is not None:
                 return y
-        elif self.onech:
+        if self.onech and self.onech != "up":
             return self._fwd_onech(x, training)
         # a batch-statistics BN right behind this layer: let the conv kernel emit the statistics' partial sums
         bn = self.next_bn
@@ -414,13 +427,14 @@ class ConvOp(Op):
                 dy = F.act_bwd(dy, self.y, self.act, self.alpha)
         x = self.x
         dx = None
-        if self.onech == "up":
+        if self.onech == "up" or (self.stream1 and self.stream_used):
             bnd, self.bn_deferred = self.bn_deferred, None
             if need_dw and not need_dx and self.x_affine is None:
                 done = [False]
 
                 def wg_up():
-                    done[0] = F.hip_backend().upconv_1ch_wgrad(x, dy, self.w_main, g, self.gkernel, bn=bnd)
+                    done[0] = F.hip_backend().upconv_1ch_wgrad(self.x_img if self.onech == "in" else x, dy, self.w_main,
+                                                               g, self.gkernel, bn=bnd, fwdconv=self.onech == "in")
                     if done[0]:
                         self._bias_grad(dy)
                 _BR.run(wg_up, dy)
@@ -429,7 +443,7 @@ class ConvOp(Op):
             if bnd is not None:         # (not reached with the shipped shapes) the generic kernels want the real dx
                 dy, _, _ = F.hip_backend().bn_bwd(dy, bnd["x"], None, bnd["mean"], bnd["invstd"], bnd["gamma"], None, 0.3,
                                                   True, bnd["act"], bnd["alpha"])
-        elif self.onech:
+        if self.onech and self.onech != "up":
             return self._bwd_onech(dy, need_dx, need_dw, mul)
         if self.kind == "dense":
             B = x.shape[0]
@@ -617,7 +631,8 @@ class BNOp(Op):
         conv = self.bias_grad_for
         pre, self.pre_bwd = self.pre_bwd, None
         tgt = self.defer_apply_to
-        if (tgt is not None and BN_BWD_ON_LOAD and need_dw and not self.below_needs_dx and pre is None and dy.is_cuda
+        if (tgt is not None and tgt.stream_used and BN_BWD_ON_LOAD and need_dw and not self.below_needs_dx
+                and pre is None and dy.is_cuda
                 and self.used_batch_stats and self.groups_used == 1 and self.post_act in (None, "linear")):
             # The layer below is the network's first (a Conv2DTranspose from the one-channel image): our dx has exactly
             # one consumer, that layer's weight gradient, which forms it on load from (dy, x) -- the apply pass and the
@@ -889,6 +904,10 @@ class Network:
                 if op.kind == "conv2d":         # canonical [O][T][8]
                     Op = _round_up(g.O, 8)
                     op.onech = "in"
+                    # small kernels (the random_layer search space): the streaming kernels of the "up" path
+                    op.stream1 = STREAM1 and g.KH == g.KW <= 3
+                    if op.stream1 and op is self.first_param_op() and op.next_bn is not None and op.next_bn.rank4:
+                        op.next_bn.defer_apply_to = op
                     op.g1 = ConvGeom(g.OH, g.OW, T, g.OH, g.OW, g.O, 1, 1).check()
                     specs = [("w_tap", (g.O, 1, 1, Tp), (koff, g.O, T, g.O, Tp, T * 8, 8)),
                              ("w_tapT", (T, 1, 1, Op), (koff, T, g.O, T, Op, 8, T * 8))]

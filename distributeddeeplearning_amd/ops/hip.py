@@ -79,11 +79,11 @@ _tapfold = _sig("ddl_tapfold_1ch", ci, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, c
                 cf, vp, vp, ci, ci, ci, vp)
 _tapconv = _sig("ddl_tapconv_1ch", ci, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci,
                 cf, vp, vp, vp, vp, ci, ci, cf, vp)
-_upconv_blocks = _sig("ddl_upconv_1ch_blocks", ci, ci, ci, ci, ci, ci, ci, ci, ci, ci)
+_upconv_blocks = _sig("ddl_upconv_1ch_blocks", ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci)
 _upconv = _sig("ddl_upconv_1ch", ci, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci,
-               ci, ci, ci, cf, vp)
+               ci, ci, ci, cf, ci, vp)
 _upconv_wgrad = _sig("ddl_upconv_1ch_wgrad", ci, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci,
-                     ci, ci, ci, vp, vp, vp, vp, vp, vp, ci, cf, vp)
+                     ci, ci, ci, vp, vp, vp, vp, vp, vp, ci, cf, ci, vp)
 _gather = _sig("ddl_relayout_gather", None, vp, vp, vp, ci, cl, vp)
 _relayout_both = _sig("ddl_relayout_both", None, vp, vp, vp, ci, vp, vp, ci, cl, vp)
 _gemm_sk = _sig("ddl_gemm_sk", ci, vp, vp, vp, vp, cl, ci, ci, ci, ci, cf, vp, vp, ci, vp, ci, ci, vp)
@@ -673,44 +673,46 @@ UPCONV = os.environ.get("DDL_UPCONV", "1") == "1"
 DW_STATS = os.environ.get("DDL_DW_STATS", "1") == "1"       # BatchNorm statistics out of the depthwise ring forward
 
 
-def _upconv_shape(x, w, g: ConvGeom, name, wgrad=0):
-    """Operands of a transposed convolution from a one-channel image against its core geometry `g` (the forward conv
-    whose input gradient it is: g.O = 1 layer input channel, g.I layer output channels, g.OH x g.OW the layer's input,
-    g.H x g.W its output).  Returns (B, Cs, Cw, Np, blocks of the launch) or None when outside the kernels' range."""
+def _upconv_shape(x, w, g: ConvGeom, name, wgrad=0, fwdconv=False):
+    """Operands of a convolution from a one-channel image against its core geometry `g`.  Transposed (default): g is
+    the forward conv whose input gradient the layer is (g.O = 1 layer input channel, g.I layer output channels,
+    g.OH x g.OW the layer's input, g.H x g.W its output).  `fwdconv`: a Conv2D, g.I = 1, g.H x g.W -> g.OH x g.OW x g.O.
+    Returns (B, Cs, Cw, Np, blocks of the launch, (IH, IW, H, W, N)) or None when outside the kernels' range."""
     _chk_act(x, "x")
     B, Cs = x.shape[0], x.shape[-1]
-    if g.O != 1 or g.depthwise or tuple(x.shape[1:3]) != (g.OH, g.OW):
+    IH, IW, H, W, N = (g.H, g.W, g.OH, g.OW, g.O) if fwdconv else (g.OH, g.OW, g.H, g.W, g.I)
+    if (g.I if fwdconv else g.O) != 1 or g.depthwise or tuple(x.shape[1:3]) != (IH, IW):
         raise ValueError(f"{name}: x {tuple(x.shape)} vs geometry {g}")
     if not (w.is_cuda and w.dtype == torch.bfloat16 and w.is_contiguous()) or w.dim() != 4 \
-            or tuple(w.shape[:3]) != (g.I, g.KH, g.KW):
+            or tuple(w.shape[:3]) != (N, g.KH, g.KW):
         raise ValueError(f"{name}: weights must be contiguous bf16 [N][KH][KW][Cw], got {tuple(w.shape)} for {g}")
-    Np = pad8(g.I)
-    nby = _upconv_blocks(wgrad, B, g.H, g.W, Np, g.KH, g.KW, g.sh, g.sw)
-    if nby <= 0 or _batch_ranges(B, max(g.H * g.W * Np, g.OH * g.OW * Cs)) is not None:
+    Np = pad8(N)
+    nby = _upconv_blocks(wgrad, B, H, W, Np, g.KH, g.KW, g.sh, g.sw, int(fwdconv))
+    if nby <= 0 or _batch_ranges(B, max(H * W * Np, IH * IW * Cs)) is not None:
         return None
-    return B, Cs, w.shape[-1], Np, nby
+    return B, Cs, w.shape[-1], Np, nby, (IH, IW, H, W, N)
 
 
-def upconv_1ch(x, w, g: ConvGeom, bias=None, act=None, alpha=0.3, stats_out=None):
-    """Transposed convolution from a single-channel image (csrc/hip/upconv_1ch.hip): x [B][g.OH][g.OW][Cs] (channel 0
-    real), w canonical [N][KH][KW][Cw] bf16 (channel 0 real) -> [B][g.H][g.W][pad8(N)] = act(bias + taps).  A streaming
-    kernel: one 16-byte store per lane, only the taps live for the block's stride class are computed.
+def upconv_1ch(x, w, g: ConvGeom, bias=None, act=None, alpha=0.3, stats_out=None, fwdconv=False):
+    """Convolution from a single-channel image as a streaming kernel (csrc/hip/upconv_1ch.hip): transposed (default: x
+    [B][g.OH][g.OW][Cs] -> [B][g.H][g.W][pad8(N)]) or forward (`fwdconv`: x [B][g.H][g.W][Cs] -> [B][g.OH][g.OW][pad8(N)]),
+    w canonical [N][KH][KW][Cw] bf16 (channel 0 real), K <= 3.  One 16-byte store per lane, only live taps computed.
     `stats_out` (dict): receives the BatchNorm partials of the output ("part", "nb", "img") like the conv kernels'
     statistics epilogue.  Returns None when the shape is outside the kernel's range (nothing launched)."""
     if not UPCONV:
         return None
-    shp = _upconv_shape(x, w, g, "upconv_1ch")
+    shp = _upconv_shape(x, w, g, "upconv_1ch", 0, fwdconv)
     if shp is None:
         return None
-    B, Cs, Cw, Np, nby = shp
+    B, Cs, Cw, Np, nby, (IH, IW, H, W, N) = shp
     if bias is not None:
-        _chk_f32(bias, g.I, "bias")
-    y = torch.empty(B, g.H, g.W, Np, dtype=torch.bfloat16, device=x.device)
+        _chk_f32(bias, N, "bias")
+    y = torch.empty(B, H, W, Np, dtype=torch.bfloat16, device=x.device)
     part = None
     if stats_out is not None:
         part = torch.empty(2 * Np * nby, dtype=torch.float32, device=x.device)
-    rc = _upconv(x.data_ptr(), w.data_ptr(), _p(bias), y.data_ptr(), _p(part), 0, 0, B, g.OH, g.OW, Cs, Cw, g.H, g.W,
-                 Np, g.I, g.KH, g.KW, g.sh, g.sw, g.dh, g.dw, g.pt, g.pl, ACT_CODE[act], alpha, _stream())
+    rc = _upconv(x.data_ptr(), w.data_ptr(), _p(bias), y.data_ptr(), _p(part), 0, 0, B, IH, IW, Cs, Cw, H, W,
+                 Np, N, g.KH, g.KW, g.sh, g.sw, g.dh, g.dw, g.pt, g.pl, ACT_CODE[act], alpha, int(fwdconv), _stream())
     if rc < 0:
         raise ValueError(f"upconv_1ch rejected its arguments (rc={rc})")
     if rc > 0:
@@ -721,7 +723,7 @@ def upconv_1ch(x, w, g: ConvGeom, bias=None, act=None, alpha=0.3, stats_out=None
     return y
 
 
-def upconv_1ch_wgrad(x, dy, w_like, g: ConvGeom, out, bn=None):
+def upconv_1ch_wgrad(x, dy, w_like, g: ConvGeom, out, bn=None, fwdconv=False):
     """Weight gradient of `upconv_1ch`: out (fp32, canonical [N][KH][KW][Cw] like `w_like`) = sum over pixels of
     dY[b][h][w][n] * x[tap]; the padding channels of `out` are written as zeros.  Deterministic (per-block slabs summed
     in a fixed order).  `bn` = dict(x, mean, invstd, gamma, c1, c2, act, alpha): `dy` is the gradient at the OUTPUT of
@@ -731,14 +733,14 @@ def upconv_1ch_wgrad(x, dy, w_like, g: ConvGeom, out, bn=None):
     Returns False when the shape is outside the kernel's range (nothing launched)."""
     if not UPCONV:
         return False
-    shp = _upconv_shape(x, w_like, g, "upconv_1ch_wgrad", 2 if bn is not None else 1)
+    shp = _upconv_shape(x, w_like, g, "upconv_1ch_wgrad", 2 if bn is not None else 1, fwdconv)
     if shp is None:
         return False
-    B, Cs, Cw, Np, nby = shp
+    B, Cs, Cw, Np, nby, (IH, IW, H, W, N) = shp
     _chk_act(dy, "dy")
-    if tuple(dy.shape) != (B, g.H, g.W, Np):
-        raise ValueError(f"upconv_1ch_wgrad: dy {tuple(dy.shape)} != {(B, g.H, g.W, Np)}")
-    _chk_f32(out, g.I * g.KH * g.KW * Cw, "out")
+    if tuple(dy.shape) != (B, H, W, Np):
+        raise ValueError(f"upconv_1ch_wgrad: dy {tuple(dy.shape)} != {(B, H, W, Np)}")
+    _chk_f32(out, N * g.KH * g.KW * Cw, "out")
     if tuple(out.shape) != tuple(w_like.shape):
         raise ValueError(f"upconv_1ch_wgrad: out {tuple(out.shape)} != weights {tuple(w_like.shape)}")
     bargs = (None, None, None, None, None, None, 0, 0.0)
@@ -747,12 +749,12 @@ def upconv_1ch_wgrad(x, dy, w_like, g: ConvGeom, out, bn=None):
         if tuple(bn["x"].shape) != tuple(dy.shape):
             raise ValueError(f"upconv_1ch_wgrad: bn x {tuple(bn['x'].shape)} vs dy {tuple(dy.shape)}")
         for k_ in ("mean", "invstd", "gamma", "c1", "c2"):
-            _chk_f32(bn[k_], g.I, f"bn {k_}")
+            _chk_f32(bn[k_], N, f"bn {k_}")
         bargs = (bn["x"].data_ptr(), bn["mean"].data_ptr(), bn["invstd"].data_ptr(), bn["gamma"].data_ptr(),
                  bn["c1"].data_ptr(), bn["c2"].data_ptr(), ACT_CODE[bn.get("act")], float(bn.get("alpha", 0.3)))
     slab = torch.empty(nby * g.KH * g.KW * Np, dtype=torch.float32, device=x.device)
-    rc = _upconv_wgrad(x.data_ptr(), dy.data_ptr(), slab.data_ptr(), out.data_ptr(), B, g.OH, g.OW, Cs, Cw, g.H, g.W, Np,
-                       g.I, g.KH, g.KW, g.sh, g.sw, g.dh, g.dw, g.pt, g.pl, *bargs, _stream())
+    rc = _upconv_wgrad(x.data_ptr(), dy.data_ptr(), slab.data_ptr(), out.data_ptr(), B, IH, IW, Cs, Cw, H, W, Np,
+                       N, g.KH, g.KW, g.sh, g.sw, g.dh, g.dw, g.pt, g.pl, *bargs, int(fwdconv), _stream())
     if rc < 0:
         raise ValueError(f"upconv_1ch_wgrad rejected its arguments (rc={rc})")
     _done()

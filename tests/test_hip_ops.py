@@ -1301,3 +1301,35 @@ def test_upconv_wgrad_applies_the_batchnorm_backward_on_load(hip, act):
         assert torch.equal(a, b)
     close(got[..., :1].cpu(), ref[..., :1].cpu(), rtol=1e-3, atol=1e-3 * float(ref.abs().max()))
     assert float(got[..., 1:].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("case", [(28, 28, 128, 3, 1, 1, "valid", "softplus"), (28, 28, 32, 2, 1, 1, "valid", "softplus"),
+                                  (28, 28, 128, 2, 3, 1, "valid", "softsign"), (28, 28, 32, 1, 1, 2, "valid", "sigmoid"),
+                                  (28, 28, 16, 3, 1, 1, "same", "relu"), (13, 11, 64, 3, 2, 2, "same", "tanh")])
+@pytest.mark.parametrize("B", [2, 33])
+def test_stream1_forward_conv_from_one_channel(hip, case, B):
+    """The streaming one-channel kernels in the forward direction (Conv2D 1 -> N, k <= 3: the first layers of replicas
+    1-4): output, BatchNorm statistics partials and the deterministic weight gradient against the fp32 oracle."""
+    H, W, Fo, k, s, d, pad, act = case
+    g = G.conv2d_geom(H, W, 1, Fo, (k, k), (s, s), (d, d), pad)
+    torch.manual_seed(81)
+    x = r16(torch.randn(B, H, W, 1))
+    w = r16(torch.randn(Fo, k, k, 1) / k)
+    b = torch.randn(Fo)
+    y_ref = cpu_ref.conv_fprop(x, w, b, g, act)
+    so = {}
+    xd, wd = dev(hip, x), padw(hip, w)
+    y = hip.upconv_1ch(xd, wd, g, b.cuda(), act, 0.3, stats_out=so, fwdconv=True)
+    assert y is not None and tuple(y.shape) == (B, g.OH, g.OW, hip.pad8(Fo))
+    close(host(hip, y, Fo), y_ref)
+    Np, nb = hip.pad8(Fo), so["nb"]
+    sums = so["part"].view(2, Np, nb).double().sum(-1).cpu()
+    yf = y.float().reshape(-1, Np).double().cpu()
+    assert torch.allclose(sums[0], yf.sum(0), rtol=1e-4, atol=1e-2)
+    assert torch.allclose(sums[1], (yf * yf).sum(0), rtol=1e-4, atol=1e-2)
+    dout = r16(torch.randn(B, g.OH, g.OW, Fo))
+    dw_ref = cpu_ref.conv_wgrad(x, dout, g)
+    out = torch.full(tuple(wd.shape), float("nan"), device="cuda")
+    assert hip.upconv_1ch_wgrad(xd, dev(hip, dout), wd, g, out, fwdconv=True)
+    close(out[..., :1].cpu(), dw_ref, rtol=1e-2)
+    assert float(out[..., 1:].abs().max()) == 0.0
