@@ -42,6 +42,10 @@ struct UpArgs {
     // and never stored: the first layer is its only consumer.
     const bf16_t* bx; const float *bmean, *binvstd, *bgamma, *bc1, *bc2;
     int bact; float balpha;
+    // stream1_wgrad_kernel only: per-channel affine applied to the streamed operand on load (a BatchNorm folded into
+    // its consumer), and whether the block also sums its image plane (the scalar bias gradient of a C -> 1 layer)
+    const float *as, *ah;
+    int actrue, planesum;
 };
 
 __device__ __forceinline__ int up_fdiv(int x, float inv) { return __float2int_rz(((float)x + 0.5f) * inv); }
@@ -51,7 +55,7 @@ __device__ __forceinline__ int up_mod(int a, int m) { int r = a % m; return r < 
 struct UpBlock {
     int h_first, w_first, ncols, i0, i1, m_first, n_first;
     int oh_step, ow_step, ih_step, iw_step;   // output pixel (h_first + oh_step * i, ..) reads plane row m_first + ih_step * i (+ halo)
-    int toff[9];
+    int toff[25];
     unsigned live;            // bit t: tap t contributes to this class
 };
 
@@ -382,18 +386,20 @@ static long up_env(const char* name, long dflt) {
 // weight gradient 512 / 1024 / 2048 blocks -> 63 / 53 / 68 us (1024 = one round at its register count, half the slabs).
 static int up_fill(UpArgs& a, const void* x, const void* w, const float* bias, void* y, float* part, int B, int IH,
                    int IW, int Cs, int Cw, int H, int W, int Np, int N, int KH, int KW, int sh, int sw, int dh, int dw,
-                   int pt, int pl, int act, float alpha, long target, int fwdconv) {
+                   int pt, int pl, int act, float alpha, long target, int fwdconv, int ch = 8, int kmax = 3) {
     if (B <= 0 || IH <= 0 || IW <= 0 || H <= 0 || W <= 0 || Cs <= 0 || Cw <= 0 || N <= 0 || N > Np || Np % 8) return -1;
     if (sh <= 0 || sw <= 0 || dh <= 0 || dw <= 0 || pt < 0 || pl < 0) return -1;
-    if (KH != KW || KH < 1 || KH > 3) return 1;
-    const int LP = Np / 8;
-    if (LP > 16 || (LP & (LP - 1))) return 1;
+    if (KH != KW || KH < 1 || KH > kmax) return 1;
+    if (Np % ch) return 1;
+    const int LP = Np / ch;
+    if (LP > (ch == 8 ? 16 : 32) || (LP & (LP - 1))) return 1;
     if ((long)B * H * W * Np >= (1L << 31) || (long)B * IH * IW * Cs >= (1L << 31)) return 1;
     a.x = (const bf16_t*)x; a.w = (const bf16_t*)w; a.bias = bias; a.y = (bf16_t*)y; a.part = part;
     a.stats_stride = 0; a.stats_off = 0;
     a.B = B; a.IH = IH; a.IW = IW; a.Cs = Cs; a.Cw = Cw; a.H = H; a.W = W; a.Np = Np; a.N = N; a.KH = KH; a.KW = KW;
     a.sh = sh; a.sw = sw; a.dh = dh; a.dw = dw; a.pt = pt; a.pl = pl; a.act = act; a.alpha = alpha;
     a.fwdconv = fwdconv;
+    a.as = a.ah = nullptr; a.actrue = 0; a.planesum = 0;
     if (fwdconv) {          // plane rows 0 .. (H-1) sh + (KH-1) dh, the image at row pt
         a.halo_h = pt;
         a.halo_w = pl;
@@ -498,5 +504,335 @@ DDL_API int ddl_upconv_1ch_wgrad(const void* x, const void* dy, float* slab, flo
     }
     const int E = T * Np;
     upconv_1ch_wgrad_finish_kernel<<<(E + 31) / 32, 256, 0, s>>>(slab, out, E, Np, N, T, Cw, gx * gy);
+    return 0;
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Weight gradient of a LARGER kernel (k = 4, 5) between a one-channel image and an N-channel tensor:
+//
+//   dW[n][kh][kw] = sum_{b,oh,ow} t[b][oh][ow][n] * img[b][oh*sh + kh*dh - pt][ow*sw + kw*dw - pl]
+//
+// This is the weight gradient of BOTH ends of the DCGAN pair (/root/reference/DCGAN.py:22-66): the discriminator's
+// first Conv2D (img = the input image, t = dY) and the generator's last Conv2DTranspose (img = the gradient at its
+// one-channel output, t = the layer's input, optionally with the BatchNorm in front of it applied on load).  The
+// matrix-core path needed a taps tensor of the image (im2col), a split-K GEMM with 25 of 32 K columns live and a slab
+// reduce -- 29 + 44 us of kernel time in the 1.14 ms headline step for 12 MB operands.  Here the image sits in LDS, a
+// lane owns CH channels of one pixel of t and 25 x CH accumulators, and t is read exactly once: 31 + 18 us at first
+// (index arithmetic and per-tap address adds cost more than the multiply-adds), then tap offsets as immediates of
+// paired LDS reads, a division-free pixel walk and all of a block's images staged behind one barrier pair.  Both
+// layers run on the side stream, so the step time is unchanged either way (see s1_ch); what the kernel removes is the
+// taps tensor (12 .. 200 MB of scratch per step) and two launches.
+template <int CH> struct S1Vec;
+template <> struct S1Vec<2> { typedef unsigned type; };
+template <> struct S1Vec<4> { typedef unsigned type __attribute__((ext_vector_type(2))); };
+
+template <int CH>
+__device__ __forceinline__ void s1_unpack(const typename S1Vec<CH>::type& v, float* d) {
+    if constexpr (CH == 2) {
+        d[0] = __uint_as_float(v << 16);
+        d[1] = __uint_as_float(v & 0xffff0000u);
+    } else {
+#pragma unroll
+        for (int i = 0; i < CH / 2; ++i) {
+            const unsigned w = v[i];
+            d[2 * i] = __uint_as_float(w << 16);
+            d[2 * i + 1] = __uint_as_float(w & 0xffff0000u);
+        }
+    }
+}
+
+// zero-haloed fp32 planes of images b0 .. b0 + nimg - 1, `ps` floats apart: ONE barrier pair for all of them (a block
+// that stages image by image spends its time in the load latency, not in the 25 taps)
+__device__ __forceinline__ void s1_stage(const UpArgs& a, float* plane, int b0, int nimg, int ps) {
+    const int tid = threadIdx.x;
+    for (int i = tid; i < nimg * ps; i += 256) plane[i] = 0.f;
+    __syncthreads();
+    const bf16_t* src = a.x + (size_t)b0 * a.IH * a.IW * a.Cs;
+    const float invW = 1.0f / (float)a.IW, invI = 1.0f / (float)(a.IH * a.IW);
+    const int per = a.IH * a.IW, n = nimg * per;
+    for (int i0 = tid; i0 < n; i0 += 2048) {
+        bf16_t v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int i = min(i0 + k * 256, n - 1);
+            v[k] = src[(size_t)i * a.Cs];
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int i = i0 + k * 256;
+            if (i < n) {
+                const int im = up_fdiv(i, invI), p = i - im * per;
+                const int r = up_fdiv(p, invW), c = p - r * a.IW;
+                plane[im * ps + (r + a.halo_h) * a.PW + c + a.halo_w] = bf2f(v[k]);
+            }
+        }
+    }
+    __syncthreads();
+}
+
+// slab[block][(T + 1) * Np + 1]: rows 0 .. T-1 the taps, row T the column sums of t, the last element the plane sum
+// PWC: the plane's row pitch as a compile-time constant (0: a.PW, any dilation) -- tap offsets become the immediate
+// offsets of the LDS reads (paired into two-address reads) instead of one address add per tap.
+template <int K, int CH, int PWC>
+__global__ __launch_bounds__(256) void stream1_wgrad_kernel(const UpArgs a) {
+    constexpr int T = K * K, U = 4;
+    typedef typename S1Vec<CH>::type vec_t;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* plane = (float*)smem;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const UpBlock u = up_block<K>(a);
+    const int LP = 1 << a.lps;
+    const int cg = tid & (LP - 1);
+    const bool affine = a.as != nullptr;
+    float sc[CH], sf[CH];
+#pragma unroll
+    for (int e = 0; e < CH; ++e) {
+        const int c = cg * CH + e;
+        const bool real = affine && c < a.actrue;
+        sc[e] = real ? a.as[c] : 0.f;
+        sf[e] = real ? a.ah[c] : 0.f;
+    }
+
+    float acc[T][CH], accb[CH], psum = 0.f;
+#pragma unroll
+    for (int t = 0; t < T; ++t)
+#pragma unroll
+        for (int e = 0; e < CH; ++e) acc[t][e] = 0.f;
+#pragma unroll
+    for (int e = 0; e < CH; ++e) accb[e] = 0.f;
+    const int per = (u.i1 - u.i0) * u.ncols;                // pixels of one image's band
+    const float invC = 1.0f / (float)max(u.ncols, 1), invP = 1.0f / (float)max(per, 1);
+    const int ps = (a.PH * a.PW + 3) & ~3;
+    const int b0 = blockIdx.x * a.ipb, nimg = min(a.B, b0 + a.ipb) - b0;
+    {
+        s1_stage(a, plane, b0, nimg, ps);
+        if (a.planesum && blockIdx.y == 0)   // (the halos are zero: the planes' sum is the images')
+            for (int i = tid; i < nimg * ps; i += 256) psum += plane[i];
+        const bf16_t* yb = a.y + (size_t)b0 * a.H * a.W * a.Np;
+        const int total = (nimg * per) << a.lps;
+        // A lane walks pixels tid / LP, + D, + 2 D, ... (D = 256 / LP) of the block's images: (image, row, column) are
+        // carried along and advanced by (D / ncols, D % ncols) -- no division and no 32-bit multiply per pixel (the
+        // first version's index arithmetic cost as many cycles as its 25 multiply-adds).  s1_fill guarantees
+        // D / ncols + 1 <= rows, so one wrap per step suffices.
+        const int D = 256 >> a.lps, rows = u.i1 - u.i0;
+        const int dR = D / max(u.ncols, 1), dC = D - dR * u.ncols;
+        int wim, wil, wj;
+        {
+            const int q0 = tid >> a.lps;
+            wim = up_fdiv(q0, invP);
+            const int r = q0 - wim * per;
+            wil = up_fdiv(r, invC);
+            wj = r - wil * u.ncols;
+        }
+        const int pw = PWC ? PWC : a.PW;
+        const int pconst = (u.m_first + u.ih_step * u.i0 + a.halo_h) * pw + u.n_first + a.halo_w;
+        const int gconst = u.i0 * a.W * a.Np + cg * CH, gimg = a.H * a.W * a.Np, grow = a.W * a.Np;
+        const int prow = u.ih_step * pw;
+        // the loads of trip n+1 are in flight while trip n is multiplied (two or three waves per SIMD do not hide a
+        // global load behind each other)
+        vec_t vn[U];
+        int pbn[U];
+        bool okn[U];
+        auto issue = [&]() {
+#pragma unroll
+            for (int k = 0; k < U; ++k) {
+                const bool ok = wim < nimg;             // (past the end: plane offset 0 and element 0, multiplied by 0)
+                okn[k] = ok;
+                const int po = __mul24(wim, ps) + __mul24(wil, prow) + __mul24(wj, u.iw_step) + pconst;
+                const int go = __mul24(wim, gimg) + __mul24(wil, grow) + __mul24(wj, a.Np) + gconst;
+                pbn[k] = ok ? po : 0;
+                vn[k] = *(const vec_t*)(yb + (unsigned)(ok ? go : 0));
+                wj += dC;
+                wil += dR;
+                if (wj >= u.ncols) { wj -= u.ncols; ++wil; }
+                if (wil >= rows) { wil -= rows; ++wim; }
+            }
+        };
+        if (total > 0) issue();
+        for (int base = tid; base < total; base += 256 * U) {
+            vec_t v[U];
+            int pb[U];
+            bool okc[U];
+#pragma unroll
+            for (int k = 0; k < U; ++k) {
+                v[k] = vn[k];
+                pb[k] = pbn[k];
+                okc[k] = okn[k];
+            }
+            issue();
+#pragma unroll
+            for (int k = 0; k < U; ++k) {
+                const bool ok = okc[k];
+                float d[CH];
+                s1_unpack<CH>(v[k], d);
+#pragma unroll
+                for (int e = 0; e < CH; ++e) {
+                    if (affine) d[e] = bf2f(f2bf(fmaf(d[e], sc[e], sf[e])));     // the rounding of the tensor it replaces
+                    d[e] = ok ? d[e] : 0.f;
+                    accb[e] += d[e];
+                }
+#pragma unroll
+                for (int t = 0; t < T; ++t) {
+                    const float xv = plane[pb[k] + (PWC ? (t / K) * PWC + (t % K) : u.toff[t])];
+#pragma unroll
+                    for (int e = 0; e < CH; ++e) acc[t][e] = fmaf(xv, d[e], acc[t][e]);
+                }
+                if (!PWC) __builtin_amdgcn_sched_barrier(0);      // (run-time tap offsets: hoisted address adds cost a wave)
+            }
+        }
+    }
+    for (int o = LP; o < 64; o <<= 1) {
+#pragma unroll
+        for (int t = 0; t < T; ++t)
+#pragma unroll
+            for (int e = 0; e < CH; ++e) acc[t][e] += __shfl_xor(acc[t][e], o, 64);
+#pragma unroll
+        for (int e = 0; e < CH; ++e) accb[e] += __shfl_xor(accb[e], o, 64);
+    }
+    for (int o = 1; o < 64; o <<= 1) psum += __shfl_xor(psum, o, 64);
+    __syncthreads();                         // the plane is no longer read
+    float* red = (float*)smem;               // [4 waves][(T + 1) * Np] + [4]
+    const int E = (T + 1) * a.Np;
+    if (lane < LP) {
+#pragma unroll
+        for (int t = 0; t < T; ++t)
+#pragma unroll
+            for (int e = 0; e < CH; ++e) red[wave * E + t * a.Np + cg * CH + e] = acc[t][e];
+#pragma unroll
+        for (int e = 0; e < CH; ++e) red[wave * E + T * a.Np + cg * CH + e] = accb[e];
+    }
+    if (lane == 0) red[4 * E + wave] = psum;
+    __syncthreads();
+    float* dst = a.part + ((size_t)blockIdx.x * gridDim.y + blockIdx.y) * (E + 1);
+    for (int i = tid; i < E; i += 256) dst[i] = ((red[i] + red[E + i]) + red[2 * E + i]) + red[3 * E + i];
+    if (tid == 0) dst[E] = ((red[4 * E] + red[4 * E + 1]) + red[4 * E + 2]) + red[4 * E + 3];
+}
+
+// out[n * sn + t * st] = sum_k slab[k][t * Np + n] (+ zfill - 1 zeros behind it), the column sums / the plane sum into
+// `bias` (bias_mode 1: bias[n]; 2: bias[0]).  Fixed summation order: deterministic.
+__global__ __launch_bounds__(256) void stream1_wgrad_finish_kernel(const float* __restrict__ slab,
+                                                                   float* __restrict__ out, float* __restrict__ bias,
+                                                                   int E1, int Np, int N, int T, long sn, long st,
+                                                                   int zfill, int bias_mode, int nslab) {
+    __shared__ float red[32][9];
+    const int col = threadIdx.x & 7, kl = threadIdx.x >> 3;       // 8 columns, 32 lanes over the slabs
+    const int e = blockIdx.x * 8 + col;
+    float s = 0.f;
+    if (e < E1) {
+        int k = kl;
+        for (; k + 96 < nslab; k += 128) {
+            float v[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) v[q] = slab[(size_t)(k + 32 * q) * E1 + e];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) s += v[q];
+        }
+        for (; k < nslab; k += 32) s += slab[(size_t)k * E1 + e];
+    }
+    red[kl][col] = s;
+    __syncthreads();
+    if (kl == 0 && e < E1) {
+#pragma unroll
+        for (int q = 1; q < 32; ++q) s += red[q][col];
+        if (e < T * Np) {
+            const int t = e / Np, n = e - t * Np;
+            if (n < N) {
+                float* o = out + (size_t)n * sn + (size_t)t * st;
+                o[0] = s;
+                for (int c = 1; c < zfill; ++c) o[c] = 0.f;
+            }
+        } else if (e < (T + 1) * Np) {
+            const int n = e - T * Np;
+            if (bias_mode == 1 && n < N) bias[n] = s;
+        } else if (bias_mode == 2) {
+            bias[0] = s;
+        }
+    }
+}
+
+// Channels per lane.  Measured (DCGAN step, both layers on the side stream): 2 -> 1.154 ms, 4 -> 1.148 ms, the
+// matrix-core path with its taps tensor 1.146 .. 1.150 ms; the 64 x 64 pair 149.5 -> 148.0 .. 149.0 ms.
+static int s1_ch() {
+    static const int ch = (int)up_env("DDL_S1_CH", 4);
+    return ch == 2 ? 2 : 4;
+}
+
+static int s1_fill(UpArgs& a, const void* img, const void* t, float* slab, int B, int IH, int IW, int Cs, int H, int W,
+                   int Np, int N, int KH, int KW, int sh, int sw, int dh, int dw, int pt, int pl) {
+    // 512 = one round at two blocks per CU; a block stages ALL its images at once (LDS budget 48 KB)
+    static const long target = up_env("DDL_S1_WG_BLOCKS", 512);
+    if (KH < 4) return 1;                    // (k <= 3 is upconv_1ch_wgrad's)
+    const int rc = up_fill(a, img, nullptr, nullptr, const_cast<void*>(t), slab, B, IH, IW, Cs, 8, H, W, Np, N, KH, KW, sh,
+                           sw, dh, dw, pt, pl, 0, 0.f, target, 1, s1_ch(), 5);
+    if (rc) return rc;
+    if (dh == 1 && dw == 1) a.PW = a.PW <= 32 ? 32 : (a.PW <= 72 ? 72 : a.PW);     // the kernels' compile-time pitches
+    const long ps = ((long)a.PH * a.PW + 3) & ~3L;
+    long cap = (48 * 1024) / (ps * 4);
+    if (cap < 1) cap = 1;
+    if (a.ipb > cap) a.ipb = (int)cap;
+    // up_fdiv's exact range over (image, pixel) of a block, and 32-bit offsets into the block's slice of t
+    if ((long)a.ipb * a.rpb * W * (Np / s1_ch()) >= (1L << 21) || (long)a.ipb * IH * IW >= (1L << 21)) return 1;
+    if ((long)a.ipb * H * W * Np >= (1L << 31)) return 1;
+    // the kernel's pixel walk wraps at most one row and one image per step, and multiplies 24-bit operands
+    const int Dpix = 256 / (Np / s1_ch());
+    auto short_band = [&]() {
+        const int last_rows = H - (a.bands - 1) * a.rpb;
+        return last_rows < 1 || Dpix / W + 1 > (last_rows < a.rpb ? last_rows : a.rpb);
+    };
+    while (a.bands > 1 && short_band()) {        // fewer, taller bands
+        a.bands /= 2;
+        a.rpb = (H + a.bands - 1) / a.bands;
+    }
+    if (short_band()) return 1;
+    if ((long)H * W * Np >= (1L << 24) || ps * a.ipb >= (1L << 24)) return 1;
+    return 0;
+}
+
+// Slabs of a launch (each (KH*KW + 1) * Np + 1 floats); 0: outside the kernel's range.
+DDL_API int ddl_stream1_wgrad_blocks(int B, int IH, int IW, int Cs, int H, int W, int Np, int KH, int KW, int sh, int sw,
+                                     int dh, int dw, int pt, int pl) {
+    UpArgs a;
+    if (s1_fill(a, nullptr, nullptr, nullptr, B, IH, IW, Cs, H, W, Np, Np, KH, KW, sh, sw, dh, dw, pt, pl)) return 0;
+    return ((B + a.ipb - 1) / a.ipb) * a.bands;
+}
+
+// img [B][IH][IW][Cs] (channel 0), t [B][H][W][Np]; out[n * sn + t * st] (n < N) fp32.  Returns 0 on success, 1 when the
+// shape is outside the kernel's range (nothing launched), < 0 on bad arguments.
+DDL_API int ddl_stream1_wgrad(const void* img, const void* t, float* slab, float* out, float* bias, int B, int IH, int IW,
+                              int Cs, int H, int W, int Np, int N, int KH, int KW, int sh, int sw, int dh, int dw, int pt,
+                              int pl, long sn, long st, int zfill, int bias_mode, const float* aff_scale,
+                              const float* aff_shift, int aff_ctrue, hipStream_t s) {
+    UpArgs a;
+    const int rc = s1_fill(a, img, t, slab, B, IH, IW, Cs, H, W, Np, N, KH, KW, sh, sw, dh, dw, pt, pl);
+    if (rc) return rc;
+    if (!slab || !out || sn < 0 || st < 0 || zfill < 1 || bias_mode < 0 || bias_mode > 2) return -1;
+    if (bias_mode && !bias) return -1;
+    if ((aff_scale == nullptr) != (aff_shift == nullptr) || (aff_scale && (aff_ctrue < 0 || aff_ctrue > Np))) return -1;
+    // the image must cover what the taps read: rows 0 .. (H-1) sh + (KH-1) dh - pt may exceed IH only into the halo,
+    // which up_fill sized from both
+    a.as = aff_scale; a.ah = aff_shift; a.actrue = aff_ctrue; a.planesum = bias_mode == 2;
+    const int T = KH * KW, E = (T + 1) * Np;
+    size_t smem = (size_t)((a.PH * a.PW + 3) & ~3) * 4 * a.ipb;
+    const size_t red = (size_t)(4 * E + 4) * 4;
+    if (red > smem) smem = red;
+    if (smem > 64 * 1024) return 1;
+    const int gx = (B + a.ipb - 1) / a.ipb;
+    const dim3 grid(gx, a.bands);
+    const int ch = s1_ch();
+    const int pwc = (dh == 1 && dw == 1) ? a.PW : 0;           // s1_fill rounded PW up to 32 / 72 where it could
+#define S1_LAUNCH(K_, CH_, P_) stream1_wgrad_kernel<K_, CH_, P_><<<grid, 256, smem, s>>>(a)
+#define S1_PICK(K_, CH_) (pwc == 32 ? S1_LAUNCH(K_, CH_, 32) : pwc == 72 ? S1_LAUNCH(K_, CH_, 72) : S1_LAUNCH(K_, CH_, 0))
+    if (KH == 4) {
+        if (ch == 4) S1_PICK(4, 4);
+        else S1_PICK(4, 2);
+    } else {
+        if (ch == 4) S1_PICK(5, 4);
+        else S1_PICK(5, 2);
+    }
+#undef S1_PICK
+#undef S1_LAUNCH
+    stream1_wgrad_finish_kernel<<<(E + 1 + 7) / 8, 256, 0, s>>>(slab, out, bias, E + 1, Np, N, T, sn, st, zfill,
+                                                                  bias_mode, gx * a.bands);
     return 0;
 }

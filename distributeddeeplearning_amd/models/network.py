@@ -135,6 +135,9 @@ class Op:
         pass
 
 
+_NO = object()        # sentinel: "an affine exists but cannot be applied on load"
+
+
 class ConvOp(Op):
     """Conv2D / Conv2DTranspose / DepthwiseConv2D / Dense with fused bias + activation."""
     has_params = True
@@ -223,6 +226,14 @@ class ConvOp(Op):
         self._gbias_is_zero = False
         F.bias_grad(dy, out=self.gbias)
 
+    def _bias_plain(self):
+        """True when the bias gradient is a plain sum of dY (not zero by construction in front of a batch-statistics
+        BatchNorm, not written by that BatchNorm's backward): a weight-gradient kernel may produce it."""
+        bn = self.next_bn
+        if self.gbias is None or self.gbias.dtype != torch.float32 or not self.gbias.is_contiguous():
+            return False
+        return not (bn is not None and ((bn.used_batch_stats and self.act in (None, "linear")) or bn.bias_grad_for is self))
+
     def _bias_tail(self, T, nbias=None):
         """(offset, flat view over [kernel gradient | alignment gap | bias gradient]) when this layer's bias gradient
         is a plain column sum of dY and can be produced by the weight-gradient launch itself, else None."""
@@ -288,6 +299,16 @@ class ConvOp(Op):
         if self.onech == "in":
             if need_dw:                 # dW[n][t] -> canonical [O][KH][KW][8] slot (n, t, channel 0)
                 def wg():
+                    # 4x4 / 5x5: the streaming kernel reads dY once against the image in LDS (bias gradient included)
+                    if self.x is None and self.x_img is not None and self.gkernel.dtype == torch.float32:
+                        plain = self._bias_plain()
+                        if hip.stream1_wgrad(self.x_img, dy, g, self.gkernel.reshape(-1), T * 8, 8, zfill=8, n_out=g.O,
+                                             bias=self.gbias if plain else None, bias_mode=1 if plain else 0):
+                            if plain:
+                                self._gbias_is_zero = False
+                            else:
+                                self._bias_grad(dy)
+                            return
                     # The bias gradient (column sums of dY) rides in the same MFMAs: the taps tensor gets a column of
                     # ones in its first padding tap and the kernel routes that column of dW to the bias slot, which
                     # sits behind the kernel's in the flat gradient buffer (one launch covers both).
@@ -325,15 +346,27 @@ class ConvOp(Op):
                     dyc[0] = hip.im2col_1ch(dy, g)
                     dx = hip.conv_dgrad(dyc[0], self.w_tapT, g1, mul=mul)
             if need_dw:
-                x, xa = self.x, None
+                x, xa, xa_any = self.x, None, None
                 if self.x_affine is not None:
                     sc, sh, groups, ctrue = self.x_affine
                     if groups == 1:
-                        xa = (sc.reshape(-1), sh.reshape(-1), ctrue)
+                        xa = xa_any = (sc.reshape(-1), sh.reshape(-1), ctrue)
                     else:               # several statistics groups in one backward: materialise
                         x = hip.bn_apply(x, sc, sh, None, 0.3, ctrue, groups)
+                        xa_any = _NO
 
                 def wg():
+                    if dyc[0] is None and xa_any is not _NO and self.gkernel.dtype == torch.float32:
+                        # 4x4 / 5x5: streaming kernel, the dY image in LDS, x read once with its BatchNorm on load
+                        plain = self._bias_plain()
+                        Ip = self.x.shape[-1]
+                        if hip.stream1_wgrad(dy, self.x, g, self.gkernel.reshape(-1), 1, Ip, affine=xa_any,
+                                             bias=self.gbias if plain else None, bias_mode=2 if plain else 0):
+                            if plain:
+                                self._gbias_is_zero = False
+                            else:
+                                self._bias_grad(dy)
+                            return
                     d = dyc[0] if dyc[0] is not None else hip.im2col_1ch(dy, g)
                     # the scalar bias gradient sum(dY) = the pixel sum of d's centre tap: one more MFMA in this launch
                     ctr = self._centre_tap()

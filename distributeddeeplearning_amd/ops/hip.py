@@ -84,6 +84,9 @@ _upconv = _sig("ddl_upconv_1ch", ci, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci,
                ci, ci, ci, cf, ci, vp)
 _upconv_wgrad = _sig("ddl_upconv_1ch_wgrad", ci, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci,
                      ci, ci, ci, vp, vp, vp, vp, vp, vp, ci, cf, ci, vp)
+_s1_blocks = _sig("ddl_stream1_wgrad_blocks", ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci)
+_s1_wgrad = _sig("ddl_stream1_wgrad", ci, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci,
+                 ci, cl, cl, ci, ci, vp, vp, ci, vp)
 _gather = _sig("ddl_relayout_gather", None, vp, vp, vp, ci, cl, vp)
 _relayout_both = _sig("ddl_relayout_both", None, vp, vp, vp, ci, vp, vp, ci, cl, vp)
 _gemm_sk = _sig("ddl_gemm_sk", ci, vp, vp, vp, vp, cl, ci, ci, ci, ci, cf, vp, vp, ci, vp, ci, ci, vp)
@@ -757,6 +760,57 @@ def upconv_1ch_wgrad(x, dy, w_like, g: ConvGeom, out, bn=None, fwdconv=False):
                        N, g.KH, g.KW, g.sh, g.sw, g.dh, g.dw, g.pt, g.pl, *bargs, int(fwdconv), _stream())
     if rc < 0:
         raise ValueError(f"upconv_1ch_wgrad rejected its arguments (rc={rc})")
+    _done()
+    return rc == 0
+
+
+S1_WGRAD = os.environ.get("DDL_S1_WGRAD", "1") == "1"
+
+
+def stream1_wgrad(img, t, g: ConvGeom, out, sn, st, zfill=1, n_out=None, bias=None, bias_mode=0, affine=None):
+    """Weight gradient of a 4x4 / 5x5 convolution between a one-channel image and an N-channel tensor, as a streaming
+    kernel (csrc/hip/upconv_1ch.hip, stream1_wgrad_kernel; no taps tensor, no split-K GEMM):
+
+        out[n * sn + tap * st] = sum_{b,oh,ow} t[b][oh][ow][n] * img[b][oh*sh + kh*dh - pt][ow*sw + kw*dw - pl]   (n < n_out)
+
+    with `zfill - 1` zeros written behind each element (the padding channels of a canonical [O][KH][KW][8] gradient).
+    `g` is the forward core geometry image (g.H x g.W, 1 channel) -> tensor (g.OH x g.OW): the first Conv2D of the DCGAN
+    discriminator (img = x, t = dY) and the last Conv2DTranspose of its generator (img = dY, t = x;
+    /root/reference/DCGAN.py:22-66).  `affine` = (scale, shift, c_true): t is a BatchNorm's INPUT and the normalisation
+    is applied on load (rounded to bf16 like the tensor it replaces).  bias_mode 1: bias[n] = column sums of t (a Conv2D's
+    bias gradient); 2: bias[0] = sum of img's channel 0 (the C -> 1 layer's scalar bias gradient).  Deterministic.
+    Returns False when the shape is outside the kernel's range (nothing launched)."""
+    if not S1_WGRAD or g.depthwise or g.KH != g.KW or g.KH not in (4, 5):
+        return False
+    _chk_act(img, "img")
+    _chk_act(t, "t")
+    B, Cs, Np = img.shape[0], img.shape[-1], t.shape[-1]
+    if img.dim() != 4 or t.dim() != 4 or tuple(img.shape[1:3]) != (g.H, g.W) or tuple(t.shape[:3]) != (B, g.OH, g.OW):
+        raise ValueError(f"stream1_wgrad: img {tuple(img.shape)} / t {tuple(t.shape)} vs geometry {g}")
+    N = Np if n_out is None else int(n_out)
+    if not 0 < N <= Np:
+        raise ValueError(f"stream1_wgrad: n_out {N} vs {Np} channels")
+    nby = _s1_blocks(B, g.H, g.W, Cs, g.OH, g.OW, Np, g.KH, g.KW, g.sh, g.sw, g.dh, g.dw, g.pt, g.pl)
+    if nby <= 0 or _batch_ranges(B, max(g.OH * g.OW * Np, g.H * g.W * Cs)) is not None:
+        return False
+    T = g.KH * g.KW
+    _chk_f32(out, (N - 1) * sn + (T - 1) * st + zfill, "out")
+    if sn < 0 or st < 0 or zfill < 1 or bias_mode not in (0, 1, 2):
+        raise ValueError("stream1_wgrad: bad output layout")
+    if bias_mode:
+        _chk_f32(bias, N if bias_mode == 1 else 1, "bias")
+    asc = ash = None
+    actrue = 0
+    if affine is not None:
+        asc, ash, actrue = affine
+        _chk_f32(asc, Np, "affine scale")
+        _chk_f32(ash, Np, "affine shift")
+    slab = torch.empty(nby * ((T + 1) * Np + 1), dtype=torch.float32, device=img.device)
+    rc = _s1_wgrad(img.data_ptr(), t.data_ptr(), slab.data_ptr(), out.data_ptr(), _p(bias) if bias_mode else None, B,
+                   g.H, g.W, Cs, g.OH, g.OW, Np, N, g.KH, g.KW, g.sh, g.sw, g.dh, g.dw, g.pt, g.pl, int(sn), int(st),
+                   int(zfill), int(bias_mode), _p(asc), _p(ash), int(actrue), _stream())
+    if rc < 0:
+        raise ValueError(f"stream1_wgrad rejected its arguments (rc={rc})")
     _done()
     return rc == 0
 

@@ -1333,3 +1333,42 @@ def test_stream1_forward_conv_from_one_channel(hip, case, B):
     assert hip.upconv_1ch_wgrad(xd, dev(hip, dout), wd, g, out, fwdconv=True)
     close(out[..., :1].cpu(), dw_ref, rtol=1e-2)
     assert float(out[..., 1:].abs().max()) == 0.0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", [(28, 28, 32, 5, 2, "same"), (28, 28, 64, 4, 1, "valid"), (17, 13, 16, 5, 1, "same"),
+                                  (64, 64, 32, 5, 2, "same")])
+@pytest.mark.parametrize("B", [3, 130])
+def test_stream1_wgrad_of_a_5x5_layer_at_a_one_channel_image(hip, case, B):
+    """The streaming weight gradient of the DCGAN pair's one-channel ends (k = 4, 5): as the discriminator's first
+    Conv2D (canonical [O][KH][KW][8] layout, bias = column sums of dY) and as the generator's last Conv2DTranspose
+    ([KH][KW][Cp] layout, BatchNorm applied to x on load, scalar bias = sum of the dY image), against the fp32 oracle."""
+    H, W, Fo, k, s, pad = case
+    g = G.conv2d_geom(H, W, 1, Fo, (k, k), (s, s), (1, 1), pad)
+    torch.manual_seed(83)
+    T, Np = k * k, hip.pad8(Fo)
+    img = r16(torch.randn(B, H, W, 1))
+    t = r16(torch.randn(B, g.OH, g.OW, Fo))
+    ref = cpu_ref.conv_wgrad(img, t, g)                     # [Fo][k][k][1]
+    imgd, td = dev(hip, img), dev(hip, t)
+    out = torch.full((Fo, k, k, 8), float("nan"), device="cuda")
+    bias = torch.full((Fo,), float("nan"), device="cuda")
+    assert hip.stream1_wgrad(imgd, td, g, out.view(-1), T * 8, 8, zfill=8, n_out=Fo, bias=bias, bias_mode=1)
+    close(out[..., :1].cpu(), ref, rtol=1e-2)
+    assert float(out[..., 1:].abs().max()) == 0.0
+    assert torch.allclose(bias.cpu(), t.reshape(-1, Fo).sum(0), rtol=1e-3, atol=1e-2)
+    out2 = torch.empty_like(out)
+    assert hip.stream1_wgrad(imgd, td, g, out2.view(-1), T * 8, 8, zfill=8, n_out=Fo)
+    assert torch.equal(out, out2)                           # deterministic, and the bias output is optional
+    # transposed-layer form: t is the layer's input in front of a BatchNorm folded into the load
+    ctrue = Fo - 3
+    sc, sh = torch.rand(Np) + 0.5, torch.randn(Np) * 0.3
+    tn = r16(t * sc[:Fo] + sh[:Fo])
+    tn[..., ctrue:] = 0
+    ref2 = cpu_ref.conv_wgrad(img, tn, g)[..., 0].reshape(Fo, T).t()       # [T][Fo]
+    out3 = torch.full((T, Np), float("nan"), device="cuda")
+    b1 = torch.full((1,), float("nan"), device="cuda")
+    assert hip.stream1_wgrad(imgd, td, g, out3.view(-1), 1, Np, affine=(sc.cuda(), sh.cuda(), ctrue), bias=b1, bias_mode=2)
+    close(out3[:, :Fo].cpu(), ref2, rtol=1e-2)
+    assert float(out3[:, ctrue:].abs().max()) == 0.0
+    assert torch.allclose(b1.cpu(), img.sum().reshape(1), rtol=1e-3, atol=1e-2)
