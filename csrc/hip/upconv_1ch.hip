@@ -604,8 +604,12 @@ __global__ __launch_bounds__(256) void stream1_wgrad_kernel(const UpArgs a) {
     const int per = (u.i1 - u.i0) * u.ncols;                // pixels of one image's band
     const float invC = 1.0f / (float)max(u.ncols, 1), invP = 1.0f / (float)max(per, 1);
     const int ps = (a.PH * a.PW + 3) & ~3;
-    const int b0 = blockIdx.x * a.ipb, nimg = min(a.B, b0 + a.ipb) - b0;
-    {
+    // a block takes image groups blockIdx.x, + gridDim.x, ...: the slab count stays at one round of blocks however
+    // large the batch (64 x 64 images at B = 32768: two images fit the LDS budget, 16384 groups)
+    const int ngrp = (a.B + a.ipb - 1) / a.ipb;
+    for (int grp = blockIdx.x; grp < ngrp; grp += gridDim.x) {
+        const int b0 = grp * a.ipb, nimg = min(a.B, b0 + a.ipb) - b0;
+        __syncthreads();                     // every lane is done with the previous group's planes
         s1_stage(a, plane, b0, nimg, ps);
         if (a.planesum && blockIdx.y == 0)   // (the halos are zero: the planes' sum is the images')
             for (int i = tid; i < nimg * ps; i += 256) psum += plane[i];
@@ -790,11 +794,17 @@ static int s1_fill(UpArgs& a, const void* img, const void* t, float* slab, int B
 }
 
 // Slabs of a launch (each (KH*KW + 1) * Np + 1 floats); 0: outside the kernel's range.
+static int s1_gx(const UpArgs& a, int B) {
+    static const long cap = up_env("DDL_S1_WG_MAXBLOCKS", 512);
+    const long ngrp = (B + a.ipb - 1) / a.ipb;
+    return (int)(ngrp < cap ? ngrp : cap);
+}
+
 DDL_API int ddl_stream1_wgrad_blocks(int B, int IH, int IW, int Cs, int H, int W, int Np, int KH, int KW, int sh, int sw,
                                      int dh, int dw, int pt, int pl) {
     UpArgs a;
     if (s1_fill(a, nullptr, nullptr, nullptr, B, IH, IW, Cs, H, W, Np, Np, KH, KW, sh, sw, dh, dw, pt, pl)) return 0;
-    return ((B + a.ipb - 1) / a.ipb) * a.bands;
+    return s1_gx(a, B) * a.bands;
 }
 
 // img [B][IH][IW][Cs] (channel 0), t [B][H][W][Np]; out[n * sn + t * st] (n < N) fp32.  Returns 0 on success, 1 when the
@@ -802,11 +812,12 @@ DDL_API int ddl_stream1_wgrad_blocks(int B, int IH, int IW, int Cs, int H, int W
 DDL_API int ddl_stream1_wgrad(const void* img, const void* t, float* slab, float* out, float* bias, int B, int IH, int IW,
                               int Cs, int H, int W, int Np, int N, int KH, int KW, int sh, int sw, int dh, int dw, int pt,
                               int pl, long sn, long st, int zfill, int bias_mode, const float* aff_scale,
-                              const float* aff_shift, int aff_ctrue, hipStream_t s) {
+                              const float* aff_shift, int aff_ctrue, int slab_first, int finish_slabs, hipStream_t s) {
     UpArgs a;
     const int rc = s1_fill(a, img, t, slab, B, IH, IW, Cs, H, W, Np, N, KH, KW, sh, sw, dh, dw, pt, pl);
     if (rc) return rc;
     if (!slab || !out || sn < 0 || st < 0 || zfill < 1 || bias_mode < 0 || bias_mode > 2) return -1;
+    if (slab_first < 0 || finish_slabs < 0) return -1;
     if (bias_mode && !bias) return -1;
     if ((aff_scale == nullptr) != (aff_shift == nullptr) || (aff_scale && (aff_ctrue < 0 || aff_ctrue > Np))) return -1;
     // the image must cover what the taps read: rows 0 .. (H-1) sh + (KH-1) dh - pt may exceed IH only into the halo,
@@ -817,7 +828,10 @@ DDL_API int ddl_stream1_wgrad(const void* img, const void* t, float* slab, float
     const size_t red = (size_t)(4 * E + 4) * 4;
     if (red > smem) smem = red;
     if (smem > 64 * 1024) return 1;
-    const int gx = (B + a.ipb - 1) / a.ipb;
+    // batch slices of one reduction (tensors of 2^31 elements and more): every slice writes its slabs behind the
+    // previous one's (`slab_first`), the last call sums all of them (`finish_slabs`, 0 = not yet)
+    const int gx = s1_gx(a, B);
+    a.part = slab + (size_t)slab_first * (E + 1);
     const dim3 grid(gx, a.bands);
     const int ch = s1_ch();
     const int pwc = (dh == 1 && dw == 1) ? a.PW : 0;           // s1_fill rounded PW up to 32 / 72 where it could
@@ -832,7 +846,10 @@ DDL_API int ddl_stream1_wgrad(const void* img, const void* t, float* slab, float
     }
 #undef S1_PICK
 #undef S1_LAUNCH
-    stream1_wgrad_finish_kernel<<<(E + 1 + 7) / 8, 256, 0, s>>>(slab, out, bias, E + 1, Np, N, T, sn, st, zfill,
-                                                                  bias_mode, gx * a.bands);
+    if (finish_slabs > 0) {
+        if (finish_slabs < slab_first + gx * a.bands) return -1;
+        stream1_wgrad_finish_kernel<<<(E + 1 + 7) / 8, 256, 0, s>>>(slab, out, bias, E + 1, Np, N, T, sn, st, zfill,
+                                                                      bias_mode, finish_slabs);
+    }
     return 0;
 }

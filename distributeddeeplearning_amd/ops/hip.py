@@ -86,7 +86,7 @@ _upconv_wgrad = _sig("ddl_upconv_1ch_wgrad", ci, vp, vp, vp, vp, ci, ci, ci, ci,
                      ci, ci, ci, vp, vp, vp, vp, vp, vp, ci, cf, ci, vp)
 _s1_blocks = _sig("ddl_stream1_wgrad_blocks", ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci)
 _s1_wgrad = _sig("ddl_stream1_wgrad", ci, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci,
-                 ci, cl, cl, ci, ci, vp, vp, ci, vp)
+                 ci, cl, cl, ci, ci, vp, vp, ci, ci, ci, vp)
 _gather = _sig("ddl_relayout_gather", None, vp, vp, vp, ci, cl, vp)
 _relayout_both = _sig("ddl_relayout_both", None, vp, vp, vp, ci, vp, vp, ci, cl, vp)
 _gemm_sk = _sig("ddl_gemm_sk", ci, vp, vp, vp, vp, cl, ci, ci, ci, ci, cf, vp, vp, ci, vp, ci, ci, vp)
@@ -790,8 +790,11 @@ def stream1_wgrad(img, t, g: ConvGeom, out, sn, st, zfill=1, n_out=None, bias=No
     N = Np if n_out is None else int(n_out)
     if not 0 < N <= Np:
         raise ValueError(f"stream1_wgrad: n_out {N} vs {Np} channels")
-    nby = _s1_blocks(B, g.H, g.W, Cs, g.OH, g.OW, Np, g.KH, g.KW, g.sh, g.sw, g.dh, g.dw, g.pt, g.pl)
-    if nby <= 0 or _batch_ranges(B, max(g.OH * g.OW * Np, g.H * g.W * Cs)) is not None:
+    # tensors of 2^31 elements and more go in batch slices: each writes its slabs, the last call sums them all
+    rngs = _batch_ranges(B, max(g.OH * g.OW * Np, g.H * g.W * Cs)) or [(0, B)]
+    nbys = [_s1_blocks(b1 - b0, g.H, g.W, Cs, g.OH, g.OW, Np, g.KH, g.KW, g.sh, g.sw, g.dh, g.dw, g.pt, g.pl)
+            for b0, b1 in rngs]
+    if min(nbys) <= 0:
         return False
     T = g.KH * g.KW
     _chk_f32(out, (N - 1) * sn + (T - 1) * st + zfill, "out")
@@ -805,14 +808,24 @@ def stream1_wgrad(img, t, g: ConvGeom, out, sn, st, zfill=1, n_out=None, bias=No
         asc, ash, actrue = affine
         _chk_f32(asc, Np, "affine scale")
         _chk_f32(ash, Np, "affine shift")
-    slab = torch.empty(nby * ((T + 1) * Np + 1), dtype=torch.float32, device=img.device)
-    rc = _s1_wgrad(img.data_ptr(), t.data_ptr(), slab.data_ptr(), out.data_ptr(), _p(bias) if bias_mode else None, B,
-                   g.H, g.W, Cs, g.OH, g.OW, Np, N, g.KH, g.KW, g.sh, g.sw, g.dh, g.dw, g.pt, g.pl, int(sn), int(st),
-                   int(zfill), int(bias_mode), _p(asc), _p(ash), int(actrue), _stream())
-    if rc < 0:
-        raise ValueError(f"stream1_wgrad rejected its arguments (rc={rc})")
+    total = sum(nbys)
+    slab = torch.empty(total * ((T + 1) * Np + 1), dtype=torch.float32, device=img.device)
+    first = 0
+    for k, (b0, b1) in enumerate(rngs):
+        last = k + 1 == len(rngs)
+        rc = _s1_wgrad(img[b0:b1].data_ptr(), t[b0:b1].data_ptr(), slab.data_ptr(), out.data_ptr(),
+                       _p(bias) if bias_mode else None, b1 - b0, g.H, g.W, Cs, g.OH, g.OW, Np, N, g.KH, g.KW, g.sh, g.sw,
+                       g.dh, g.dw, g.pt, g.pl, int(sn), int(st), int(zfill), int(bias_mode), _p(asc), _p(ash),
+                       int(actrue), first, total if last else 0, _stream())
+        if rc < 0:
+            raise ValueError(f"stream1_wgrad rejected its arguments (rc={rc})")
+        if rc != 0:
+            if k:
+                raise RuntimeError("stream1_wgrad: a later batch slice fell outside the kernel's range")
+            return False
+        first += nbys[k]
     _done()
-    return rc == 0
+    return True
 
 
 def bn_bwd_sums(dy, x, mean, invstd, gamma, prev_act, prev_alpha, out_dgamma, out_dbeta, out_dbias=None):

@@ -1372,3 +1372,37 @@ def test_stream1_wgrad_of_a_5x5_layer_at_a_one_channel_image(hip, case, B):
     close(out3[:, :Fo].cpu(), ref2, rtol=1e-2)
     assert float(out3[:, ctrue:].abs().max()) == 0.0
     assert torch.allclose(b1.cpu(), img.sum().reshape(1), rtol=1e-3, atol=1e-2)
+
+
+@pytest.mark.gpu
+def test_stream1_wgrad_in_batch_slices_and_over_many_image_groups(hip, monkeypatch):
+    """Tensors of 2^31 elements and more reach the streaming weight gradient in batch slices whose slabs are summed by
+    one finish launch, and a block walks several image groups when the batch exceeds one round of blocks: both against
+    the unsliced result and the fp32 oracle."""
+    g = G.conv2d_geom(28, 28, 1, 32, (5, 5), (2, 2), (1, 1), "same")
+    torch.manual_seed(84)
+    B, T = 2100, 25
+    img = r16(torch.randn(B, 28, 28, 1))
+    t = r16(torch.randn(B, g.OH, g.OW, 32))
+    ref = cpu_ref.conv_wgrad(img, t, g)
+    imgd, td = dev(hip, img), dev(hip, t)
+    out = torch.full((32, 5, 5, 8), float("nan"), device="cuda")
+    bias = torch.full((32,), float("nan"), device="cuda")
+    assert hip.stream1_wgrad(imgd, td, g, out.view(-1), T * 8, 8, zfill=8, n_out=32, bias=bias, bias_mode=1)
+    close(out[..., :1].cpu(), ref, rtol=1e-2)
+    monkeypatch.setattr(hip, "ELEM_LIMIT", 700 * g.OH * g.OW * 32)          # three slices of 700 images
+    out2 = torch.full_like(out, float("nan"))
+    bias2 = torch.full_like(bias, float("nan"))
+    assert hip.stream1_wgrad(imgd, td, g, out2.view(-1), T * 8, 8, zfill=8, n_out=32, bias=bias2, bias_mode=1)
+    assert torch.allclose(out2, out, rtol=1e-4, atol=1e-3)
+    assert torch.allclose(bias2, bias, rtol=1e-4, atol=1e-3)
+    assert torch.allclose(bias.cpu(), t.reshape(-1, 32).sum(0), rtol=1e-3, atol=2e-2)
+    # 64 x 64 images: two per block fit the LDS budget, 1100 images = 550 groups over one round of 512 blocks
+    monkeypatch.undo()
+    g2 = G.conv2d_geom(64, 64, 1, 8, (5, 5), (1, 1), (1, 1), "same")
+    img = r16(torch.randn(1100, 64, 64, 1))
+    t = r16(torch.randn(1100, 64, 64, 8))
+    ref = cpu_ref.conv_wgrad(img, t, g2)
+    out3 = torch.full((8, 5, 5, 8), float("nan"), device="cuda")
+    assert hip.stream1_wgrad(dev(hip, img), dev(hip, t), g2, out3.view(-1), T * 8, 8, zfill=8, n_out=8)
+    close(out3[..., :1].cpu(), ref, rtol=1e-2)
