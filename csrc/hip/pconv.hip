@@ -68,12 +68,17 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 // tanh01): only that instantiation carries their (fully unrolled) code.
 // EPI: 0 = plain epilogue, 1 = STATS (batch-statistics partials for a following BN), 2 = AFFINE (inference BN folded in),
 // 3 = MULY (result *= act'(y) of the layer below, y laid out like dst: the activation backward fused into an input gradient)
-template <int BN, int FR, bool SLOW, int EPI>
-__global__ __launch_bounds__(256, (BN * FR >= 512 ? 1 : 2)) void pconv_kernel(const PConvArgs a) {
+// NW = waves per block (4 | 8).  The patch in LDS limits a CU to one or two blocks, and every phase of a block (staging,
+// per class: weight prologue, stage loop, epilogue) is a chain of dependent latencies that only OTHER waves can fill:
+// eight waves on the same patch and the same weight stages double the waves per CU at the same LDS footprint.
+template <int BN, int FR, bool SLOW, int EPI, int NW>
+__global__ __launch_bounds__(NW * 64, (BN * FR * NW >= 2048 ? 1 : 2)) void pconv_kernel(const PConvArgs a) {
     constexpr bool STATS = EPI == 1, AFFINE = EPI == 2, MULY = EPI == 3;
+    constexpr int NTHR = NW * 64;
     constexpr int NT = BN / 16;                        // 16-channel MFMA tiles per wave
-    constexpr int RW = (BN * 8 + 255) / 256;           // 16-B weight units staged per thread per stage
-    constexpr int PASS = 4 * FR * 16;                  // rows per pass (4 waves x FR fragments x 16 px)
+    constexpr int RW = (BN * 8 + NTHR - 1) / NTHR;     // 16-B weight units staged per thread per stage
+    constexpr int WROWS = NTHR / 8;                    // weight rows staged per round of the block's threads
+    constexpr int PASS = NW * FR * 16;                 // rows per pass (NW waves x FR fragments x 16 px)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* sP = smem;                                   // patch
     char* sW = smem + a.w_off;                         // [2][BN][WPITCH]
@@ -101,12 +106,12 @@ __global__ __launch_bounds__(256, (BN * FR >= 512 ? 1 : 2)) void pconv_kernel(co
         const int per_img = a.PH * a.PW * cs8;
         const int total = a.IMG * per_img;
         // eight independent 16-byte loads in flight per thread before the first LDS store
-        for (int base = tid; base < total; base += 256 * 8) {
+        for (int base = tid; base < total; base += NTHR * 8) {
             u32x4 v[8];
             int dst[8], aoff[8];
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
-                int u = base + k * 256;
+                int u = base + k * NTHR;
                 bool in = u < total;
                 int uu = in ? u : 0;
                 int img = fdiv(uu, a.inv_per_img), r = uu - img * per_img;
@@ -142,7 +147,7 @@ __global__ __launch_bounds__(256, (BN * FR >= 512 ? 1 : 2)) void pconv_kernel(co
                 if (dst[k] >= 0) *(u32x4*)(sP + dst[k]) = v[k];
         }
         int2* sKw = (int2*)(smem + a.k_off);
-        for (int t = tid; t < a.total_stages * 8; t += 256) sKw[t] = a.ktab[t];
+        for (int t = tid; t < a.total_stages * 8; t += NTHR) sKw[t] = a.ktab[t];
     }
     __syncthreads();
 
@@ -151,7 +156,7 @@ __global__ __launch_bounds__(256, (BN * FR >= 512 ? 1 : 2)) void pconv_kernel(co
     unsigned wbase[RW];                                // byte offset of the weight row, OOB if there is none
 #pragma unroll
     for (int r = 0; r < RW; ++r) {
-        int nl = wr0 + 32 * r, n = n0 + nl;
+        int nl = wr0 + WROWS * r, n = n0 + nl;
         wbase[r] = (nl < BN && n < a.Nw) ? (unsigned)(n * a.wrow) * 2u : OOB;
     }
 
@@ -233,8 +238,8 @@ __global__ __launch_bounds__(256, (BN * FR >= 512 ? 1 : 2)) void pconv_kernel(co
             auto lstore = [&](int buf, const u32x4 (&reg)[RW]) {
 #pragma unroll
                 for (int r = 0; r < RW; ++r) {
-                    int nl = wr0 + 32 * r;
-                    if (BN % 32 == 0 || nl < BN) *(u32x4*)(sW + (buf * BN + nl) * WPITCH + wq * 16) = reg[r];
+                    int nl = wr0 + WROWS * r;
+                    if (BN % WROWS == 0 || nl < BN) *(u32x4*)(sW + (buf * BN + nl) * WPITCH + wq * 16) = reg[r];
                 }
             };
 
@@ -437,7 +442,7 @@ __global__ __launch_bounds__(256, (BN * FR >= 512 ? 1 : 2)) void pconv_kernel(co
                     st_q[t][e] += __shfl_xor(st_q[t][e], o, 64);
                 }
         __syncthreads();                                   // every wave is done with the weight stages
-        float* red = (float*)sW;                           // [4 waves][BN][2]
+        float* red = (float*)sW;                           // [NW waves][BN][2]
         if (fr == 0) {
 #pragma unroll
             for (int t = 0; t < NT; ++t)
@@ -452,7 +457,7 @@ __global__ __launch_bounds__(256, (BN * FR >= 512 ? 1 : 2)) void pconv_kernel(co
         if (tid < BN && n0 + tid < a.Nd) {
             float s0 = 0.f, s1 = 0.f;
 #pragma unroll
-            for (int w = 0; w < 4; ++w) { s0 += red[(w * BN + tid) * 2]; s1 += red[(w * BN + tid) * 2 + 1]; }
+            for (int w = 0; w < NW; ++w) { s0 += red[(w * BN + tid) * 2]; s1 += red[(w * BN + tid) * 2 + 1]; }
             const size_t nb = a.stats_stride, col = (size_t)a.stats_off + blockIdx.x;
             a.stats[((size_t)(n0 + tid)) * nb + col] = s0;
             a.stats[((size_t)(a.Nd + n0 + tid)) * nb + col] = s1;
@@ -460,36 +465,41 @@ __global__ __launch_bounds__(256, (BN * FR >= 512 ? 1 : 2)) void pconv_kernel(co
     }
 }
 
-template <int BN, int FR, bool SLOW, int EPI>
+template <int BN, int FR, bool SLOW, int EPI, int NW>
 static int launch_pconv2(PConvArgs& a, int units, size_t smem, hipStream_t s) {
     if (smem > 64 * 1024) {
         static bool done = false;
         if (!done) {
-            hipFuncSetAttribute((const void*)pconv_kernel<BN, FR, SLOW, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize,
+            hipFuncSetAttribute((const void*)pconv_kernel<BN, FR, SLOW, EPI, NW>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 160 * 1024);
             done = true;
         }
     }
     dim3 grid(units, (a.Nd + BN - 1) / BN);
-    pconv_kernel<BN, FR, SLOW, EPI><<<grid, 256, smem, s>>>(a);
+    pconv_kernel<BN, FR, SLOW, EPI, NW><<<grid, NW * 64, smem, s>>>(a);
     return 0;
 }
 
-template <int BN, int FR>
+template <int BN, int FR, int NW>
 static int launch_pconv(PConvArgs& a, int units, size_t smem, hipStream_t s) {
     const bool fast = a.act == ACT_LINEAR || a.act == ACT_RELU || a.act == ACT_LEAKY;
     if (a.stats)
-        return fast ? launch_pconv2<BN, FR, false, 1>(a, units, smem, s) : launch_pconv2<BN, FR, true, 1>(a, units, smem, s);
+        return fast ? launch_pconv2<BN, FR, false, 1, NW>(a, units, smem, s) : launch_pconv2<BN, FR, true, 1, NW>(a, units, smem, s);
     if (a.mul_y)
-        return fast ? launch_pconv2<BN, FR, false, 3>(a, units, smem, s) : -4;
+        return fast ? launch_pconv2<BN, FR, false, 3, NW>(a, units, smem, s) : -4;
     if (a.bn_gamma)
-        return fast ? launch_pconv2<BN, FR, false, 2>(a, units, smem, s) : launch_pconv2<BN, FR, true, 2>(a, units, smem, s);
-    return fast ? launch_pconv2<BN, FR, false, 0>(a, units, smem, s) : launch_pconv2<BN, FR, true, 0>(a, units, smem, s);
+        return fast ? launch_pconv2<BN, FR, false, 2, NW>(a, units, smem, s) : launch_pconv2<BN, FR, true, 2, NW>(a, units, smem, s);
+    return fast ? launch_pconv2<BN, FR, false, 0, NW>(a, units, smem, s) : launch_pconv2<BN, FR, true, 0, NW>(a, units, smem, s);
 }
 
-DDL_API int ddl_pconv_lds_bytes(int BN, int total_stages, long patch_bytes) {
-    // the epilogue's transpose scratch (4 waves x (16 rows x (2 BN + 16) + 64) bytes) aliases the weight stages
-    long w = 2L * BN * WPITCH, k = (long)total_stages * 64;
+// bytes of the weight-stage area: two stages, and the epilogue's per-wave transpose scratch that aliases them
+static long pconv_wbytes(int BN, int NW) {
+    const long w = 2L * BN * WPITCH, e = (long)NW * (16 * (BN * 2 + 16) + 64);
+    return ((w > e ? w : e) + 15) / 16 * 16;
+}
+
+DDL_API int ddl_pconv_lds_bytes(int BN, int total_stages, long patch_bytes, int NW) {
+    long w = pconv_wbytes(BN, NW), k = (long)total_stages * 64;
     long p = (patch_bytes + 15) / 16 * 16;
     long tot = p + w + k;
     return tot > (1L << 30) ? -1 : (int)tot;
@@ -501,7 +511,7 @@ DDL_API int ddl_pconv(const void* src, const void* wgt, const float* bias, void*
                       const void* ktab, int n_classes, int total_stages, int B, int Hs, int Ws, int Cs, int Hd,
                       int Wd, int Nd, int Nw, int ssh, int ssw, int sdh, int sdw, int Ttot, int act, float alpha,
                       int IMG, int BR, int bands, int omin_h, int omin_w, int PH, int PW, int pitch, int BN, int FR,
-                      float* stats, const float* bn_gamma, const float* bn_beta, const float* bn_mean,
+                      int NW, float* stats, const float* bn_gamma, const float* bn_beta, const float* bn_mean,
                       const float* bn_var, float bn_eps, const float* in_scale, const float* in_shift,
                       int in_group_rows, int in_ctrue, const void* mul_y, float mul_slope, int stats_stride,
                       int stats_off, hipStream_t s) {
@@ -531,18 +541,19 @@ DDL_API int ddl_pconv(const void* src, const void* wgt, const float* bias, void*
     long patch = (long)IMG * a.img_bytes;
     if ((long)IMG * PH * PW * (Cs / 8) >= (1L << 22)) return -2;
     a.w_off = (int)((patch + 15) / 16 * 16);
-    a.k_off = a.w_off + 2 * BN * WPITCH;
+    if (NW != 4 && NW != 8) return -4;
+    a.k_off = a.w_off + (int)pconv_wbytes(BN, NW);
     a.e_off = a.w_off;                    // epilogue scratch aliases the weight stages (see the kernel)
-    if (4 * (16 * (BN * 2 + 16) + 64) > 2 * BN * WPITCH) return -2;
     size_t smem = (size_t)a.k_off + (size_t)total_stages * 64;
     if (smem > 160 * 1024) return -2;
     a.inv_per_img = 1.0f / (float)(PH * PW * (Cs / 8));
     a.inv_cs8 = 1.0f / (float)(Cs / 8);
     a.inv_PW = 1.0f / (float)PW;
     int units = ((B + IMG - 1) / IMG) * bands;
-#define PC_CASE(BN_, FR_) if (BN == BN_ && FR == FR_) return launch_pconv<BN_, FR_>(a, units, smem, s);
-    PC_CASE(16, 4) PC_CASE(16, 8) PC_CASE(32, 2) PC_CASE(32, 4) PC_CASE(32, 8) PC_CASE(64, 2) PC_CASE(64, 4) PC_CASE(64, 8)
-    PC_CASE(128, 4)
+#define PC_CASE(BN_, FR_, NW_) if (BN == BN_ && FR == FR_ && NW == NW_) return launch_pconv<BN_, FR_, NW_>(a, units, smem, s);
+    PC_CASE(16, 4, 4) PC_CASE(16, 8, 4) PC_CASE(32, 2, 4) PC_CASE(32, 4, 4) PC_CASE(32, 8, 4) PC_CASE(64, 2, 4)
+    PC_CASE(64, 4, 4) PC_CASE(64, 8, 4) PC_CASE(128, 4, 4)
+    PC_CASE(32, 2, 8) PC_CASE(32, 4, 8) PC_CASE(64, 2, 8) PC_CASE(64, 4, 8)
 #undef PC_CASE
     return -4;
 }

@@ -95,8 +95,8 @@ _philox = _sig("ddl_philox_uniform", None, vp, cl, vp, cf, cf, vp)
 _igemm = _sig("ddl_igemm_conv", ci, vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci,
               ci, ci, ci, ci, cf, ci, ci, vp, vp, cf, vp, ci, ci, vp)
 _pconv = _sig("ddl_pconv", ci, vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, cf,
-              ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, vp, vp, vp, vp, vp, cf, vp, vp, ci, ci, vp, cf, ci, ci, vp)
-_pconv_lds = _sig("ddl_pconv_lds_bytes", ci, ci, ci, cl)
+              ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, vp, vp, vp, vp, vp, cf, vp, vp, ci, ci, vp, cf, ci, ci, vp)
+_pconv_lds = _sig("ddl_pconv_lds_bytes", ci, ci, ci, cl, ci)
 _wgrad_ksplit = _sig("ddl_wgrad_ksplit", ci, ci, ci, ci, ci)
 _wgrad = _sig("ddl_conv_wgrad", ci, vp, vp, vp, vp, cl, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci,
               ci, ci, ci, ci, cl, cl, cl, vp, vp, ci, ci, cl, ci, vp)
@@ -1179,14 +1179,14 @@ def _pick_pitch(Cs: int, stride: int) -> int:
 
 
 def _pconv_plan(g: ConvGeom, mode: str, B: int, Cs: int, Nd: int, ss, device, budget=None, img=None, fr=None,
-                min_rows=None):
+                min_rows=None, nw=4):
     """Unit decomposition + patch geometry + k-unit table for the patch-resident kernel, or None when
     the problem does not fit the scheme (Dense, patch too big for LDS, too few rows per unit).
     `budget` = LDS bytes per block (80 KiB -> two blocks per CU), `img` = images per unit (default:
     as many as fit, capped), `fr` = 16-row fragments per wave (4 | 8)."""
     budget = budget or PCONV_LDS or 80 * 1024
     min_rows = PCONV_MIN_ROWS if min_rows is None else min_rows
-    key = (g, mode, B, Cs, Nd, str(device), budget, img, fr, min_rows)
+    key = (g, mode, B, Cs, Nd, str(device), budget, img, fr, min_rows, nw)
     if key in _PLAN_CACHE:
         return _PLAN_CACHE[key]
     plan = None
@@ -1204,7 +1204,10 @@ def _pconv_plan(g: ConvGeom, mode: str, B: int, Cs: int, Nd: int, ss, device, bu
         PW = (maxWc - 1) * ssw + (omax_w - omin_w) + 1
         nst = [((c[4] * Cs + 63) // 64 + 1) // 2 * 2 for c in classes]       # even: the kernel works in stage pairs
         total_stages = sum(nst)
-        fixed = _pconv_lds(BN, total_stages, 0)
+        if nw == 8 and BN not in (32, 64):
+            _PLAN_CACHE[key] = None
+            return None
+        fixed = _pconv_lds(BN, total_stages, 0, nw)
         rows_of = lambda br: (br - 1) * ssh + (omax_h - omin_h) + 1
         img_full = rows_of(maxHc) * PW * pitch
         IMG, BR = 0, maxHc
@@ -1239,6 +1242,8 @@ def _pconv_plan(g: ConvGeom, mode: str, B: int, Cs: int, Nd: int, ss, device, bu
                 FR = 4
             elif not (fr or PCONV_FR) and 32 <= Nd <= 64 and rows_unit <= 128:
                 FR = 2                  # a 256-row pass over <= 128 rows wastes half the MFMAs (what the autotuner picks)
+            if nw == 8 and FR not in (2, 4):
+                FR = 2                  # eight-wave blocks: 256- or 512-row passes
             ktab = np.zeros((total_stages * 8, 2), dtype=np.int32)
             cdesc = np.zeros(len(classes), dtype=[("ph", "<i4"), ("pw", "<i4"), ("Hc", "<i4"), ("Wc", "<i4"),
                                                   ("nst", "<i4"), ("soff", "<i4"), ("invWc", "<f4"), ("pad", "<f4")])
@@ -1256,11 +1261,11 @@ def _pconv_plan(g: ConvGeom, mode: str, B: int, Cs: int, Nd: int, ss, device, bu
                         else:
                             ktab[row] = (0, -1)
                 soff += nst[ci_]
-            if _pconv_lds(BN, total_stages, IMG * PH * PW * pitch) <= 160 * 1024:
+            if _pconv_lds(BN, total_stages, IMG * PH * PW * pitch, nw) <= 160 * 1024:
                 plan = dict(classes=torch.from_numpy(cdesc.view(np.uint8).copy()).to(device),
                             ktab=torch.from_numpy(ktab).to(device), ncls=len(classes), nst=total_stages,
                             IMG=IMG, BR=BR, bands=bands, omin_h=omin_h, omin_w=omin_w, PH=PH, PW=PW, pitch=pitch,
-                            BN=BN, FR=FR, budget=budget)
+                            BN=BN, FR=FR, budget=budget, NW=nw)
     _PLAN_CACHE[key] = plan
     return plan
 
@@ -1276,17 +1281,21 @@ def _pconv_candidates(g, mode, B, Cs, Nd, ss, device):
         if base["bands"] == 1:
             imgs |= {max(1, base["IMG"] // 2), base["IMG"] * 2}
         for im in sorted(imgs):
-            for fr in ((2, 4, 8) if 32 <= Nd <= 64 else (4, 8)):      # FR 2: 128-row passes for small units
-                pl = _pconv_plan(g, mode, B, Cs, Nd, ss, device, budget=budget, img=im, fr=fr, min_rows=64)
+            shapes = [(fr, 4) for fr in ((2, 4, 8) if 32 <= Nd <= 64 else (4, 8))]      # FR 2: 128-row passes for small units
+            if PCONV_NW8 and 16 < Nd <= 64:
+                shapes += [(2, 8), (4, 8)]      # eight waves on one patch: twice the waves per CU at the same LDS
+            for fr, nw in shapes:
+                pl = _pconv_plan(g, mode, B, Cs, Nd, ss, device, budget=budget, img=im, fr=fr, min_rows=64, nw=nw)
                 if pl is None:
                     continue
-                sig = (pl["IMG"], pl["BR"], pl["FR"], pl["budget"] if pl["bands"] > 1 else 0)
+                sig = (pl["IMG"], pl["BR"], pl["FR"], pl["budget"] if pl["bands"] > 1 else 0, pl["NW"])
                 if sig not in seen:
                     seen.add(sig)
                     out.append(pl)
     return out
 
 
+PCONV_NW8 = os.environ.get("DDL_PCONV_NW8", "1") == "1"
 _CONV_CHOICE: Dict[Tuple, object] = {}
 AUTOTUNE = os.environ.get("DDL_AUTOTUNE", "1") == "1"
 
@@ -1430,7 +1439,8 @@ def _run_pconv(pl, src, wgt, bias, dst, g, B, Hs, Ws, Cs, Hd, Wd, Nd, Nw, ss, sd
     rc = _pconv(src.data_ptr(), wgt.data_ptr(), _p(bias), dst.data_ptr(), pl["classes"].data_ptr(),
                 pl["ktab"].data_ptr(), pl["ncls"], pl["nst"], B, Hs, Ws, Cs, Hd, Wd, Nd, Nw, ss[0], ss[1],
                 sd[0], sd[1], g.KH * g.KW, ACT_CODE[act], alpha, pl["IMG"], pl["BR"], pl["bands"],
-                pl["omin_h"], pl["omin_w"], pl["PH"], pl["PW"], pl["pitch"], pl["BN"], pl["FR"], _p(stats), bg, bb, bm,
+                pl["omin_h"], pl["omin_w"], pl["PH"], pl["PW"], pl["pitch"], pl["BN"], pl["FR"], pl.get("NW", 4), _p(stats),
+                bg, bb, bm,
                 bvv, beps, isc, ish, igr, ict, my, ms, stats_at[0], stats_at[1], _stream())
     if rc != 0:
         raise ValueError(f"pconv rejected its plan (rc={rc}): {g} B={B} "
@@ -1599,7 +1609,8 @@ def _conv_choice(src, wgt, bias, dst, g, mode, B, Hs, Ws, Cs, Hd, Wd, Nd, Nw, ss
         if spec[0] == "igemm":
             choice = ("igemm", spec[1])
         else:
-            pl = _pconv_plan(g, mode, B, Cs, Nd, ss, src.device, budget=spec[1], img=spec[2], fr=spec[3], min_rows=64)
+            pl = _pconv_plan(g, mode, B, Cs, Nd, ss, src.device, budget=spec[1], img=spec[2], fr=spec[3], min_rows=64,
+                             nw=spec[4] if len(spec) > 4 else 4)
             choice = ("pconv", pl) if pl is not None else None
         if choice is not None:
             _CONV_CHOICE[key] = choice
@@ -1626,9 +1637,9 @@ def _conv_choice(src, wgt, bias, dst, g, mode, B, Hs, Ws, Cs, Hd, Wd, Nd, Nw, ss
             timed.sort(key=lambda t: t[0])
             choice = (timed[0][1], timed[0][2])
             _record_choice(kstr, ["igemm", choice[1]] if choice[0] == "igemm" else
-                           ["pconv", choice[1]["budget"], choice[1]["IMG"], choice[1]["FR"]])
+                           ["pconv", choice[1]["budget"], choice[1]["IMG"], choice[1]["FR"], choice[1]["NW"]])
             if os.environ.get("DDL_AUTOTUNE_VERBOSE"):
-                desc = [(round(t, 1), k, p if k == "igemm" else (p["IMG"], p["BR"], p["FR"], p["budget"] // 1024))
+                desc = [(round(t, 1), k, p if k == "igemm" else (p["IMG"], p["BR"], p["FR"], p["budget"] // 1024, p["NW"]))
                         for t, k, p in timed]
                 print(f"[autotune] {mode} B={B} {g.H}x{g.W}x{g.I}->{g.OH}x{g.OW}x{g.O} k{g.KH} s{g.sh}: {desc}",
                       flush=True)

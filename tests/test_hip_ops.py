@@ -1406,3 +1406,38 @@ def test_stream1_wgrad_in_batch_slices_and_over_many_image_groups(hip, monkeypat
     out3 = torch.full((8, 5, 5, 8), float("nan"), device="cuda")
     assert hip.stream1_wgrad(dev(hip, img), dev(hip, t), g2, out3.view(-1), T * 8, 8, zfill=8, n_out=8)
     close(out3[..., :1].cpu(), ref, rtol=1e-2)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(14, 14, 32, 64, 2, 2), (7, 7, 40, 24, 1, 4), (14, 14, 64, 32, 2, 4)])
+@pytest.mark.parametrize("B", [3, 260])
+def test_pconv_eight_wave_blocks_match_four_wave_blocks(hip, shape, B):
+    """The eight-wave instantiations of the patch-resident kernel (same patch, same weight stages, twice the waves per
+    CU): output bit-identical to the four-wave plan of the same problem (the K order per output value is the same),
+    BatchNorm statistics equal to a column reduction of the stored output, and the oracle within tolerance."""
+    H, W, I, O, s, fr = shape
+    g = G.conv2d_geom(H, W, I, O, (5, 5), (s, s), (1, 1), "same")
+    torch.manual_seed(85)
+    xh, wh = r16(torch.randn(B, H, W, I)), r16(torch.randn(O, 5, 5, I) / 20)
+    x, w = dev(hip, xh), padw(hip, wh)
+    bias = torch.randn(O)
+    Ip, Op = hip.pad8(I), hip.pad8(O)
+    outs = []
+    for nw in (4, 8):
+        pl = hip._pconv_plan(g, "fprop", B, Ip, Op, (g.sh, g.sw), x.device, min_rows=16, fr=fr, nw=nw)
+        assert pl is not None and pl["NW"] == nw
+        nb = hip._pconv_units(pl, B)
+        y = torch.full((B, g.OH, g.OW, Op), float("nan"), dtype=torch.bfloat16, device="cuda")
+        part = torch.full((2 * Op * nb,), float("nan"), device="cuda")
+        hip._run_pconv(pl, x, w, bias.cuda(), y, g, B, g.H, g.W, Ip, g.OH, g.OW, Op, O, (g.sh, g.sw), (1, 1), "leaky", 0.3,
+                       stats=part)
+        sums = part.view(2, Op, nb).double().sum(-1).cpu()
+        yf = y.float().reshape(-1, Op).double().cpu()
+        assert torch.allclose(sums[0], yf.sum(0), rtol=1e-4, atol=1e-2)
+        assert torch.allclose(sums[1], (yf * yf).sum(0), rtol=1e-4, atol=1e-2)
+        y0 = torch.full_like(y, float("nan"))
+        hip._run_pconv(pl, x, w, bias.cuda(), y0, g, B, g.H, g.W, Ip, g.OH, g.OW, Op, O, (g.sh, g.sw), (1, 1), "tanh", 0.3)
+        outs.append((y, y0))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    close(host(hip, outs[1][0], O), cpu_ref.conv_fprop(xh, wh, bias, g, "leaky", 0.3))
+    close(host(hip, outs[1][1], O), cpu_ref.conv_fprop(xh, wh, bias, g, "tanh"))
