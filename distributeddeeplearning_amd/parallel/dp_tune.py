@@ -79,7 +79,7 @@ def _free_port() -> int:
         return s.getsockname()[1]
 
 
-def probe_p2p(device, capacity_elems: int, timeout_s: float = 180.0, verbose: bool = False) -> bool:
+def probe_p2p(device, capacity_elems: int, timeout_s: float = 90.0, verbose: bool = False) -> bool:
     """Run `parallel/p2p_probe.py` as a child of every rank (same device, a gloo group of their own) and agree on the
     verdict.  True iff every child mapped its peers, validated one- and two-shot all-reduces and the fused update
     against host sums, stayed healthy and exited cleanly.  A collective: every rank calls it."""
