@@ -213,7 +213,7 @@ __global__ __launch_bounds__(NW * 64, (BN * FR * NW >= 2048 ? 1 : 2)) void pconv
 
         for (int ms = 0; ms < Mloc; ms += PASS) {
             // ---- this lane's FR pixels (one per 16-row fragment)
-            int pixbase[FR];
+            int pixbase[FR], pixdst[FR];           // patch byte offset / destination pixel (-1: no such row) of the lane's pixels
 #pragma unroll
             for (int j = 0; j < FR; ++j) {
                 int m = ms + (wave * FR + j) * 16 + fr;
@@ -221,6 +221,8 @@ __global__ __launch_bounds__(NW * 64, (BN * FR * NW >= 2048 ? 1 : 2)) void pconv
                 int img = fdiv(mm, inv_rows), rem = mm - img * per_img_rows;
                 int il = fdiv(rem, cd.inv_Wc), jl = rem - il * cd.Wc;
                 pixbase[j] = img * a.img_bytes + (il * a.ssh * a.PW + jl * a.ssw) * a.pitch;
+                const int b = b0 + img;
+                pixdst[j] = (m < Mloc && b < a.B) ? (b * a.Hd + cd.ph + a.sdh * (i0 + il)) * a.Wd + cd.pw + a.sdw * jl : -1;
             }
 
             u32x4 regA[RW], regB[RW];              // stage s lives in regA (s even) / regB (s odd)
@@ -372,27 +374,24 @@ __global__ __launch_bounds__(NW * 64, (BN * FR * NW >= 2048 ? 1 : 2)) void pconv
                 const int nlim = a.Nw - n0 - 4 * fq;       // channel 16t + e is real iff 16t + e < nlim
 #pragma unroll
                 for (int j = 0; j < FR; ++j) {
-                    int m = ms + (wave * FR + j) * 16 + fr;
-                    int mm = m < Mloc ? m : 0;
-                    int img = fdiv(mm, inv_rows), rem = mm - img * per_img_rows;
-                    int il = fdiv(rem, cd.inv_Wc), jl = rem - il * cd.Wc;
-                    int b = b0 + img;
-                    bool ok = m < Mloc && b < a.B;
-                    int pix = (b * a.Hd + cd.ph + a.sdh * (i0 + il)) * a.Wd + cd.pw + a.sdw * jl;
-                    if (fq == 0) sPix[fr] = ok ? pix : -1;
+                    const bool ok = pixdst[j] >= 0;
+                    if (fq == 0) sPix[fr] = pixdst[j];
 #pragma unroll
                     for (int t = 0; t < NT; ++t) {
                         float v[4];
 #pragma unroll
                         for (int e = 0; e < 4; ++e) v[e] = (16 * t + e < nlim) ? acc[t][j][e] : 0.f;
-                        *(uint2*)(sE + fr * EROW + (16 * t + 4 * fq) * 2) =
-                            make_uint2(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]));
+                        const uint32_t w0 = pack2bf(v[0], v[1]), w1 = pack2bf(v[2], v[3]);
+                        *(uint2*)(sE + fr * EROW + (16 * t + 4 * fq) * 2) = make_uint2(w0, w1);
                         if (STATS) {
+                            // what the stored tensor holds: the packed words, unpacked again
+                            const float r[4] = {__uint_as_float(w0 << 16), __uint_as_float(w0 & 0xffff0000u),
+                                                __uint_as_float(w1 << 16), __uint_as_float(w1 & 0xffff0000u)};
 #pragma unroll
                             for (int e = 0; e < 4; ++e) {
-                                const float r = ok ? bf2f(f2bf(v[e])) : 0.f;     // what the stored tensor holds
-                                st_s[t][e] += r;
-                                st_q[t][e] = fmaf(r, r, st_q[t][e]);
+                                const float q = ok ? r[e] : 0.f;
+                                st_s[t][e] += q;
+                                st_q[t][e] = fmaf(q, q, st_q[t][e]);
                             }
                         }
                     }
