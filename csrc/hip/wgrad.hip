@@ -259,7 +259,15 @@ __global__ void slab_reduce_kernel(const float* __restrict__ slab, float* __rest
                                    long slab_stride, int ksplit) {
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
         float s = 0.f;
-        for (int k = 0; k < ksplit; ++k) s += slab[k * slab_stride + i];
+        int k = 0;
+        for (; k + 7 < ksplit; k += 8) {              // eight independent loads per trip, summed in slab order
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = slab[(k + u) * slab_stride + i];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s += v[u];
+        }
+        for (; k < ksplit; ++k) s += slab[k * slab_stride + i];
         out[i] = s;
     }
 }
@@ -276,6 +284,13 @@ __global__ __launch_bounds__(256) void slab_reduce_wide_kernel(const float4* __r
     float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
     if (i < n4) {
         int k = kl;
+        for (; k + 120 < ksplit; k += 128) {          // sixteen loads per trip where there are that many slabs (same order)
+            float4 v[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) v[u] = slab[(long)(k + 8 * u) * stride4 + i];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) { s.x += v[u].x; s.y += v[u].y; s.z += v[u].z; s.w += v[u].w; }
+        }
         for (; k + 24 < ksplit; k += 32) {            // four independent 16-byte loads per trip, fixed order
             float4 v[4];
 #pragma unroll

@@ -401,6 +401,15 @@ __global__ __launch_bounds__(256) void slab_reduce_frag_kernel(const float4* __r
     const bool live = tap < d.T;                 // uniform per 64 consecutive f (a wave of the producer)
     if (live) {
         int k = kl;
+        // (a lane's ~30 slabs used to be seven dependent trips of four loads: the kernel is a chain of memory latencies,
+        //  not a bandwidth problem -- sixteen loads per trip, summed in the same order as before)
+        for (; k + 120 < nsplit; k += 128) {
+            float4 v[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) v[u] = slab[(long)(k + 8 * u) * e4 + f];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) { s.x += v[u].x; s.y += v[u].y; s.z += v[u].z; s.w += v[u].w; }
+        }
         for (; k + 24 < nsplit; k += 32) {       // four independent 16-byte loads per trip, fixed order
             float4 v[4];
 #pragma unroll
