@@ -14,6 +14,7 @@
 // reduced across waves through LDS and written to a per-split slab; a second kernel sums the
 // slabs in a fixed order (deterministic, no float atomics).
 #include "common.h"
+#include <cstdlib>
 
 struct WgradArgs {
     const bf16_t* dy; const bf16_t* x; float* slab;
@@ -339,8 +340,15 @@ DDL_API int ddl_wgrad_ksplit(int M, int taps, int n_lim, int c_lim) {
     int tn = n_lim > 32 ? 64 : (n_lim > 16 ? 32 : 16);
     int tc = c_lim > 32 ? 64 : (c_lim > 16 ? 32 : 16);
     long tiles = (long)((n_lim + tn - 1) / tn) * ((c_lim + tc - 1) / tc) * taps;
-    long want = (1024 + tiles - 1) / tiles;
-    long maxk = (M + 127) / 128;
+    static const long target = getenv("DDL_WGRAD_BLOCKS") ? atol(getenv("DDL_WGRAD_BLOCKS")) : 1024;
+    long want = (target + tiles - 1) / tiles;
+    // At least 1024 rows of the reduction per split (was 128).  The DCGAN generator's Dense layer (M = 1000 rows,
+    // 196 tiles) ran as six splits of 167 rows -- 19 MB of slab traffic for a 3 MB gradient, plus the reduce launch;
+    // as one split the headline step is 10-14 us shorter.  Measured 128 / 512 / 1024 / 2048 / 4096: dcgan28 1.134 /
+    // 1.126 / 1.120 / 1.124 / 1.124 ms, classifier 3.287 / 3.274 / 3.273 / 3.297 / 3.307 ms, batch-32 ensemble
+    // 25.85 / - / 25.83 / - / 26.9 ms.
+    static const long minrows = getenv("DDL_WGRAD_MINROWS") ? atol(getenv("DDL_WGRAD_MINROWS")) : 1024;
+    long maxk = (M + minrows - 1) / minrows;
     long k = want < 1 ? 1 : want;
     if (k > maxk) k = maxk;
     if (k > 256) k = 256;
