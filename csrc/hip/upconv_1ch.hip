@@ -521,8 +521,8 @@ DDL_API int ddl_upconv_1ch_wgrad(const void* x, const void* dy, float* slab, flo
 // lane owns CH channels of one pixel of t and 25 x CH accumulators, and t is read exactly once: 31 + 18 us at first
 // (index arithmetic and per-tap address adds cost more than the multiply-adds), then tap offsets as immediates of
 // paired LDS reads, a division-free pixel walk and all of a block's images staged behind one barrier pair.  Both
-// layers run on the side stream, so the step time is unchanged either way (see s1_ch); what the kernel removes is the
-// taps tensor (12 .. 200 MB of scratch per step) and two launches.
+// layers' kernels take as long inside the step as the path they replace (see s1_ch), so the executor uses this kernel
+// from 2^27 operand elements up (network.S1_WGRAD_MIN_ELEMS): there it removes an 8.6 GB taps tensor and 1 ms per step.
 template <int CH> struct S1Vec;
 template <> struct S1Vec<2> { typedef unsigned type; };
 template <> struct S1Vec<4> { typedef unsigned type __attribute__((ext_vector_type(2))); };

@@ -135,6 +135,10 @@ class Op:
         pass
 
 
+# The streaming 5x5 one-channel weight gradient (ops/hip.py stream1_wgrad) from this many elements of the N-channel
+# operand up.  Below it the taps tensor + split-K GEMM path is as fast or faster (dcgan28, 6-12 M elements: 1.120 vs
+# 1.124 ms per step); at dcgan64's 2-4 G elements the streaming kernel saves the 8.6 GB taps tensor and 1 ms per step.
+S1_WGRAD_MIN_ELEMS = int(os.environ.get("DDL_S1_WGRAD_MIN_ELEMS", str(1 << 27)))
 _NO = object()        # sentinel: "an affine exists but cannot be applied on load"
 
 
@@ -300,7 +304,8 @@ class ConvOp(Op):
             if need_dw:                 # dW[n][t] -> canonical [O][KH][KW][8] slot (n, t, channel 0)
                 def wg():
                     # 4x4 / 5x5: the streaming kernel reads dY once against the image in LDS (bias gradient included)
-                    if self.x is None and self.x_img is not None and self.gkernel.dtype == torch.float32:
+                    if (self.x is None and self.x_img is not None and self.gkernel.dtype == torch.float32
+                            and dy.numel() >= S1_WGRAD_MIN_ELEMS):
                         plain = self._bias_plain()
                         if hip.stream1_wgrad(self.x_img, dy, g, self.gkernel.reshape(-1), T * 8, 8, zfill=8, n_out=g.O,
                                              bias=self.gbias if plain else None, bias_mode=1 if plain else 0):
@@ -356,7 +361,8 @@ class ConvOp(Op):
                         xa_any = _NO
 
                 def wg():
-                    if dyc[0] is None and xa_any is not _NO and self.gkernel.dtype == torch.float32:
+                    if (dyc[0] is None and xa_any is not _NO and self.gkernel.dtype == torch.float32
+                            and self.x.numel() >= S1_WGRAD_MIN_ELEMS):
                         # 4x4 / 5x5: streaming kernel, the dY image in LDS, x read once with its BatchNorm on load
                         plain = self._bias_plain()
                         Ip = self.x.shape[-1]

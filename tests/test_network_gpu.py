@@ -333,3 +333,36 @@ def test_depthwise_bn_backward_fusion_matches_three_pass_form(i):
     assert any(used[True]) and not any(used[False])
     err = float((res[True] - res[False]).norm() / (res[False].norm() + 1e-12))
     assert err < 2e-2, err
+
+
+def test_streaming_one_channel_weight_gradients_match_the_taps_path(monkeypatch):
+    """The streaming 5x5 weight gradient of the DCGAN pair's one-channel ends (network.S1_WGRAD_MIN_ELEMS forced to 0:
+    by default it serves only operands of 2^27 elements and more) against the taps-tensor + split-K GEMM path: D's first
+    conv with its bias gradient, G's last transposed conv with the BatchNorm in front of it on load and its scalar bias
+    gradient; nothing else in the flat gradient buffers changes."""
+    from distributeddeeplearning_amd.models import network
+    import distributeddeeplearning_amd.ops.hip as hip
+    torch.manual_seed(0)
+    x = torch.rand(96, 28, 28, 1).bfloat16().float()
+    dyD = hip.pad_channels((torch.randn(96, 1).abs() / 64).bfloat16().float().cuda(), 8)
+    z = (torch.rand(64, 128) * 2 - 1).bfloat16().float()
+    dyG = hip.pad_channels(torch.randn(64, 28, 28, 1).bfloat16().float().cuda(), 8)
+    calls = []
+    real = hip.stream1_wgrad
+    monkeypatch.setattr(hip, "stream1_wgrad", lambda *a, **k: (calls.append(1), real(*a, **k))[1])
+    res = {}
+    for lim in (0, 1 << 40):
+        monkeypatch.setattr(network, "S1_WGRAD_MIN_ELEMS", lim)
+        n0 = len(calls)
+        d = Network(discriminator_spec(), "cuda", 1, "batch")
+        d.forward(d.prepare_input(x), training=True)
+        d.backward(dyD, need_input_grad=True)
+        g = Network(generator_spec(), "cuda", 2, "batch")
+        g.forward(g.prepare_input(z), training=True)
+        g.backward(dyG)
+        torch.cuda.synchronize()
+        assert (len(calls) - n0) == (2 if lim == 0 else 0)
+        res[lim] = (d.G.clone(), g.G.clone())
+    for a, b in zip(res[0], res[1 << 40]):
+        assert torch.allclose(a, b, rtol=2e-3, atol=2e-3 * float(b.abs().max()))
+        assert float((a - b).abs().max()) > 0 or torch.equal(a, b)
