@@ -1144,14 +1144,27 @@ __global__ __launch_bounds__(256) void im2col_1ch_kernel(const bf16_t* __restric
         int kh = t / g.KW, kw = t - kh * g.KW;
         tap[t] = t < g.T ? kh * g.dh * PW + kw * g.dw : ((g.ones && t == g.T) ? -2 : -1);
     }
-    for (int i = threadIdx.x; i < nimg * psz; i += 256) {
-        const int im = fdiv_small(i, 1.0f / (float)psz), e = i - im * psz;
-        const int r = fdiv_small(e, invPW), c = e - r * PW;
-        const int ih = r - g.pt, iw = c - g.pl;
-        bf16_t v = 0;
-        if ((unsigned)ih < (unsigned)g.H && (unsigned)iw < (unsigned)g.W)
-            v = img[(((long)(b0 + im) * g.H + ih) * g.W + iw) * g.Ci];
-        plane[i] = v;
+    // four plane elements per thread and trip, their loads issued together (a one-image block has four trips: as a
+    // loop of guarded loads that was four global-memory latencies in a row before the first store)
+    const float invPsz = 1.0f / (float)psz;
+    for (int i0 = threadIdx.x; i0 < nimg * psz; i0 += 1024) {
+        bf16_t v[4];
+        bool in[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int i = min(i0 + k * 256, nimg * psz - 1);
+            const int im = fdiv_small(i, invPsz), e = i - im * psz;
+            const int r = fdiv_small(e, invPW), c = e - r * PW;
+            const int ih = r - g.pt, iw = c - g.pl;
+            in[k] = (unsigned)ih < (unsigned)g.H && (unsigned)iw < (unsigned)g.W;
+            const int ihc = min(max(ih, 0), g.H - 1), iwc = min(max(iw, 0), g.W - 1);
+            v[k] = img[(((long)(b0 + im) * g.H + ihc) * g.W + iwc) * g.Ci];
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int i = i0 + k * 256;
+            if (i < nimg * psz) plane[i] = in[k] ? v[k] : (bf16_t)0;
+        }
     }
     __syncthreads();
     const int tg = g.Tp / 8, npix = g.OH * g.OW, per_img = npix * tg;
