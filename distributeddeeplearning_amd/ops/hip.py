@@ -1280,6 +1280,9 @@ def _pconv_candidates(g, mode, B, Cs, Nd, ss, device):
         imgs = {base["IMG"]}
         if base["bands"] == 1:
             imgs |= {max(1, base["IMG"] // 2), base["IMG"] * 2}
+            # unit counts that fill whole rounds of the chip at one to four blocks per CU (2000 images in units of
+            # five are 400 blocks: 1.56 rounds of 256 one-block CUs, the second round 56 % full; units of four are 1.95)
+            imgs |= {-(-B // (256 * k)) for k in (1, 2, 3, 4)}
         for im in sorted(imgs):
             shapes = [(fr, 4) for fr in ((2, 4, 8) if 32 <= Nd <= 64 else (4, 8))]      # FR 2: 128-row passes for small units
             if PCONV_NW8 and 16 < Nd <= 64:
