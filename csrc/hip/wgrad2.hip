@@ -38,6 +38,10 @@ struct Wg2Args {
     // contiguous KiB); rx / ry = chunks per thread of the X / dY section, xcpp / ycpp = chunks per pixel
     int buf_bytes, rx, ry, xcpp, ycpp;
     float inv_xcpp, inv_ycpp, inv_phpw;
+    // register-staged forms only: a per-channel affine on the dY operand as it is staged -- dY' = bf16(dY * y_scale[n] +
+    // y_shift[n]) on real pixels, channels >= y_ctrue zero -- i.e. a BatchNorm in front of a transposed convolution
+    // (whose INPUT is this kernel's dY operand) that was applied on load in the forward pass and never materialised
+    const float* y_scale; const float* y_shift; int y_ctrue, a_off;
 };
 
 __device__ __forceinline__ int fdiv2(int x, float inv) { return __float2int_rz(((float)x + 0.5f) * inv); }
@@ -101,6 +105,15 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 || TPW * (TN / 16) * (TC / 16) * 
     for (int t = tid; t < T; t += NT) {
         int kh = t / a.KW, kw = t - kh * a.KW;
         sTap[t] = (kh * a.dh * a.PW + kw * a.dw) * a.xpitch;
+    }
+    const float* sAff = (const float*)(smem + a.a_off);     // [2][TN]: scale, shift of this tile's dY channels
+    if (!DMA && a.y_scale) {
+        float* w = (float*)(smem + a.a_off);
+        for (int c = tid; c < TN; c += NT) {
+            const bool real = n0 + c < a.y_ctrue;
+            w[c] = real ? a.y_scale[n0 + c] : 0.f;
+            w[TN + c] = real ? a.y_shift[n0 + c] : 0.f;
+        }
     }
 
     f32x4 acc[TPW][SN][SC];
@@ -181,14 +194,28 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 || TPW * (TN / 16) * (TC / 16) * 
                 const bool ok = in & (m < a.Mmax) & (bb < a.B) & (il < nrow) & (n0 + c8 * 8 < a.Ny);
                 const unsigned off = ok ? (unsigned)(((bb * a.OH + i0 + il) * a.OW + jl) * a.Ny + n0 + c8 * 8) * 2u : OOB_OFF;
                 v[k] = __builtin_amdgcn_raw_buffer_load_b128(rsY, off, 0, 0);
-                dst[k] = in ? a.y_off + m * a.ypitch + c8 * 16 : -1;
+                // bit 30 + the channel unit in bits 20..23: `store` applies the affine (real pixels only: rows past
+                // the band / batch must stay zero)
+                dst[k] = in ? ((a.y_off + m * a.ypitch + c8 * 16) | ((ok && a.y_scale) ? ((1 << 30) | (c8 << 20)) : 0)) : -1;
             }
         }
     };
     auto store = [&](const u32x4_t (&v)[NLD], const int (&dst)[NLD]) {
 #pragma unroll
         for (int k = 0; k < NLD; ++k)
-            if (dst[k] >= 0) *(u32x4_t*)(smem + dst[k]) = v[k];
+            if (dst[k] >= 0) {
+                u32x4_t o = v[k];
+                if (dst[k] & (1 << 30)) {
+                    const int cb = ((dst[k] >> 20) & 15) * 8;
+                    float f[8];
+                    unpack8(make_uint4(o[0], o[1], o[2], o[3]), f);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) f[e] = fmaf(f[e], sAff[cb + e], sAff[TN + cb + e]);
+                    const uint4 r = pack8(f);
+                    o = (u32x4_t){r.x, r.y, r.z, r.w};
+                }
+                *(u32x4_t*)(smem + (dst[k] & 0x3FFFF)) = o;
+            }
     };
     // ---- every wave walks all 32-pixel slices; its taps' accumulators stay in registers.  All of a
     // slice's fragments are fetched first (one burst of transposing LDS reads), then the MFMAs run.
@@ -489,8 +516,11 @@ DDL_API int ddl_wgrad2_lds(int IMG, int BR, int OW, int Ny, int PH, int PW, int 
 DDL_API int ddl_conv_wgrad2(const void* dy, const void* x, float* slab, long numel, int nsplit, int B, int OH,
                             int OW, int Ny, int H, int W, int Cx, int KH, int KW, int sh, int sw, int dh, int dw,
                             int pt, int pl, int n_lim, int c_lim, long sn, long st, long sc, int IMG, int BR,
-                            int xpitch, int ypitch, int TN, int TC, int TPW, int NW, int ngroups, int frag, hipStream_t s) {
+                            int xpitch, int ypitch, int TN, int TC, int TPW, int NW, int ngroups, int frag,
+                            const float* y_scale, const float* y_shift, int y_ctrue, hipStream_t s) {
     if (Ny % 8 || Cx % 8 || nsplit < 1 || IMG < 1 || BR < 1 || ngroups < 1) return -1;
+    if ((y_scale == nullptr) != (y_shift == nullptr) || (y_scale && (y_ctrue < 0 || y_ctrue > Ny || TN > 128))) return -1;
+    if (y_scale && ((frag >> 1) & 1)) return -6;          // the LDS-DMA forms move dY without touching it
     if ((long)B * OH * OW * Ny >= (1L << 31) || (long)B * H * W * Cx >= (1L << 31)) return -3;
     const bool dma = (frag >> 1) & 1;          // bit 1 of `frag`: LDS-DMA staging, double-buffered
     frag &= 1;
@@ -527,7 +557,10 @@ DDL_API int ddl_conv_wgrad2(const void* dy, const void* x, float* slab, long num
         a.k_off = a.t_off + ((a.Mmax * 4 + 15) / 16 * 16);
     }
     size_t smem = (size_t)a.k_off + (size_t)(KH * KW * 4 + 15) / 16 * 16;
-    if (smem > 160 * 1024) return -2;
+    a.y_scale = y_scale; a.y_shift = y_shift; a.y_ctrue = y_ctrue; a.a_off = (int)smem;
+    if (y_scale) smem += (size_t)2 * TN * 4;
+    if (smem > 160 * 1024) return y_scale ? -6 : -2;      // -6: the caller materialises the operand instead
+    if (smem >= (1 << 18)) return -2;                      // (staging packs LDS offsets into 18 bits)
     int tiles_n = (n_lim + TN - 1) / TN;
     a.tiles_c = (c_lim + TC - 1) / TC;
     a.ngroups = ngroups;

@@ -520,6 +520,13 @@ class ConvOp(Op):
                                            x_affine=(sc.reshape(-1), sh.reshape(-1), ctrue))
                             self._bias_grad(dy)
                             return
+                        if groups == 1:
+                            # our input is the core problem's dY operand: the persistent kernel applies the BatchNorm
+                            # as it stages the tile (no 12 MB .. 8 GB tensor rebuilt just to be read once)
+                            hip.conv_wgrad(dy, x, g, "B", out=self.gkernel,
+                                           dy_affine=(sc.reshape(-1), sh.reshape(-1), ctrue))
+                            self._bias_grad(dy)
+                            return
                         xx = hip.bn_apply(x, sc, sh, None, 0.3, ctrue, groups)      # rebuild it (on the wgrad branch)
                     F.conv_wgrad(dy, xx, g, "B", out=self.gkernel)
                     self._bias_grad(dy)

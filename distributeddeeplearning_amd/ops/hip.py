@@ -101,7 +101,7 @@ _wgrad_ksplit = _sig("ddl_wgrad_ksplit", ci, ci, ci, ci, ci)
 _wgrad = _sig("ddl_conv_wgrad", ci, vp, vp, vp, vp, cl, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci,
               ci, ci, ci, ci, cl, cl, cl, vp, vp, ci, ci, cl, ci, vp)
 _wgrad2 = _sig("ddl_conv_wgrad2", ci, vp, vp, vp, cl, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci,
-               cl, cl, cl, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, vp)
+               cl, cl, cl, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, vp, vp, ci, vp)
 _wgrad2_frag_elems = _sig("ddl_wgrad2_frag_elems", cl, ci, ci, ci, ci, ci, ci, ci)
 _slab_reduce_frag = _sig("ddl_slab_reduce_frag", ci, vp, vp, ci, ci, ci, ci, ci, ci, ci, ci, ci, cl, cl, cl, vp)
 _wgrad2_lds = _sig("ddl_wgrad2_lds", ci, ci, ci, ci, ci, ci, ci, ci, ci, ci)
@@ -2198,7 +2198,11 @@ def _box_slab(holder, n, box, device):
     return slab
 
 
-def conv_wgrad(x, dy, g: ConvGeom, layout="A", out=None, box=None, x_affine=None, slab_holder=None, bias_tail=None):
+W2_DY_AFFINE = os.environ.get("DDL_W2_DY_AFFINE", "1") == "1"
+
+
+def conv_wgrad(x, dy, g: ConvGeom, layout="A", out=None, box=None, x_affine=None, slab_holder=None, bias_tail=None,
+               dy_affine=None):
     """`box` = (n_lim, c_lim, sn, st, sc, numel): write dW[n][t][c] at out[n*sn + t*st + c*sc] instead of one of
     the two standard layouts (the caller guarantees `out` has `numel` elements and is zero elsewhere).
     `x_affine` = (scale, shift, c_true), fp32 [Ip]: X is read as bf16(X * scale + shift) on real pixels (a
@@ -2208,25 +2212,36 @@ def conv_wgrad(x, dy, g: ConvGeom, layout="A", out=None, box=None, x_affine=None
     `bias_tail` = ("row", row, off): sum_m dY[m][row] (one row of the dY operand summed over all pixels, from one more
     MFMA against a fragment of ones) is written at out[off] -- the scalar bias gradient of a one-channel transposed
     conv, whose dY operand is the taps tensor of the image gradient (row = the centre tap).
-    `bias_tail` = ("rows", off): the same for every row n < n_lim, at out[off + n] (a Dense layer's bias gradient)."""
+    `bias_tail` = ("rows", off): the same for every row n < n_lim, at out[off + n] (a Dense layer's bias gradient).
+    `dy_affine` = (scale, shift, c_true), fp32 [Op]: the dY OPERAND is read as bf16(dY * scale + shift) on real pixels
+    (channels >= c_true as zero) -- the weight gradient of a transposed convolution, whose input plays dY here, behind a
+    BatchNorm that was applied on load.  The register-staged persistent kernel applies it as it stages the tile; where
+    no such plan exists the operand is materialised first."""
     _chk_act(x, "x")
     _chk_act(dy, "dy")
     B = x.shape[0]
     Ip, Op = pad8(g.I), pad8(g.O)
     if tuple(x.shape) != (B, g.H, g.W, Ip) or tuple(dy.shape) != (B, g.OH, g.OW, Op):
         raise ValueError(f"conv_wgrad: x {tuple(x.shape)} / dy {tuple(dy.shape)} vs geometry {g}")
+    if dy_affine is not None:
+        _chk_f32(dy_affine[0], Op, "dy_affine scale")
+        _chk_f32(dy_affine[1], Op, "dy_affine shift")
+        usable = W2_DY_AFFINE and WGRAD_IMPL == "wgrad2" and bias_tail is None and x_affine is None and not g.depthwise
+        if not usable:
+            dy = bn_apply(dy, dy_affine[0], dy_affine[1], None, 0.3, int(dy_affine[2]), 1)
+            dy_affine = None
     ranges = _batch_ranges(B, max(g.H * g.W * Ip, g.OH * g.OW * Op))
     if ranges is not None:                      # sum of the per-slice gradients (fp32)
         total = None
         for b0, b1 in ranges:
             if total is None:
-                total = conv_wgrad(x[b0:b1], dy[b0:b1], g, layout, out, box, x_affine, slab_holder, bias_tail)
+                total = conv_wgrad(x[b0:b1], dy[b0:b1], g, layout, out, box, x_affine, slab_holder, bias_tail, dy_affine)
             else:
                 part = torch.empty_like(total)
                 if box is not None:
                     zero_(part)
                 add_f32_(total.reshape(-1), conv_wgrad(x[b0:b1], dy[b0:b1], g, layout, part, box, x_affine,
-                                                       slab_holder, bias_tail).reshape(-1))
+                                                       slab_holder, bias_tail, dy_affine).reshape(-1))
         return total
     dev = x.device
     T = g.KH * g.KW
@@ -2272,6 +2287,14 @@ def conv_wgrad(x, dy, g: ConvGeom, layout="A", out=None, box=None, x_affine=None
     _chk_f32(out, numel, "dW")
     plans = _wgrad2_plans(g, B, Ip, Op, n_lim, c_lim) \
         if (WGRAD_IMPL == "wgrad2" and bias_tail is None and x_affine is None) else []
+    if dy_affine is not None:
+        # only the register-staged forms touch the operand (plans are filtered, so their indices -- what a recorded
+        # choice holds -- are those of this filtered list: the choice key below carries the affine flag)
+        plans = [pl for pl in plans if not pl.get("DMA")]
+        if not plans:
+            dy = bn_apply(dy, dy_affine[0], dy_affine[1], None, 0.3, int(dy_affine[2]), 1)
+            dy_affine = None
+            plans = _wgrad2_plans(g, B, Ip, Op, n_lim, c_lim)
     if bias_tail is not None and box is None:
         raise ValueError("conv_wgrad: bias_tail needs a custom box")
     bcol, boff, brow = -1, 0, -1
@@ -2306,7 +2329,9 @@ def conv_wgrad(x, dy, g: ConvGeom, layout="A", out=None, box=None, x_affine=None
                      g.KH, g.KW, g.sh, g.sw, g.dh, g.dw, g.pt, g.pl, n_lim, c_lim, sn, st, sc, pl["IMG"], pl["BR"],
                      pl["xp"], pl["yp"], pl["TN"], pl["TC"], pl["TPW"], pl["NW"], pl["ngroups"],
                      (1 if W2_FRAG_SLAB else 0) | (2 if pl.get("DMA") else 0),
-                     _stream())
+                     None if dy_affine is None else dy_affine[0].data_ptr(),
+                     None if dy_affine is None else dy_affine[1].data_ptr(),
+                     0 if dy_affine is None else int(dy_affine[2]), _stream())
         if rc:
             raise ValueError(f"conv_wgrad2 rejected its plan (rc={rc}): {g} {pl}")
         if W2_FRAG_SLAB:
@@ -2331,15 +2356,17 @@ def conv_wgrad(x, dy, g: ConvGeom, layout="A", out=None, box=None, x_affine=None
             raise ValueError(f"conv_wgrad rejected the problem (rc={rc}): {g}")
 
     if plans:
-        key = ("wgrad", g, B, Ip, Op, n_lim, c_lim, sn, st, sc)
-        kstr = _kstr("wgrad", g, B, Ip, Op, n_lim, c_lim, sn, st, sc, len(plans))
+        aff = 0 if dy_affine is None else 1
+        key = ("wgrad", g, B, Ip, Op, n_lim, c_lim, sn, st, sc, aff)
+        kstr = _kstr("wgrad", g, B, Ip, Op, n_lim, c_lim, sn, st, sc, len(plans), aff)
         choice = _CONV_CHOICE.get(key)
-        if choice is None and kstr in _CHOICE_SPEC and -1 <= int(_CHOICE_SPEC[kstr][1]) < len(plans):
+        if choice is None and kstr in _CHOICE_SPEC and (-1 if dy_affine is None else 0) <= int(_CHOICE_SPEC[kstr][1]) < len(plans):
             choice = _CONV_CHOICE[key] = int(_CHOICE_SPEC[kstr][1])
         if choice is None:
             if AUTOTUNE and not torch.cuda.is_current_stream_capturing():
                 timed = [(_time_us(lambda pl=pl: run_w2(pl)), i) for i, pl in enumerate(plans)]
-                timed.append((_time_us(run_w1), -1))
+                if dy_affine is None:       # (the streaming kernel has no affine on this operand)
+                    timed.append((_time_us(run_w1), -1))
                 timed.sort()
                 choice = timed[0][1]
                 _record_choice(kstr, ["wgrad", choice])

@@ -1441,3 +1441,26 @@ def test_pconv_eight_wave_blocks_match_four_wave_blocks(hip, shape, B):
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
     close(host(hip, outs[1][0], O), cpu_ref.conv_fprop(xh, wh, bias, g, "leaky", 0.3))
     close(host(hip, outs[1][1], O), cpu_ref.conv_fprop(xh, wh, bias, g, "tanh"))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B", [6, 300])
+def test_wgrad2_applies_a_batchnorm_to_the_dy_operand_on_load(hip, B):
+    """conv_wgrad(dy_affine=...): the persistent weight-gradient kernel stages its dY operand as bf16(dY * scale + shift)
+    (channels >= c_true zero) -- the weight gradient of a transposed convolution behind a BatchNorm applied on load.
+    Bit-identical to the gradient taken from the materialised operand with the same plan set."""
+    g = G.conv2d_geom(28, 28, 32, 64, (5, 5), (2, 2), (1, 1), "same")      # core geometry of convT 14x14x64 -> 28x28x32
+    torch.manual_seed(86)
+    xd = dev(hip, r16(torch.randn(B, 28, 28, 32)))                          # core X: the layer's output gradient
+    yd = dev(hip, r16(torch.randn(B, 14, 14, 64)))                          # core dY: the layer's input, before its BatchNorm
+    ctrue = 61
+    sc, sh = (torch.rand(64) + 0.5).cuda(), (torch.randn(64) * 0.3).cuda()
+    ym = hip.bn_apply(yd, sc, sh, None, 0.3, ctrue, 1)
+    ref = hip.conv_wgrad(xd, ym, g, "B")
+    got = hip.conv_wgrad(xd, yd, g, "B", dy_affine=(sc, sh, ctrue))
+    assert got.shape == ref.shape
+    assert torch.allclose(got, ref, rtol=1e-5, atol=1e-5 * float(ref.abs().max()))
+    # and against the fp32 oracle
+    ymh = host(hip, ym, 64)
+    dw = cpu_ref.conv_wgrad(host(hip, xd, 32), ymh, g).permute(3, 1, 2, 0)
+    close(got[..., :64].cpu(), dw, rtol=2e-2)
